@@ -1,0 +1,65 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+class Tiny:
+    """A golden fixture: two tiny ResNets, their spec, data and the reference's outputs."""
+
+    def __init__(self, fname):
+        from pleas_merging_amd import resnet as zoo
+        from pleas_merging_amd.core.utils import spec_from_json
+
+        self.z = np.load(os.path.join(GOLDEN, fname))
+        self.block = str(self.z["block"])
+        self.spec = spec_from_json(json.loads(str(self.z["spec_json"])))
+        self.m1, self.m2 = (self._model(zoo, p) for p in ("m1", "m2"))
+
+    def _model(self, zoo, prefix):
+        m = zoo.tiny_resnet(self.block, (1, 1, 1, 1), num_classes=10, width=4)
+        m.load_state_dict(self.state(prefix))
+        return m.eval()
+
+    def state(self, prefix):
+        return {k[len(prefix) + 1:]: torch.from_numpy(self.z[k]) for k in self.z.files if k.startswith(prefix + "/")}
+
+    def batches(self, prefix="x"):
+        n = len([k for k in self.z.files if k.startswith(prefix + "/")])
+        return [(torch.from_numpy(self.z["%s/%d" % (prefix, i)]), torch.zeros(4, dtype=torch.long)) for i in range(n)]
+
+    def per_key(self, prefix):
+        from pleas_merging_amd.core.utils import Axis
+
+        return {k: torch.from_numpy(self.z["%s/%s" % (prefix, k)]) for k in self.spec}
+
+
+@pytest.fixture(scope="session")
+def tiny_basic():
+    return Tiny("tiny_basic.npz")
+
+
+@pytest.fixture(scope="session")
+def tiny_bottleneck():
+    return Tiny("tiny_bottleneck.npz")
