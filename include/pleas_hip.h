@@ -1,0 +1,123 @@
+/*
+ * pleas_hip.h -- C ABI of libpleas_hip.so: the MI355X (gfx950) kernels behind the
+ * PLeaS activation-matching + least-squares merging hot path.
+ *
+ * Conventions (all entry points):
+ *   - plain C types only; every data pointer is a DEVICE pointer borrowed for the
+ *     duration of the call unless marked HOST; nothing is retained after return;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream) and the call returns without synchronising;
+ *   - no hidden device allocation: scratch comes from a caller-sized workspace
+ *     (`*_ws_bytes` tells how much);
+ *   - return value: 0 on success, negative PLEAS_E* on error; never throws.
+ *
+ * The reference has no native code: each entry point replaces the
+ * vendor-library kernels that the cited reference Python line dispatches to.
+ */
+#ifndef PLEAS_HIP_H
+#define PLEAS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLEAS_OK 0
+#define PLEAS_EINVAL (-22)   /* bad argument (shape, null pointer, unsupported size) */
+#define PLEAS_ENOMEM (-12)   /* workspace too small */
+#define PLEAS_EHIP (-5)      /* a HIP runtime call failed (see pleas_last_error) */
+
+/* Library / build identification: "pleas_hip <version> gfx950". */
+const char* pleas_version(void);
+/* Text of the last HIP error seen by this thread's calls ("" if none). */
+const char* pleas_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * Cross features: Gram / negative Euclidean distance between the channels of two
+ * activation (or weight) tensors, accumulated into a C x C matrix.
+ *
+ * Replaces: pleas/methods/activation_matching.py:31-46 (cross_features_cdist:
+ *   movedim+reshape copies, torch.cdist mm-path) and :14-28 (cross_features_inner_product),
+ *   plus the per-batch / per-node accumulation at :123-127 and :129-134.
+ *
+ * x, y: contiguous fp32 tensors viewed as [B][C][HW] (for NCHW activations: B = batch,
+ *   HW = H*W; for axis `a` of any contiguous tensor: B = prod(shape[:a]), C = shape[a],
+ *   HW = prod(shape[a+1:])).  The contraction runs over all (b, hw).
+ * epilogue: PLEAS_EPI_INNER  -> v = sum_k x_ik y_jk
+ *           PLEAS_EPI_NEG_CDIST -> v = -sqrt(max(0, |x_i|^2 + |y_j|^2 - 2 sum_k x_ik y_jk))
+ * accumulate: 0 -> acc = v ; 1 -> acc += v           (acc: C x C fp32, row-major)
+ * ws: workspace of at least pleas_gram_ws_bytes(B, C, HW) bytes.
+ * Deterministic: a fixed (B, C, HW) always reduces in the same order.
+ */
+#define PLEAS_EPI_INNER 0
+#define PLEAS_EPI_NEG_CDIST 1
+size_t pleas_gram_ws_bytes(int B, int C, int64_t HW);
+int pleas_gram_accum(const float* x, const float* y, int B, int C, int64_t HW, int epilogue, int accumulate,
+                     float* acc, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Batched linear assignment (square, dense), one workgroup per problem.
+ *
+ * Replaces: pleas/core/solvers.py:18-33 (scipy_solve_lsa -> D2H copy +
+ *   scipy.optimize.linear_sum_assignment), called at activation_matching.py:173 and
+ *   weight_matching.py:78.
+ *
+ * cost[p]   : DEVICE pointer to an n[p] x n[p] row-major fp32 matrix (HOST array of pointers)
+ * n[p]      : HOST array, 1 <= n[p] <= PLEAS_LSAP_MAX_N
+ * col_ind[p]: DEVICE pointer to n[p] int64 (HOST array of pointers); on completion row i is
+ *             assigned to column col_ind[p][i]
+ * Arithmetic: costs are widened to fp64; duals and path lengths are fp64; the scan order and
+ * tie rule are those of scipy's shortest-augmenting-path solver, so the output is the same
+ * assignment scipy returns, including on degenerate (tied) inputs.
+ */
+#define PLEAS_LSAP_MAX_N 2048
+int pleas_lsap_batched(const float* const* cost, const int* n, int nprob, int maximize, int64_t* const* col_ind,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Block gather / average used by partial merging and by the PLeaS regression targets.
+ *
+ * Replaces: pleas/methods/partial_matching.py:122-129 (1-axis tensors) and :157-172
+ *   (2-axis block matrix), and pleas/methods/pleas_merging.py:116-147 (index_select x8 + cat).
+ *
+ * Tensors are viewed as [outer][rows][cols][inner] (contiguous).  For every output
+ * (o, r, c, i):   out = coef(r) * ( [row1[r]>=0 && col1[c]>=0] w1[o, row1[r], col1[c], i]
+ *                                 + [row2[r]>=0 && col2[c]>=0] w2[o, row2[r], col2[c], i] )
+ * with coef(r) = 0.5 for r < n_merged_rows and 1 otherwise.  row1/row2 (length rows_out) and
+ * col1/col2 (length cols_out) are DEVICE int32 maps with -1 = "absent"; col1 == NULL means
+ * cols are passed through unchanged (cols_out must equal cols_src).
+ */
+int pleas_merge_blocks(const float* w1, const float* w2, float* out, int64_t outer, int rows_out, int cols_out,
+                       int64_t inner, int rows_src, int cols_src, const int32_t* row1, const int32_t* row2,
+                       const int32_t* col1, const int32_t* col2, int n_merged_rows, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Fused masked Adam step over a flat parameter arena.
+ *
+ * Replaces: pleas/methods/pleas_merging.py:288-291 (`param.grad *= mask` for every
+ *   parameter, then torch.optim.Adam.step with default betas/eps, no weight decay).
+ *
+ * g <- g * mask (mask may be NULL = all ones); m <- m + (1-b1)(g - m); v <- b2 v + (1-b2) g g;
+ * p <- p - (lr / (1 - b1^step)) * m / (sqrt(v) / sqrt(1 - b2^step) + eps).   step counts from 1.
+ */
+int pleas_masked_adam(float* p, const float* g, const float* mask, float* m, float* v, int64_t n, float lr,
+                      float b1, float b2, float eps, int step, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Squared-error reduction: out[0] (+)= scale * sum_k (a[k] - b[k])^2 ; also writes
+ * diff[k] = dscale * (a[k] - b[k]) if diff != NULL.
+ *
+ * Replaces: pleas/methods/pleas_merging.py:282 (`((out - target)**2).mean()`) and the
+ *   first node of its autograd backward (2 (out - target) / numel).
+ * ws: at least pleas_sqerr_ws_bytes(n) bytes.  Deterministic two-stage reduction.
+ */
+size_t pleas_sqerr_ws_bytes(int64_t n);
+int pleas_sqerr(const float* a, const float* b, int64_t n, float scale, int accumulate, float* out, float dscale,
+                float* diff, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLEAS_HIP_H */

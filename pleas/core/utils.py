@@ -1,0 +1,4 @@
+from pleas_merging_amd.core.utils import *  # noqa: F401,F403
+from pleas_merging_amd.core.utils import (Axis, PermutationGroup, PermutationSpec, Permutation, StateDict,  # noqa: F401
+                                          apply_perm, make_identity_perm, make_random_perm, invert_perm, perm_eq,
+                                          get_attr, set_attr, UnionFind)

@@ -1,0 +1,59 @@
+"""ctypes binding of libpleas_hip.so (the C-ABI in include/pleas_hip.h).
+
+There is no fallback: if the library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+from typing import Optional
+
+_LIB: Optional[ctypes.CDLL] = None
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libpleas_hip.so")
+
+EPI_INNER, EPI_NEG_CDIST = 0, 1
+LSAP_MAX_N = 2048
+
+# name -> (restype, argtypes); one row per symbol declared in include/pleas_hip.h
+SIGNATURES = {
+    "pleas_version": (c_char_p, []),
+    "pleas_last_error": (c_char_p, []),
+    "pleas_gram_ws_bytes": (c_size_t, [c_int, c_int, c_int64]),
+    "pleas_gram_accum": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_size_t,
+                                 c_void_p]),
+    "pleas_lsap_batched": (c_int, [POINTER(c_void_p), POINTER(c_int), c_int, c_int, POINTER(c_void_p), c_void_p]),
+    "pleas_merge_blocks": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int, c_int, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "pleas_masked_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
+                                  c_float, c_int, c_void_p]),
+    "pleas_sqerr_ws_bytes": (c_size_t, [c_int64]),
+    "pleas_sqerr": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_int, c_void_p, c_float, c_void_p, c_void_p, c_size_t,
+                            c_void_p]),
+}
+
+
+class PleasHipError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """Load the library once; raise loudly when it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise PleasHipError(
+                "libpleas_hip.so is missing (%s). Build it with `python -m pleas_merging_amd.build` "
+                "(needs hipcc); there is no CPU fallback for the HIP path." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the build lacks a declared symbol
+            fn.restype, fn.argtypes = restype, argtypes
+        _LIB = handle
+    return _LIB
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().pleas_last_error().decode() or "error code %d" % rc
+        raise PleasHipError("%s failed (%d): %s" % (what, rc, msg))

@@ -356,8 +356,11 @@ def trace_with_shapes(model: nn.Module, inputs_or_shapes: InputsOrShapes) -> tor
     shapes = [tuple(s) if isinstance(s, (tuple, list, torch.Size)) else tuple(s.shape) for s in inputs_or_shapes]
     from torch._subclasses.fake_tensor import FakeTensorMode
 
+    params = list(model.parameters())
+    device = params[0].device if params else torch.device("cpu")
+
     with FakeTensorMode(allow_non_fake_inputs=True) as mode:
-        fake_inputs = [torch.empty(s) for s in shapes]
+        fake_inputs = [torch.empty(s, device=device) for s in shapes]
         was_training = gm.training
         gm.eval()  # BN in eval: no running-stat side effects on fake tensors
         try:

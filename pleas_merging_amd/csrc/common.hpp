@@ -1,0 +1,39 @@
+// Shared host-side helpers of libpleas_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "pleas_hip.h"
+
+namespace pleas {
+
+extern thread_local char g_last_error[256];
+
+inline int hip_fail(hipError_t e, const char* what) {
+    std::snprintf(g_last_error, sizeof(g_last_error), "%s: %s", what, hipGetErrorString(e));
+    return PLEAS_EHIP;
+}
+
+inline int bad_arg(const char* what) {
+    std::snprintf(g_last_error, sizeof(g_last_error), "invalid argument: %s", what);
+    return PLEAS_EINVAL;
+}
+
+#define PLEAS_HIP_CHECK(expr)                                  \
+    do {                                                       \
+        hipError_t e_ = (expr);                                \
+        if (e_ != hipSuccess) return ::pleas::hip_fail(e_, #expr); \
+    } while (0)
+
+#define PLEAS_LAUNCH_CHECK(name)                                   \
+    do {                                                           \
+        hipError_t e_ = hipGetLastError();                         \
+        if (e_ != hipSuccess) return ::pleas::hip_fail(e_, name);  \
+    } while (0)
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace pleas

@@ -1,0 +1,204 @@
+// HBM-bound streaming kernels of the merging path (gfx950): block gather/average, fused
+// masked Adam, squared-error reduction.  All are coalesced 16-B-per-lane streams where the
+// layout allows, grid-strided over <= 2048 workgroups (8 per CU).
+#include <algorithm>
+#include <cmath>
+
+#include "common.hpp"
+
+namespace pleas {
+
+thread_local char g_last_error[256] = "";
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kEwThreads = 256;
+constexpr int kEwMaxBlocks = 2048;
+
+static inline unsigned ew_grid(int64_t work_items) {
+    return (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(work_items, kEwThreads), kEwMaxBlocks));
+}
+
+// ------------------------------------------------------------------------------------------
+// out[o][r][c][i] = coef(r) * ([row1[r],col1[c] present] w1[o][row1[r]][col1[c]][i] + same for w2)
+// One thread per (o, r, c, i4) where i4 indexes VEC-wide pieces of the contiguous `inner` run.
+template <int VEC>
+__global__ __launch_bounds__(kEwThreads) void merge_blocks_kernel(
+    const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ out, int64_t outer, int rows_out,
+    int cols_out, int64_t inner, int rows_src, int cols_src, const int32_t* __restrict__ row1,
+    const int32_t* __restrict__ row2, const int32_t* __restrict__ col1, const int32_t* __restrict__ col2,
+    int n_merged_rows) {
+    const int64_t inner_v = inner / VEC;
+    const int64_t total = outer * rows_out * (int64_t)cols_out * inner_v;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t iv = idx % inner_v;
+        int64_t t = idx / inner_v;
+        const int c = (int)(t % cols_out);
+        t /= cols_out;
+        const int r = (int)(t % rows_out);
+        const int64_t o = t / rows_out;
+        const int r1 = row1[r], r2 = row2[r];
+        const int c1 = col1 ? col1[c] : c, c2 = col2 ? col2[c] : c;
+        const float coef = r < n_merged_rows ? 0.5f : 1.0f;
+        float a[VEC], b[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a[e] = b[e] = 0.f;
+        if (r1 >= 0 && c1 >= 0) {
+            const float* src = w1 + ((o * rows_src + r1) * cols_src + c1) * inner + iv * VEC;
+            if constexpr (VEC == 4) {
+                const f32x4 q = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = q[e];
+            } else {
+                a[0] = src[0];
+            }
+        }
+        if (r2 >= 0 && c2 >= 0) {
+            const float* src = w2 + ((o * rows_src + r2) * cols_src + c2) * inner + iv * VEC;
+            if constexpr (VEC == 4) {
+                const f32x4 q = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b[e] = q[e];
+            } else {
+                b[0] = src[0];
+            }
+        }
+        float* dst = out + ((o * rows_out + r) * cols_out + c) * inner + iv * VEC;
+        if constexpr (VEC == 4) {
+            f32x4 q;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q[e] = (a[e] + b[e]) * coef;
+            *reinterpret_cast<f32x4*>(dst) = q;
+        } else {
+            dst[0] = (a[0] + b[0]) * coef;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kEwThreads) void masked_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                                 const float* __restrict__ mask, float* __restrict__ m,
+                                                                 float* __restrict__ v, int64_t n, float one_minus_b1,
+                                                                 float b2, float one_minus_b2, float step_size,
+                                                                 float bc2_sqrt, float eps) {
+    // Same operation order as torch's single-tensor Adam: lerp for m, mul+addcmul for v,
+    // (sqrt(v) / sqrt(bc2) + eps) denominator, addcdiv update.
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float gi = g[i];
+        if (mask) gi *= mask[i];
+        float mi = m[i];
+        mi = mi + one_minus_b1 * (gi - mi);
+        float vi = v[i] * b2;
+        vi = vi + one_minus_b2 * gi * gi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] - (step_size * mi) / denom;
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+constexpr int kSqBlocks = 1024;
+
+__global__ __launch_bounds__(kEwThreads) void sqerr_partial_kernel(const float* __restrict__ a,
+                                                                   const float* __restrict__ b, int64_t n, float dscale,
+                                                                   float* __restrict__ diff, float* __restrict__ part) {
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = a[i] - b[i];
+        s = fmaf(d, d, s);
+        if (diff) diff[i] = dscale * d;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    __shared__ float ws[kEwThreads / 64];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < kEwThreads / 64; ++w) t += ws[w];
+        part[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(64) void sqerr_final_kernel(const float* __restrict__ part, int nparts, float scale,
+                                                         int accumulate, float* __restrict__ out) {
+    // fp64 combine of <= 1024 partials in a fixed order (one wave)
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 64) s += (double)part[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if (threadIdx.x == 0) {
+        const float r = (float)(s * (double)scale);
+        out[0] = accumulate ? out[0] + r : r;
+    }
+}
+
+}  // namespace pleas
+
+using namespace pleas;
+
+extern "C" const char* pleas_version(void) { return "pleas_hip 0.1.0 gfx950"; }
+extern "C" const char* pleas_last_error(void) { return g_last_error; }
+
+extern "C" int pleas_merge_blocks(const float* w1, const float* w2, float* out, int64_t outer, int rows_out,
+                                  int cols_out, int64_t inner, int rows_src, int cols_src, const int32_t* row1,
+                                  const int32_t* row2, const int32_t* col1, const int32_t* col2, int n_merged_rows,
+                                  void* stream_) {
+    if (!w1 || !w2 || !out || !row1 || !row2) return bad_arg("null pointer");
+    if (outer < 0 || rows_out < 0 || cols_out < 0 || inner <= 0 || rows_src <= 0 || cols_src <= 0)
+        return bad_arg("negative size");
+    if ((col1 == nullptr) != (col2 == nullptr)) return bad_arg("col1/col2 must both be given or both NULL");
+    if (!col1 && cols_out != cols_src) return bad_arg("cols_out != cols_src without column maps");
+    const int64_t total = outer * rows_out * (int64_t)cols_out * inner;
+    if (total == 0) return PLEAS_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    const bool vec = inner % 4 == 0 && ((((uintptr_t)w1 | (uintptr_t)w2 | (uintptr_t)out) & 15) == 0);
+    if (vec)
+        hipLaunchKernelGGL((merge_blocks_kernel<4>), dim3(ew_grid(total / 4)), dim3(kEwThreads), 0, stream, w1, w2, out,
+                           outer, rows_out, cols_out, inner, rows_src, cols_src, row1, row2, col1, col2, n_merged_rows);
+    else
+        hipLaunchKernelGGL((merge_blocks_kernel<1>), dim3(ew_grid(total)), dim3(kEwThreads), 0, stream, w1, w2, out,
+                           outer, rows_out, cols_out, inner, rows_src, cols_src, row1, row2, col1, col2, n_merged_rows);
+    PLEAS_LAUNCH_CHECK("merge_blocks_kernel");
+    return PLEAS_OK;
+}
+
+extern "C" int pleas_masked_adam(float* p, const float* g, const float* mask, float* m, float* v, int64_t n, float lr,
+                                 float b1, float b2, float eps, int step, void* stream_) {
+    if (!p || !g || !m || !v) return bad_arg("null pointer");
+    if (n < 0 || step < 1) return bad_arg("n < 0 or step < 1");
+    if (n == 0) return PLEAS_OK;
+    // scalars prepared in double exactly like torch.optim.Adam (_single_tensor_adam)
+    const double bc1 = 1.0 - std::pow((double)b1, step);
+    const double bc2 = 1.0 - std::pow((double)b2, step);
+    const double step_size = (double)lr / bc1;
+    const double bc2_sqrt = std::sqrt(bc2);
+    hipLaunchKernelGGL(masked_adam_kernel, dim3(ew_grid(n)), dim3(kEwThreads), 0, (hipStream_t)stream_, p, g, mask, m, v,
+                       n, (float)(1.0 - (double)b1), b2, (float)(1.0 - (double)b2), (float)step_size,
+                       (float)bc2_sqrt, eps);
+    PLEAS_LAUNCH_CHECK("masked_adam_kernel");
+    return PLEAS_OK;
+}
+
+extern "C" size_t pleas_sqerr_ws_bytes(int64_t n) {
+    (void)n;
+    return kSqBlocks * sizeof(float);
+}
+
+extern "C" int pleas_sqerr(const float* a, const float* b, int64_t n, float scale, int accumulate, float* out,
+                           float dscale, float* diff, void* ws, size_t ws_bytes, void* stream_) {
+    if (!a || !b || !out) return bad_arg("null pointer");
+    if (n < 0) return bad_arg("n < 0");
+    if (!ws || ws_bytes < pleas_sqerr_ws_bytes(n)) return PLEAS_ENOMEM;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, kEwThreads), kSqBlocks));
+    hipLaunchKernelGGL(sqerr_partial_kernel, dim3(blocks), dim3(kEwThreads), 0, stream, a, b, n, dscale, diff,
+                       (float*)ws);
+    PLEAS_LAUNCH_CHECK("sqerr_partial_kernel");
+    hipLaunchKernelGGL(sqerr_final_kernel, dim3(1), dim3(64), 0, stream, (const float*)ws, blocks, scale, accumulate,
+                       out);
+    PLEAS_LAUNCH_CHECK("sqerr_final_kernel");
+    return PLEAS_OK;
+}

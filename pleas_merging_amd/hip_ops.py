@@ -1,0 +1,191 @@
+"""Tensor-level wrappers over the C-ABI (include/pleas_hip.h).
+
+PyTorch is used for device memory and streams only: every function here enqueues a
+hand-written gfx950 kernel on torch's current stream via ctypes.  Inputs must be fp32
+CUDA(=HIP) tensors; anything else raises -- there is no eager/CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import EPI_INNER, EPI_NEG_CDIST, PleasHipError, check
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if not t.is_cuda:
+            raise PleasHipError("HIP path needs tensors on the GPU (got device %s); no CPU fallback" % t.device)
+        if t.dtype != torch.float32:
+            raise PleasHipError("HIP path computes in fp32 (got %s)" % t.dtype)
+
+
+class Workspace:
+    """Grow-only device scratch buffer, one per device; callers never see hidden allocations
+    inside the C library."""
+
+    _per_device: dict = {}
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self.buf = torch.empty(0, dtype=torch.uint8, device=device)
+
+    @classmethod
+    def get(cls, device: torch.device) -> "Workspace":
+        key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+        if key not in cls._per_device:
+            cls._per_device[key] = cls(device)
+        return cls._per_device[key]
+
+    def reserve(self, nbytes: int) -> torch.Tensor:
+        if self.buf.numel() < nbytes:
+            # the old buffer may still be in use by queued kernels: the caching allocator keeps it
+            # alive on this stream until they have run
+            self.buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
+        return self.buf
+
+
+def _as_bchw(t: torch.Tensor, axis: int) -> Tuple[int, int, int]:
+    shape = t.shape
+    axis = axis % t.dim()
+    return math.prod(shape[:axis]), shape[axis], math.prod(shape[axis + 1:])
+
+
+# ---------------------------------------------------------------------------------------- gram / cdist
+def gram_ws_bytes(B: int, C: int, HW: int) -> int:
+    return int(_lib.lib().pleas_gram_ws_bytes(B, C, HW))
+
+
+def gram_accum(x: torch.Tensor, y: torch.Tensor, axis: int, acc: torch.Tensor, epilogue: int,
+               accumulate: bool = True) -> torch.Tensor:
+    """acc (+)= cross-features of ``x`` and ``y`` along ``axis`` (see pleas_gram_accum)."""
+    _need_gpu(x, y, acc)
+    if x.shape != y.shape:
+        raise PleasHipError("cross features need equal shapes, got %s and %s" % (tuple(x.shape), tuple(y.shape)))
+    x, y = x.contiguous(), y.contiguous()
+    B, C, HW = _as_bchw(x, axis)
+    if tuple(acc.shape) != (C, C) or not acc.is_contiguous():
+        raise PleasHipError("acc must be a contiguous (%d, %d) tensor" % (C, C))
+    need = gram_ws_bytes(B, C, HW)
+    ws = Workspace.get(x.device).reserve(need)
+    rc = _lib.lib().pleas_gram_accum(x.data_ptr(), y.data_ptr(), B, C, HW, epilogue, int(bool(accumulate)),
+                                     acc.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+    check(rc, "pleas_gram_accum")
+    return acc
+
+
+def cross_features_cdist(x: torch.Tensor, y: torch.Tensor, a: int) -> torch.Tensor:
+    """HIP drop-in for the reference's ``cross_features_cdist`` plug point
+    (pleas/methods/activation_matching.py:31-46): returns the C x C negative-distance matrix."""
+    C = x.shape[a]
+    out = torch.empty(C, C, dtype=torch.float32, device=x.device)
+    return gram_accum(x, y, a, out, EPI_NEG_CDIST, accumulate=False)
+
+
+def cross_features_inner_product(x: torch.Tensor, y: torch.Tensor, a: int) -> torch.Tensor:
+    """HIP drop-in for ``cross_features_inner_product`` (activation_matching.py:14-28)."""
+    C = x.shape[a]
+    out = torch.empty(C, C, dtype=torch.float32, device=x.device)
+    return gram_accum(x, y, a, out, EPI_INNER, accumulate=False)
+
+
+# ---------------------------------------------------------------------------------------- LAP
+def solve_lsa_batched(costs: Sequence[torch.Tensor], maximize: bool = True) -> List[torch.Tensor]:
+    """All assignment problems of a model pair in one launch; returns device int64 vectors."""
+    if not costs:
+        return []
+    _need_gpu(*costs)
+    mats = []
+    for c in costs:
+        if c.dim() != 2 or c.shape[0] != c.shape[1]:
+            raise PleasHipError("square cost matrices expected, got %s" % (tuple(c.shape),))
+        if c.shape[0] > _lib.LSAP_MAX_N:
+            raise PleasHipError("n = %d exceeds PLEAS_LSAP_MAX_N = %d" % (c.shape[0], _lib.LSAP_MAX_N))
+        mats.append(c.contiguous())
+    outs = [torch.empty(m.shape[0], dtype=torch.int64, device=m.device) for m in mats]
+    k = len(mats)
+    cost_ptrs = (ctypes.c_void_p * k)(*[m.data_ptr() for m in mats])
+    out_ptrs = (ctypes.c_void_p * k)(*[o.data_ptr() for o in outs])
+    ns = (ctypes.c_int * k)(*[m.shape[0] for m in mats])
+    rc = _lib.lib().pleas_lsap_batched(cost_ptrs, ns, k, int(bool(maximize)), out_ptrs, _stream())
+    check(rc, "pleas_lsap_batched")
+    return outs
+
+
+def hip_solve_lsa(A: torch.Tensor, maximize: bool = True) -> torch.Tensor:
+    """HIP drop-in for ``scipy_solve_lsa`` (pleas/core/solvers.py:18-33): CPU int64 ``col_ind``."""
+    return solve_lsa_batched([A], maximize)[0].cpu()
+
+
+# ---------------------------------------------------------------------------------------- merge blocks
+def merge_blocks(w1: torch.Tensor, w2: torch.Tensor, row_axis: int, row1: torch.Tensor, row2: torch.Tensor,
+                 n_merged_rows: int, col1: Optional[torch.Tensor] = None, col2: Optional[torch.Tensor] = None,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Block gather/average along ``row_axis`` (and ``row_axis + 1`` when column maps are given)."""
+    _need_gpu(w1, w2)
+    if w1.shape != w2.shape:
+        raise PleasHipError("merge_blocks needs equal source shapes")
+    w1, w2 = w1.contiguous(), w2.contiguous()
+    shape = list(w1.shape)
+    row_axis = row_axis % w1.dim()
+    outer = math.prod(shape[:row_axis])
+    rows_src = shape[row_axis]
+    rows_out = int(row1.numel())
+    if col1 is not None:
+        cols_src, cols_out = shape[row_axis + 1], int(col1.numel())
+        inner = math.prod(shape[row_axis + 2:])
+        out_shape = shape[:row_axis] + [rows_out, cols_out] + shape[row_axis + 2:]
+    else:
+        cols_src = cols_out = 1
+        inner = math.prod(shape[row_axis + 1:])
+        out_shape = shape[:row_axis] + [rows_out] + shape[row_axis + 1:]
+    maps = [row1, row2] + ([col1, col2] if col1 is not None else [])
+    for m in maps:
+        if not m.is_cuda or m.dtype != torch.int32 or not m.is_contiguous():
+            raise PleasHipError("index maps must be contiguous int32 CUDA tensors")
+    if out is None:
+        out = torch.empty(out_shape, dtype=torch.float32, device=w1.device)
+    elif list(out.shape) != out_shape or not out.is_contiguous():
+        raise PleasHipError("out has the wrong shape")
+    rc = _lib.lib().pleas_merge_blocks(
+        w1.data_ptr(), w2.data_ptr(), out.data_ptr(), outer, rows_out, cols_out, inner, rows_src, cols_src,
+        row1.data_ptr(), row2.data_ptr(), col1.data_ptr() if col1 is not None else None,
+        col2.data_ptr() if col2 is not None else None, int(n_merged_rows), _stream())
+    check(rc, "pleas_merge_blocks")
+    return out
+
+
+# ---------------------------------------------------------------------------------------- Adam / loss
+def masked_adam(p: torch.Tensor, g: torch.Tensor, mask: Optional[torch.Tensor], m: torch.Tensor, v: torch.Tensor,
+                lr: float, step: int, b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8) -> None:
+    _need_gpu(p, g, m, v)
+    n = p.numel()
+    for t in (g, m, v) + ((mask,) if mask is not None else ()):
+        if t.numel() != n or not t.is_contiguous():
+            raise PleasHipError("masked_adam operands must be contiguous and equally sized")
+    rc = _lib.lib().pleas_masked_adam(p.data_ptr(), g.data_ptr(), mask.data_ptr() if mask is not None else None,
+                                      m.data_ptr(), v.data_ptr(), n, lr, b1, b2, eps, step, _stream())
+    check(rc, "pleas_masked_adam")
+
+
+def sqerr(a: torch.Tensor, b: torch.Tensor, scale: float, out: torch.Tensor, accumulate: bool = False,
+          diff: Optional[torch.Tensor] = None, dscale: float = 1.0) -> torch.Tensor:
+    """out[0] (+)= scale * sum((a-b)^2); optionally diff = dscale * (a-b)."""
+    _need_gpu(a, b, out)
+    if a.shape != b.shape or not a.is_contiguous() or not b.is_contiguous():
+        raise PleasHipError("sqerr operands must be contiguous and equally shaped")
+    n = a.numel()
+    need = int(_lib.lib().pleas_sqerr_ws_bytes(n))
+    ws = Workspace.get(a.device).reserve(need)
+    rc = _lib.lib().pleas_sqerr(a.data_ptr(), b.data_ptr(), n, scale, int(bool(accumulate)), out.data_ptr(), dscale,
+                                diff.data_ptr() if diff is not None else None, ws.data_ptr(), ws.numel(), _stream())
+    check(rc, "pleas_sqerr")
+    return out

@@ -1,0 +1,11 @@
+"""Matching / merging methods (mirrors reference pleas/methods/__init__.py:12-35)."""
+from .activation_matching import (
+    activation_matching,
+    build_cross_module,
+    compute_matching_costs,
+    cross_features_cdist,
+    cross_features_inner_product,
+)
+from .weight_matching import weight_matching
+from .partial_matching import expand_ratios, get_blocks, partial_merge, build_partial_merge_model
+from .pleas_merging import train, get_gradient_mask

@@ -1,0 +1,234 @@
+"""Activation matching: per-group similarity of two models' activations + one LAP per group.
+
+Drop-in for the reference's ``pleas/methods/activation_matching.py``
+(``cross_features_*`` :14-46, ``build_cross_module`` :49-100,
+``compute_matching_costs`` :103-136, ``activation_matching`` :139-177).
+
+MI355X design.  Both models run under PyTorch-ROCm inside ONE fx graph (twin copies of every
+node).  Right after each tracked node -- i.e. before a following in-place ReLU can overwrite
+it -- the graph calls a *sink*.  With the default HIP cross features the sink is
+``pleas_gram_accum``: an fp32-MFMA contraction that reads both NCHW activations in place and
+adds ``-cdist`` (or the inner product) straight into the node's *group* matrix inside one
+flat fp32 arena.  No per-node C x C tensors, no Python ``sum`` over nodes, and the arena is
+what a multi-GPU run all-reduces (one RCCL call) before the batched LAP kernel solves every
+group at once.  Any other ``cross_features`` / ``lsa_solver`` callable is honoured through
+the reference's plug points (generic path).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Iterable, List, Optional, Tuple
+
+import torch
+import torch.fx
+from torch import nn
+
+from ..core.solvers import hip_solve_lsa
+from ..core.utils import Axis, Permutation, PermutationSpec
+from ..hip_ops import cross_features_cdist, cross_features_inner_product  # noqa: F401  (public plug-ins)
+
+_FUSED_EPILOGUE = {}  # callable -> epilogue id, filled below
+
+
+def _register_fused():
+    from .. import hip_ops
+
+    _FUSED_EPILOGUE[hip_ops.cross_features_cdist] = hip_ops.EPI_NEG_CDIST
+    _FUSED_EPILOGUE[hip_ops.cross_features_inner_product] = hip_ops.EPI_INNER
+
+
+_register_fused()
+
+
+# ------------------------------------------------------------------------------------------ twin graph
+def _build_twin(model1: nn.Module, model2: nn.Module, axes: Iterable[Axis], emit: Callable):
+    """Twin graph of ``model1``/``model2``; ``emit(graph, name, axis, node1, node2)`` adds the call
+    made right after tracked node ``name`` and returns the fx node that holds its value."""
+    traced = torch.fx.symbolic_trace(model1)
+    want: Dict[str, List[int]] = {}
+    for ax in axes:
+        if ax.axis not in want.setdefault(ax.key, []):
+            want[ax.key].append(ax.axis)
+
+    twin = torch.fx.Graph()
+    env = ({}, {})  # original node -> new node, per model
+    cross: Dict[Tuple[str, int], torch.fx.Node] = {}
+    result = None
+    for node in traced.graph.nodes:
+        if node.op == "placeholder":
+            shared = twin.placeholder(node.target)
+            env[0][node] = env[1][node] = shared
+            continue
+        if node.op == "output":
+            (ret,) = node.args
+            result = ([env[0][ret], env[1][ret]], cross)
+            continue
+        made = []
+        for side in (0, 1):
+            new = twin.node_copy(node, lambda n, side=side: env[side][n])
+            if node.op in ("call_module", "get_attr"):
+                new.target = "%d.%s" % (side, node.target)
+            env[side][node] = new
+            made.append(new)
+        for a in want.get(node.name, ()):
+            cross[node.name, a] = emit(twin, node.name, a, made[0], made[1])
+    twin.output(result)
+    gm = torch.fx.GraphModule(nn.ModuleList([model1, model2]), twin)
+    gm.graph.lint()
+    return gm
+
+
+def build_cross_module(model1: nn.Module, model2: nn.Module, axes: Iterable[Axis], cross_features: Callable):
+    """One GraphModule that runs ``model1`` and ``model2`` side by side on the same input and
+    calls ``cross_features(act1, act2, axis)`` right after every tracked node.
+
+    Same contract as the reference (:49-100): ``model1`` is traced and its graph reused for
+    ``model2`` (isomorphic models), submodule targets are prefixed ``0.`` / ``1.`` under a
+    ``ModuleList([model1, model2])`` root, and the module returns
+    ``([out1, out2], {(node_name, axis): cross_value})``.
+    """
+    return _build_twin(model1, model2, axes,
+                       lambda g, name, a, n1, n2: g.call_function(cross_features, (n1, n2, a)))
+
+
+class GroupArena:
+    """Flat fp32 buffer holding every group's C x C cost matrix back to back (one all-reduce)."""
+
+    def __init__(self, spec: PermutationSpec, device: torch.device):
+        self.keys = list(spec.keys())
+        sizes = [spec[k].size for k in self.keys]
+        self.flat = torch.zeros(sum(s * s for s in sizes), dtype=torch.float32, device=device)
+        self.view: Dict[Axis, torch.Tensor] = {}
+        off = 0
+        for k, s in zip(self.keys, sizes):
+            self.view[k] = self.flat[off:off + s * s].view(s, s)
+            off += s * s
+
+    def zero_(self):
+        self.flat.zero_()
+
+
+class _FusedSink:
+    """Callable placed in the twin graph: accumulates one node's cross features into its group."""
+
+    def __init__(self, arena: GroupArena, node_group: Dict[Axis, Axis], epilogue: int):
+        from .. import hip_ops
+
+        self._accum = hip_ops.gram_accum
+        self.arena, self.node_group, self.epilogue = arena, node_group, epilogue
+
+    def bind(self, node_name: str):
+        def sink(x, y, a, _name=node_name):
+            self._accum(x, y, a, self.arena.view[self.node_group[Axis(_name, a)]], self.epilogue, True)
+            return None
+
+        sink.__name__ = sink.__qualname__ = "gram_sink_%s" % node_name
+        return sink
+
+
+def build_fused_module(spec: PermutationSpec, model1: nn.Module, model2: nn.Module, arena: GroupArena, epilogue: int):
+    """Twin graph whose sinks add straight into the group arena (the HIP fast path)."""
+    node_group = {nax: key for key, group in spec.items() for nax in group.node}
+    sinks = _FusedSink(arena, node_group, epilogue)
+    return _build_twin(model1, model2, list(node_group.keys()),
+                       lambda g, name, a, n1, n2: g.call_function(sinks.bind(name), (n1, n2, a)))
+
+
+# ------------------------------------------------------------------------------------------ cost accumulation
+def _dist_info():
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def _model_device(model: nn.Module) -> torch.device:
+    return next(iter(model.parameters())).device
+
+
+def compute_matching_costs(spec: PermutationSpec, gm_cross: nn.Module, dataloader, num_batches: int,
+                           accumulate=True, device: Optional[torch.device] = None) -> Dict[Axis, torch.Tensor]:
+    """Generic path over a module built by :func:`build_cross_module` with ANY ``cross_features``
+    callable (reference: :103-136).  ``accumulate="reference"`` keeps only the last processed
+    batch, which is what the reference computes (its membership test at :123-127 compares a
+    tuple with ``Axis`` keys and never succeeds); ``True`` sums over batches."""
+    if device is None:
+        device = _model_device(gm_cross)
+    per_node: Dict[Axis, torch.Tensor] = {}
+    with torch.inference_mode():
+        for (x, _), _ in zip(dataloader, range(num_batches)):
+            _, cross = gm_cross(x.to(device))
+            for (name, a), v in cross.items():
+                ax = Axis(name, a)
+                if accumulate is True and ax in per_node:
+                    per_node[ax].add_(v)
+                else:
+                    per_node[ax] = v
+    costs = {}
+    for key, group in spec.items():
+        total = 0
+        for nax in group.node:
+            if nax in per_node:
+                total = total + per_node[nax]
+        costs[key] = total
+    return costs
+
+
+def accumulate_costs_fused(spec: PermutationSpec, model1: nn.Module, model2: nn.Module, dataloader, num_batches: int,
+                           epilogue: int, accumulate=True, shard: bool = True) -> Dict[Axis, torch.Tensor]:
+    """HIP fast path: every tracked node adds into its group matrix while the forwards run.
+
+    Data parallel: with ``torch.distributed`` initialised (one process per GPU, RCCL), rank r
+    takes batches ``b % world == r`` and the flat arena is all-reduced once at the end.  The
+    distance epilogue is applied per batch, so sharding at batch granularity is exact
+    (SURVEY.md F3).  ``accumulate="reference"`` (last batch only) does not shard.
+    """
+    device = _model_device(model1)
+    if device.type != "cuda":
+        raise RuntimeError("activation_matching: models must be on the GPU for the HIP path (got %s)" % device)
+    arena = GroupArena(spec, device)
+    gm = build_fused_module(spec, model1, model2, arena, epilogue)
+    rank, world = _dist_info() if (shard and accumulate is True) else (0, 1)
+    with torch.inference_mode():
+        for b, ((x, _), _) in enumerate(zip(dataloader, range(num_batches))):
+            if b % world != rank:
+                continue
+            if accumulate is not True:
+                arena.zero_()
+            gm(x.to(device, non_blocking=True))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.all_reduce(arena.flat, op=dist.ReduceOp.SUM)
+    return dict(arena.view)
+
+
+def solve_all(costs: Dict[Axis, torch.Tensor], lsa_solver: Callable) -> Permutation:
+    """One LAP per group.  The default solver runs all groups in ONE batched kernel launch."""
+    if lsa_solver is hip_solve_lsa:
+        from .. import hip_ops
+
+        outs = hip_ops.solve_lsa_batched(list(costs.values()), maximize=True)
+        return {k: o.cpu() for k, o in zip(costs.keys(), outs)}
+    return {k: lsa_solver(v) for k, v in costs.items()}
+
+
+def activation_matching(spec: PermutationSpec, model1: nn.Module, model2: nn.Module, dataloader, num_batches=1000,
+                        cross_features=cross_features_cdist, lsa_solver=hip_solve_lsa, output_costs=False,
+                        accumulate=True):
+    """Permutation of ``model2``'s units that best matches ``model1``'s activations.
+
+    Reference: :139-177 (same positional arguments; ``accumulate`` is the only addition,
+    ``"reference"`` reproduces the shipped last-batch-only costs).  Returns ``perm``
+    (CPU int64 per group) or ``(perm, costs)`` with fp32 costs on the compute device.
+    Does not change the models' train/eval mode and does not move them.
+    """
+    epilogue = _FUSED_EPILOGUE.get(cross_features)
+    if epilogue is not None:
+        costs = accumulate_costs_fused(spec, model1, model2, dataloader, num_batches, epilogue, accumulate)
+    else:
+        axes = [ax for group in spec.values() for ax in group.node]
+        gm = build_cross_module(model1, model2, axes, cross_features)
+        costs = compute_matching_costs(spec, gm, dataloader, num_batches, accumulate, _model_device(model1))
+    perm = solve_all(costs, lsa_solver)
+    return (perm, costs) if output_costs else perm

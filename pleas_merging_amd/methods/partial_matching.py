@@ -1,0 +1,136 @@
+"""Partial merging: which units are merged / kept apart, and the block-structured weights.
+
+Drop-in for the hot-path part of the reference's ``pleas/methods/partial_matching.py``
+(``expand_ratios`` :30-44, ``get_blocks`` :47-89, ``build_partial_merge_model`` :91-185,
+``partial_merge`` :188-202).  Tensor assembly runs in the ``pleas_merge_blocks`` HIP kernel:
+each output tensor is ONE gather/average launch driven by two (row) or four (row + column)
+int32 maps instead of the reference's chain of ``index_select`` / ``cat`` / slice-assign ops.
+"""
+from __future__ import annotations
+
+from copy import deepcopy
+from typing import Dict, Optional, Tuple, Union
+
+import torch
+from torch import nn
+
+from ..core.utils import Axis, Permutation, PermutationSpec, set_attr
+
+Ratios = Union[float, Dict[Axis, float]]
+Blocks = Dict[Axis, Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]]
+
+
+def expand_ratios(spec: PermutationSpec, ratios: Ratios) -> Dict[Axis, float]:
+    """Reference: partial_matching.py:30-44."""
+    return ratios if isinstance(ratios, dict) else {ax: ratios for ax in spec}
+
+
+def get_blocks(spec: PermutationSpec, perm: Permutation, costs: Dict[Axis, torch.Tensor], ratios: Ratios,
+               lsa_solver=None) -> Blocks:
+    """Per group: (merged idx of model 1, merged idx of model 2, separate idx 1, separate idx 2).
+
+    Reference: partial_matching.py:47-89.  Units whose matched cost reaches the ``ratio``
+    quantile (``>=``, linear interpolation) are merged; a ratio within 1e-3 of 1 forces the
+    identity pairing (and, because the maximum always satisfies ``>=``, exactly one merged
+    unit).  ``lsa_solver`` is accepted and ignored like in the reference (callers pass
+    ``False`` there).  Index tensors live on the device of the cost matrices (the reference
+    hard-codes ``.cuda()`` at :86).
+    """
+    ratios = expand_ratios(spec, ratios)
+    out: Blocks = {}
+    for key, p in perm.items():
+        r = float(ratios[key])
+        cost = costs[key]
+        n = p.numel()
+        rows = torch.arange(n, device=cost.device)
+        cols = rows if abs(r - 1.0) < 1e-3 else p.to(cost.device)
+        matched = cost[rows, cols]
+        keep = matched >= torch.quantile(matched, r)
+        out[key] = (rows[keep], cols[keep], rows[~keep], cols[~keep])
+    return out
+
+
+def spread_blocks(spec: PermutationSpec, blocks: Blocks) -> Blocks:
+    """Give every state axis of a group the group's blocks (reference :98-103)."""
+    full = dict(blocks)
+    for key, group in spec.items():
+        for ax in group.state:
+            full[ax] = blocks[key]
+    return full
+
+
+def block_maps(block: Tuple[torch.Tensor, ...], device) -> Tuple[torch.Tensor, torch.Tensor, int]:
+    """(row1, row2, n_merged) int32 source maps of ``pleas_merge_blocks`` for one axis:
+    output unit u takes model-1 unit row1[u] and/or model-2 unit row2[u] (-1 = absent);
+    layout [merged | separate-1 | separate-2] as in the reference (:125-129, :141-153)."""
+    b1, b2, b1c, b2c = (t.to(device=device, dtype=torch.int32) for t in block)
+    absent1 = torch.full_like(b2c, -1)
+    absent2 = torch.full_like(b1c, -1)
+    row1 = torch.cat([b1, b1c, absent1]).contiguous()
+    row2 = torch.cat([b2, absent2, b2c]).contiguous()
+    return row1, row2, int(b1.numel())
+
+
+def merged_state(spec: PermutationSpec, state1: Dict[str, torch.Tensor], state2: Dict[str, torch.Tensor],
+                 blocks: Blocks, device: Optional[torch.device] = None) -> Dict[str, torch.Tensor]:
+    """All tensors that carry a permutable axis, assembled on ``device`` by the HIP kernel.
+
+    Reference: partial_matching.py:105-175.  1-axis tensors become
+    ``[(W1[b1]+W2[b2])/2 | W1[b1c] | W2[b2c]]``; 2-axis tensors (axis 0 = out, 1 = in) become
+    the 3x3 block matrix whose merged rows are halved and whose two cross blocks stay zero.
+    """
+    from .. import hip_ops
+
+    full = spread_blocks(spec, blocks)
+    axes_of: Dict[str, set] = {}
+    for group in spec.values():
+        for ax in group.state:
+            axes_of.setdefault(ax.key, set()).add(ax.axis)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    maps_cache: Dict[int, tuple] = {}
+
+    def maps(ax: Axis):
+        blk = full[ax]
+        if id(blk) not in maps_cache:
+            maps_cache[id(blk)] = block_maps(blk, device)
+        return maps_cache[id(blk)]
+
+    out: Dict[str, torch.Tensor] = {}
+    for name, axes in axes_of.items():
+        if name not in state1 or name not in state2:
+            print("Could not find - %s" % name)
+            continue
+        w1 = state1[name].to(device=device, dtype=torch.float32)
+        w2 = state2[name].to(device=device, dtype=torch.float32)
+        assert len(axes) in (1, 2), name
+        if len(axes) == 1:
+            (a,) = axes
+            r1, r2, nm = maps(Axis(name, a))
+            out[name] = hip_ops.merge_blocks(w1, w2, a, r1, r2, nm)
+        else:
+            assert axes == {0, 1}, "2-axis tensors must be (out, in, ...)"
+            r1, r2, nm = maps(Axis(name, 0))
+            c1, c2, _ = maps(Axis(name, 1))
+            out[name] = hip_ops.merge_blocks(w1, w2, 0, r1, r2, nm, c1, c2)
+    return out
+
+
+def build_partial_merge_model(spec: PermutationSpec, model1: nn.Module, model2: nn.Module, blocks: Blocks) -> nn.Module:
+    """Reference: partial_matching.py:91-185 -> a NEW eval-mode CPU module whose permutable
+    tensors are frozen ``Parameter``s of the merged width; everything else is model1's."""
+    new = merged_state(spec, model1.state_dict(), model2.state_dict(), blocks)
+    model3 = deepcopy(model1).eval().cpu()
+    for name, w in new.items():
+        set_attr(model3, name.split("."), nn.Parameter(w.cpu(), requires_grad=False))
+    return model3
+
+
+def partial_merge(spec: PermutationSpec, model1: nn.Module, model2: nn.Module, perm: Permutation,
+                  costs: Dict[Axis, torch.Tensor], ratios: Ratios, zero_augmented: bool = False,
+                  return_blocks: bool = False):
+    """Reference: partial_matching.py:188-202 (same positional order; ``zero_augmented`` lands in
+    the unused solver slot of ``get_blocks`` exactly as there)."""
+    blocks = get_blocks(spec, perm, costs, ratios, zero_augmented)
+    model3 = build_partial_merge_model(spec, model1, model2, blocks)
+    return (model3, blocks) if return_blocks else model3

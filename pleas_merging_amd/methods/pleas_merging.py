@@ -1,0 +1,287 @@
+"""PLeaS: layer-wise least-squares fitting of the partially merged model.
+
+Drop-in for the hot-path part of the reference's ``pleas/methods/pleas_merging.py``
+(``get_gradient_mask`` :11-60, ``get_model_orig_activations`` :63-149, ``capture_inputs``
+:197-231, ``step`` :234-302, ``train`` :305-405).
+
+Objective (reference :281-284): for every Conv2d/Linear layer L of the merged model,
+``mean((L(ip) - op)^2)`` where ``ip`` / ``op`` are the block-merged input / output activations
+of the two source layers.  ``solver="adam"`` reproduces the reference's optimiser exactly
+(Adam, lr 5e-4, cosine schedule, masked gradients, MAX_STEPS+1 updates); ``solver="normal_eq"``
+minimises the same objective in closed form (normal equations + Cholesky), which is what
+the Adam loop approximates.
+
+MI355X design of one Adam step
+  * both source forwards run once under PyTorch-ROCm with hooks that keep each layer's input
+    AND output (the reference re-runs every source layer a second time, :113-114);
+  * ``ip``/``op`` are assembled by one ``pleas_merge_blocks`` launch each (reference: 8
+    ``index_select`` + 2 ``cat`` per layer);
+  * the merged layer's forward and weight-gradient are the only grads computed (autograd in the
+    reference also back-propagates into both source layers); the loss value and the scaled
+    residual ``2 (out - op) / numel`` come from one ``pleas_sqerr`` pass;
+  * all parameters, gradients, masks and Adam moments live in flat fp32 arenas, so the masked
+    Adam update of the whole model is ONE ``pleas_masked_adam`` launch.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..core.utils import Axis, get_attr
+from .partial_matching import block_maps, get_blocks, spread_blocks
+
+
+# ------------------------------------------------------------------------------------------ reference-shaped helpers
+def get_gradient_mask(perm_blocks, model_weights: Dict[str, nn.Module]) -> List[torch.Tensor]:
+    """One 0/1 mask per parameter of every layer in ``model_weights`` (reference :11-60).
+
+    For >=2-D parameters two blocks are frozen.  The reference indexes them as
+    ``mask[input_separate_1, output_separate_2] = 0`` and ``mask[input_separate_2,
+    output_separate_1] = 0`` -- input slices on axis 0, output slices on axis 1 (:57-58) --
+    and parity requires exactly that.  Axes missing from the spec fall back to 3 merged
+    inputs / 1000 merged outputs (:31-37), i.e. no frozen block.
+    """
+    masks = []
+    for name, layer in model_weights.items():
+        bi = perm_blocks.get(Axis("%s.weight" % name, 1))
+        bo = perm_blocks.get(Axis("%s.weight" % name, 0))
+        ni, mi = (len(bi[0]), len(bi[2])) if bi is not None else (3, 0)
+        no, mo = (len(bo[0]), len(bo[2])) if bo is not None else (1000, 0)
+        for p in layer.parameters():
+            mask = torch.ones_like(p)
+            if p.dim() >= 2:
+                mask[ni:ni + mi, no + mo:no + 2 * mo] = 0.0
+                mask[ni + mi:ni + 2 * mi, no:no + mo] = 0.0
+            masks.append(mask)
+    return masks
+
+
+class ActivationTap:
+    """Forward hooks on every Conv2d / Linear / LayerNorm of a model that keep the module's
+    input and output of the latest forward (reference keeps inputs only, :197-231)."""
+
+    KINDS = (nn.Conv2d, nn.Linear, nn.LayerNorm)
+
+    def __init__(self, model: nn.Module):
+        self.inputs: Dict[str, torch.Tensor] = {}
+        self.outputs: Dict[str, torch.Tensor] = {}
+        self.handles = []
+        for name, mod in model.named_modules():
+            if isinstance(mod, self.KINDS):
+                self.handles.append(mod.register_forward_hook(self._hook(name)))
+
+    def _hook(self, name):
+        def hook(module, inp, out):
+            if isinstance(inp, tuple):
+                assert len(inp) == 1
+                inp = inp[0]
+            self.inputs[name] = inp
+            self.outputs[name] = out
+
+        return hook
+
+    def clear(self):
+        self.inputs.clear()
+        self.outputs.clear()
+
+    def remove(self):
+        for h in self.handles:
+            h.remove()
+        self.handles = []
+
+
+def cosine_lrs(base_lr: float, t_max: int, n: int) -> List[float]:
+    """Learning rate used by update 0..n-1 under ``CosineAnnealingLR(T_max=t_max)`` stepped once
+    per update, evaluated with torch's recursive form so the doubles match the reference
+    (:358, :375)."""
+    lrs, lr = [], base_lr
+    for t in range(n):
+        if t > 0:
+            if (t - 1 - t_max) % (2 * t_max) == 0:
+                lr = lr + base_lr * (1 - math.cos(math.pi / t_max)) / 2
+            else:
+                lr = (1 + math.cos(math.pi * t / t_max)) / (1 + math.cos(math.pi * (t - 1) / t_max)) * lr
+        lrs.append(lr)
+    return lrs
+
+
+# ------------------------------------------------------------------------------------------ per-layer plan
+class _LayerPlan:
+    __slots__ = ("name", "mod", "is_conv", "w", "b", "gw", "gb", "in_maps", "out_maps", "w_shape")
+
+
+def _identity_block(n: int):
+    e = torch.empty(0, dtype=torch.long)
+    return (torch.arange(n), torch.arange(n), e, e)
+
+
+def _fallback_out_width(separate_classifier: bool, model_type: str, num_classes: int) -> int:
+    if not separate_classifier:
+        return num_classes
+    widths = {"rn50": 2048, "rn101": 2048, "rn20": 1024, "rn18": 512}
+    if model_type not in widths:
+        raise ValueError("Unknown model type: %s" % model_type)
+    return widths[model_type]
+
+
+class PleasFitter:
+    """State of one PLeaS run: flat arenas + per-layer plans.  ``train`` drives it; the bench
+    uses it directly to time single steps."""
+
+    def __init__(self, model1, model2, model3, spec, perm, costs, budget_ratios, max_steps: int, lr: float = 5e-4,
+                 separate_classifier=False, num_classes=1000, model_type="rn50", conv_backend: str = "auto"):
+        from .. import hip_ops
+
+        self.ops = hip_ops
+        self.model1, self.model2, self.model3 = model1, model2, model3
+        self.device = next(iter(model1.parameters())).device
+        if self.device.type != "cuda":
+            raise hip_ops.PleasHipError("pleas_merging.train: source models must be on the GPU (got %s)" % self.device)
+        blocks = get_blocks(spec, perm, costs, budget_ratios, False)
+        self.perm_blocks = spread_blocks(spec, blocks)
+        self.tap1, self.tap2 = ActivationTap(model1), ActivationTap(model2)
+        model1.eval()
+        model2.eval()
+
+        layers = {n: m for n, m in model3.named_modules() if isinstance(m, (nn.Conv2d, nn.Linear))}
+        self.layer_modules = layers
+        total = sum(p.numel() for m in layers.values() for p in m.parameters())
+        dev = self.device
+        self.p = torch.empty(total, dtype=torch.float32, device=dev)
+        self.g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.mask = torch.ones(total, dtype=torch.float32, device=dev)
+        masks = get_gradient_mask(self.perm_blocks, layers)
+        self.plans: List[_LayerPlan] = []
+        off, k = 0, 0
+        for name, mod in layers.items():
+            plan = _LayerPlan()
+            plan.name, plan.mod, plan.is_conv = name, mod, isinstance(mod, nn.Conv2d)
+            plan.b = plan.gb = None
+            for pname, prm in mod.named_parameters():
+                n = prm.numel()
+                self.p[off:off + n].copy_(prm.detach().reshape(-1))
+                self.mask[off:off + n].copy_(masks[k].reshape(-1))
+                view, gview = self.p[off:off + n].view(prm.shape), self.g[off:off + n].view(prm.shape)
+                if pname == "weight":
+                    plan.w, plan.gw, plan.w_shape = view, gview, tuple(prm.shape)
+                else:
+                    plan.b, plan.gb = view, gview
+                off += n
+                k += 1
+            src = get_attr(model1, name.split("."))
+            cin = src.in_channels if plan.is_conv else src.in_features
+            bi = self.perm_blocks.get(Axis("%s.weight" % name, 1)) or _identity_block(cin)
+            bo = self.perm_blocks.get(Axis("%s.weight" % name, 0)) or _identity_block(
+                _fallback_out_width(separate_classifier, model_type, num_classes))
+            plan.in_maps, plan.out_maps = block_maps(bi, dev), block_maps(bo, dev)
+            self.plans.append(plan)
+        self.max_steps = max_steps
+        self.lrs = cosine_lrs(lr, max_steps, max_steps + 1)
+        self.step_count = 0
+        self.loss_now = torch.zeros(len(self.plans), dtype=torch.float32, device=dev)   # this step, per layer
+        self.loss_sum = torch.zeros(len(self.plans), dtype=torch.float32, device=dev)   # since last report
+
+    # -- one layer: residual + weight gradient ------------------------------------------------
+    def _fit_layer(self, idx: int, plan: _LayerPlan) -> None:
+        ops = self.ops
+        name = plan.name
+        ip1, ip2 = self.tap1.inputs[name], self.tap2.inputs[name]
+        o1, o2 = self.tap1.outputs[name], self.tap2.outputs[name]
+        ip = ops.merge_blocks(ip1, ip2, 1, *plan.in_maps)
+        op = ops.merge_blocks(o1, o2, 1, *plan.out_maps)
+        mod = plan.mod
+        if plan.is_conv:
+            out = F.conv2d(ip, plan.w, plan.b, mod.stride, mod.padding, mod.dilation, mod.groups)
+        else:
+            out = F.linear(ip, plan.w, plan.b)
+        if out.shape != op.shape:
+            raise RuntimeError("layer %s: merged output %s vs target %s" % (name, tuple(out.shape), tuple(op.shape)))
+        n = out.numel()
+        resid = torch.empty_like(out)
+        ops.sqerr(out, op, 1.0 / n, self.loss_now[idx:idx + 1], accumulate=False, diff=resid, dscale=2.0 / n)
+        if plan.is_conv:
+            gw = torch.ops.aten.convolution_backward(resid, ip, plan.w, None, mod.stride, mod.padding, mod.dilation,
+                                                     False, [0, 0], mod.groups, [False, True, False])[1]
+            plan.gw.copy_(gw)
+            if plan.gb is not None:
+                plan.gb.copy_(resid.sum((0, 2, 3)))
+        else:
+            r2, i2 = resid.reshape(-1, resid.shape[-1]), ip.reshape(-1, ip.shape[-1])
+            torch.mm(r2.t(), i2, out=plan.gw)
+            if plan.gb is not None:
+                plan.gb.copy_(r2.sum(0))
+
+    @torch.no_grad()
+    def step(self, x: torch.Tensor) -> None:
+        """One update: reference ``step`` (:234-302) + ``lr_sched.step()`` (:375)."""
+        x = x.to(self.device, non_blocking=True)
+        self.model1(x)
+        self.model2(x)
+        for idx, plan in enumerate(self.plans):
+            if plan.name not in self.tap1.inputs or plan.name not in self.tap2.inputs:
+                print("Key error on %s" % plan.name)
+                continue
+            self._fit_layer(idx, plan)
+        self.loss_sum.add_(self.loss_now)
+        lr = self.lrs[min(self.step_count, len(self.lrs) - 1)]
+        self.step_count += 1
+        self.ops.masked_adam(self.p, self.g, self.mask, self.m, self.v, lr, self.step_count)
+        self.tap1.clear()
+        self.tap2.clear()
+
+    def finish(self) -> nn.Module:
+        """Write the fitted weights back into ``model3`` and drop the hooks (reference :392-403)."""
+        sd = self.model3.state_dict()
+        for plan in self.plans:
+            sd["%s.weight" % plan.name] = plan.w.detach().clone()
+            if plan.b is not None:
+                sd["%s.bias" % plan.name] = plan.b.detach().clone()
+        self.model3.load_state_dict(sd)
+        self.tap1.remove()
+        self.tap2.remove()
+        return self.model3
+
+
+def train(dataloader, model1, model2, model3, spec, perm, costs, budget_ratios, WANDB, MAX_STEPS, wandb_run,
+          separate_classifier=False, merging="perm_gradmask", num_classes=1000, lr=5e-4, verbose=False,
+          model_type="rn50", solver="adam"):
+    """Fit ``model3``'s Conv2d/Linear weights layer by layer (reference :305-405; same positional
+    order and defaults; ``solver`` is the only addition).  Consumes one batch per update from a
+    single pass over ``dataloader`` and performs ``MAX_STEPS + 1`` updates if it is long enough.
+    Puts ``model1``/``model2`` in eval mode (as the reference), mutates and returns ``model3``.
+    """
+    if merging != "perm_gradmask":
+        raise NotImplementedError("merging=%r: only 'perm_gradmask' (the drivers' mode) is on the HIP path" % merging)
+    if solver == "normal_eq":
+        from .normal_eq import train_normal_eq
+
+        return train_normal_eq(dataloader, model1, model2, model3, spec, perm, costs, budget_ratios, MAX_STEPS,
+                               separate_classifier, num_classes, model_type, verbose)
+    if solver != "adam":
+        raise ValueError("solver must be 'adam' or 'normal_eq'")
+    fit = PleasFitter(model1, model2, model3, spec, perm, costs, budget_ratios, MAX_STEPS, lr, separate_classifier,
+                      num_classes, model_type)
+    names = [p.name for p in fit.plans]
+    for idx, batch in enumerate(dataloader):
+        if idx > MAX_STEPS:
+            break
+        x, _ = batch
+        fit.step(x)
+        if verbose:
+            print(float(fit.loss_sum.sum()))
+        if idx % 20 == 0 and idx:
+            per_layer = (fit.loss_sum / 20).cpu()
+            total = float(per_layer.sum())
+            print("Loss: %.3f" % total)
+            if WANDB:
+                metrics = {"loss_%s" % n: float(v) for n, v in zip(names, per_layer)}
+                metrics["step"], metrics["loss"] = idx, total
+                wandb_run.log(metrics)
+            fit.loss_sum.zero_()
+    return fit.finish()

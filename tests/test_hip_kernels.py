@@ -1,0 +1,214 @@
+"""Kernel-level parity: every C-ABI entry point against the CPU oracle / scipy / torch fp32.
+
+All tests here need the MI355X (`-m gpu`) and go through libpleas_hip.so.
+"""
+import numpy as np
+import pytest
+import torch
+from scipy.optimize import linear_sum_assignment
+
+from oracle import pleas_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from pleas_merging_amd import hip_ops
+
+    return hip_ops
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+GRAM_SHAPES = [
+    # (shape, axis)                       what it exercises
+    ((4, 8, 6, 6), 1),      # tiny C, HW % 4 == 0, masked rows
+    ((3, 20, 7, 7), 1),     # HW = 49: scalar-load path, chunk straddles samples
+    ((2, 64, 28, 28), 1),   # one 64-tile, vector path
+    ((2, 96, 14, 14), 1),   # 128-tile with masked rows
+    ((16, 256, 14, 14), 1), # the most common ResNet-101 node
+    ((5, 130, 9, 9), 1),    # 2x2 tiles, ragged everything, HW = 81
+    ((16, 512, 1, 1), 1),   # avgpool-like (B, C, 1, 1)
+    ((16, 300), 1),         # flatten-like 2-D node
+    ((64, 32, 3, 3), 0),    # conv weight, axis 0 (B = 1)
+    ((64, 32, 3, 3), 1),    # conv weight, axis 1 (B = Cout, HW = 9)
+    ((10, 48), 0),          # fc weight axis 0
+    ((48,), 0),             # BN vector: K = 1
+    ((2, 64, 112, 112), 1), # long K, split-K across many workgroups
+]
+
+
+@pytest.mark.parametrize("shape,axis", GRAM_SHAPES)
+def test_gram_inner_and_cdist(ops, shape, axis):
+    g = torch.Generator().manual_seed(hash(shape) % 1000)
+    x = torch.randn(shape, generator=g)
+    y = 0.7 * x + 0.5 * torch.randn(shape, generator=g)
+    xd, yd = x.cuda(), y.cuda()
+    inner = ops.cross_features_inner_product(xd, yd, axis).cpu()
+    want = orc.cross_features_inner_product(x.double(), y.double(), axis)
+    assert _rel(inner, want) < 2e-6
+    dist = ops.cross_features_cdist(xd, yd, axis).cpu()
+    want64 = orc.cross_features_cdist_f64(x, y, axis)
+    ref32 = orc.cross_features_cdist(x, y, axis)
+    # tolerance = the fp32 reference formula's own distance from fp64 (x3) + a floor
+    tol = max(3 * _rel(ref32, want64), 2e-6)
+    assert _rel(dist, want64) < tol, (_rel(dist, want64), tol)
+
+
+def test_gram_accumulates_and_overwrites(ops):
+    x, y = torch.randn(2, 40, 5, 5), torch.randn(2, 40, 5, 5)
+    acc = torch.full((40, 40), 3.0, device="cuda")
+    ops.gram_accum(x.cuda(), y.cuda(), 1, acc, ops.EPI_INNER, accumulate=True)
+    want = 3.0 + orc.cross_features_inner_product(x, y, 1)
+    assert torch.allclose(acc.cpu(), want, rtol=1e-5, atol=1e-5)
+    ops.gram_accum(x.cuda(), y.cuda(), 1, acc, ops.EPI_INNER, accumulate=False)
+    assert torch.allclose(acc.cpu(), want - 3.0, rtol=1e-5, atol=1e-5)
+
+
+def test_gram_deterministic(ops):
+    x, y = torch.randn(8, 256, 14, 14).cuda(), torch.randn(8, 256, 14, 14).cuda()
+    a = ops.cross_features_cdist(x, y, 1)
+    b = ops.cross_features_cdist(x, y, 1)
+    assert torch.equal(a, b)
+
+
+def test_gram_identical_inputs_give_zero_diagonal_floor(ops):
+    # x == y: |x|^2 + |y|^2 - 2 x.y cancels to rounding noise; clamp keeps sqrt real
+    x = torch.randn(4, 64, 8, 8).cuda()
+    d = ops.cross_features_cdist(x, x, 1)
+    assert torch.isfinite(d).all() and (d <= 0).all()
+    assert d.diagonal().abs().max() < 0.05 * d.abs().mean()
+
+
+def test_gram_rejects_cpu_tensors(ops):
+    with pytest.raises(ops.PleasHipError):
+        ops.cross_features_cdist(torch.randn(2, 4, 3, 3), torch.randn(2, 4, 3, 3), 1)
+
+
+# ------------------------------------------------------------------------------------------ LAP
+def _lap_cases(n, rng):
+    x = rng.standard_normal((n, 32)).astype(np.float32)
+    y = (x[rng.permutation(n)] + 0.1 * rng.standard_normal((n, 32))).astype(np.float32)
+    return {
+        "normal": rng.standard_normal((n, n)).astype(np.float32),
+        "ties": rng.integers(0, 3, (n, n)).astype(np.float32),
+        "binary": rng.integers(0, 2, (n, n)).astype(np.float32),
+        "equal": np.zeros((n, n), np.float32),
+        "cdist": -np.sqrt(np.maximum(((x[:, None] - y[None]) ** 2).sum(-1), 0)).astype(np.float32),
+    }
+
+
+@pytest.mark.parametrize("maximize", [True, False])
+def test_lsap_bit_exact_vs_scipy_batched(ops, maximize):
+    rng = np.random.default_rng(7)
+    mats = []
+    for n in (1, 2, 3, 5, 17, 64, 100, 255, 256, 257, 300, 512):
+        mats += list(_lap_cases(n, rng).values())
+    outs = ops.solve_lsa_batched([torch.from_numpy(m).cuda() for m in mats], maximize=maximize)
+    for m, o in zip(mats, outs):
+        _, want = linear_sum_assignment(m, maximize=maximize)
+        assert (o.cpu().numpy() == want).all(), (m.shape, maximize)
+
+
+@pytest.mark.parametrize("n", [1024, 2048])
+def test_lsap_large(ops, n):
+    rng = np.random.default_rng(n)
+    cases = _lap_cases(n, rng)
+    mats = [cases["normal"], cases["cdist"], cases["ties"]]
+    outs = ops.solve_lsa_batched([torch.from_numpy(m).cuda() for m in mats], maximize=True)
+    for m, o in zip(mats, outs):
+        _, want = linear_sum_assignment(m, maximize=True)
+        assert (o.cpu().numpy() == want).all()
+
+
+def test_lsap_golden_fixture(ops):
+    import os
+    from conftest import GOLDEN
+
+    z = np.load(os.path.join(GOLDEN, "lap_small.npz"))
+    idx = list(range(int(z["n_cases"])))
+    for mx, tag in ((True, "max"), (False, "min")):
+        outs = ops.solve_lsa_batched([torch.from_numpy(z["cost_%d" % i]).cuda() for i in idx], maximize=mx)
+        for i, o in zip(idx, outs):
+            assert (o.cpu().numpy() == z["col_%s_%d" % (tag, i)]).all(), (i, tag)
+
+
+def test_hip_solve_lsa_signature(ops):
+    a = torch.randn(33, 33)
+    got = ops.hip_solve_lsa(a.cuda())
+    assert got.device.type == "cpu" and got.dtype == torch.int64
+    assert (got == orc.solve_lsa(a)).all()
+
+
+def test_lsap_rejects_bad_sizes(ops):
+    with pytest.raises(ops.PleasHipError):
+        ops.solve_lsa_batched([torch.zeros(3, 4).cuda()])
+    with pytest.raises(ops.PleasHipError):
+        ops.solve_lsa_batched([torch.zeros(2049, 2049).cuda()])
+
+
+# ------------------------------------------------------------------------------------------ merge / adam / sqerr
+def test_merge_blocks_two_axis(ops):
+    g = torch.Generator().manual_seed(3)
+    W1, W2 = torch.randn(12, 10, 3, 3, generator=g), torch.randn(12, 10, 3, 3, generator=g)
+    bo = (torch.tensor([0, 3, 5, 7, 9, 11, 1]), torch.tensor([2, 0, 4, 6, 8, 10, 3]), torch.tensor([2, 4, 6, 8, 10]),
+          torch.tensor([1, 5, 7, 9, 11]))
+    bi = (torch.tensor([1, 2, 3, 4]), torch.tensor([4, 3, 2, 1]), torch.tensor([0, 5, 6, 7, 8, 9]),
+          torch.tensor([0, 5, 6, 7, 8, 9]))
+    from pleas_merging_amd.methods.partial_matching import block_maps
+
+    r1, r2, nm = block_maps(bo, "cuda")
+    c1, c2, _ = block_maps(bi, "cuda")
+    got = ops.merge_blocks(W1.cuda(), W2.cuda(), 0, r1, r2, nm, c1, c2).cpu()
+    from pleas_merging_amd.core.utils import Axis, PermutationGroup
+
+    spec = {Axis("w", 0): PermutationGroup(12, {Axis("w", 0), Axis("d", 0)}, set()),
+            Axis("w", 1): PermutationGroup(10, {Axis("w", 1), Axis("e", 0)}, set())}
+    want = orc.merged_state(spec, {"w": W1}, {"w": W2}, {Axis("w", 0): bo, Axis("w", 1): bi})["w"]
+    assert torch.equal(got, want)
+
+
+def test_merge_blocks_one_axis_activation(ops):
+    g = torch.Generator().manual_seed(4)
+    x1, x2 = torch.randn(3, 9, 5, 5, generator=g), torch.randn(3, 9, 5, 5, generator=g)
+    b = (torch.tensor([0, 2, 4, 6]), torch.tensor([1, 3, 5, 7]), torch.tensor([1, 3, 5, 7, 8]),
+         torch.tensor([0, 2, 4, 6, 8]))
+    from pleas_merging_amd.methods.partial_matching import block_maps
+
+    r1, r2, nm = block_maps(b, "cuda")
+    got = ops.merge_blocks(x1.cuda(), x2.cuda(), 1, r1, r2, nm).cpu()
+    want = torch.cat([(x1[:, b[0]] + x2[:, b[1]]) / 2, x1[:, b[2]], x2[:, b[3]]], 1)
+    assert torch.equal(got, want)
+
+
+def test_masked_adam_matches_torch(ops):
+    g = torch.Generator().manual_seed(5)
+    p0 = torch.randn(1000, generator=g)
+    mask = (torch.rand(1000, generator=g) > 0.2).float()
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p_ref], lr=5e-4)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, 10)
+    p, m, v = p0.clone().cuda(), torch.zeros(1000).cuda(), torch.zeros(1000).cuda()
+    for step in range(1, 12):
+        grad = torch.randn(1000, generator=g) * 10 ** float(torch.randint(-6, 1, (1,), generator=g))
+        p_ref.grad = grad * mask
+        lr = opt.param_groups[0]["lr"]
+        opt.step()
+        sched.step()
+        ops.masked_adam(p, grad.cuda(), mask.cuda(), m, v, lr, step)
+    assert _rel(p.cpu(), p_ref.detach()) < 1e-6
+    assert torch.equal(p.cpu()[mask == 0], p0[mask == 0])
+
+
+def test_sqerr(ops):
+    a, b = torch.randn(100003), torch.randn(100003)
+    out = torch.zeros(1, device="cuda")
+    diff = torch.empty(100003, device="cuda")
+    ops.sqerr(a.cuda(), b.cuda(), 1.0 / a.numel(), out, diff=diff, dscale=2.0 / a.numel())
+    assert abs(float(out) - float(((a - b) ** 2).mean())) < 1e-5
+    assert torch.allclose(diff.cpu(), 2 * (a - b) / a.numel(), rtol=1e-6, atol=1e-12)
+    ops.sqerr(a.cuda(), b.cuda(), 1.0 / a.numel(), out, accumulate=True)
+    assert abs(float(out) - 2 * float(((a - b) ** 2).mean())) < 2e-5
