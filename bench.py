@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): wall-clock seconds to merge a ResNet-101 pair --
+100-batch activation matching + LAP + partial merge + 400-step PLeaS (401 updates) -- on
+synthetic 224x224 inputs, on N MI355X GPUs of one node.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--arch resnet101] [--batch 16]
+  N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one batch through the hot path.  The default K = 501 is the whole job (100 matching
+batches + 401 PLeaS updates); a smaller K runs a proportionally shortened job and says so in
+``config.workload``.  W warm-up steps (untimed) run the same code on throw-away state first.
+Inputs and both models are resident in HBM before the timed region starts.
+
+Multi-GPU (strong scaling, total work fixed): matching shards whole batches over ranks and
+all-reduces the flat cost arena once (RCCL); each PLeaS update shards the batch's samples over
+ranks and all-reduces the flat gradient arena, so every rank applies the identical update.
+
+The JSON line also carries
+  roofline     -- the dominant kernel (fp32-MFMA gram contraction): algorithmic FLOP / HIP-event time
+                  of its launches inside the timed region, against the 157.3 TFLOP/s fp32 matrix peak;
+  cpu_baseline -- the CPU oracle (restatement of the reference) timed on this box's host cores on a
+                  bounded sample, extrapolated to the job, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
+FULL_MATCH, FULL_PLEAS = 100, 401
+T_START = time.time()
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %7.1fs] %s" % (time.time() - T_START, msg), file=sys.stderr, flush=True)
+
+
+def usable_cores():
+    """Host cores this process may really use (affinity mask and cgroup quota, not the socket count)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=FULL_MATCH + FULL_PLEAS)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--arch", default="resnet101")
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--ratio", type=float, default=0.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-batch", type=int, default=2)
+    return ap.parse_args()
+
+
+def split_steps(k):
+    if k >= FULL_MATCH + FULL_PLEAS:
+        return FULL_MATCH, k - FULL_MATCH
+    n_match = max(1, round(k * FULL_MATCH / (FULL_MATCH + FULL_PLEAS)))
+    return n_match, max(1, k - n_match)
+
+
+class Pool:
+    """Synthetic batches resident in HBM: batch b = N(0,1) from a generator seeded 1000 + b."""
+
+    def __init__(self, n, batch, device):
+        gen = torch.Generator(device=device)
+        self.items = []
+        for b in range(n):
+            gen.manual_seed(1000 + b)
+            self.items.append(torch.randn(batch, 3, 224, 224, generator=gen, device=device))
+
+    def loader(self, start, count):
+        return [(self.items[(start + i) % len(self.items)], None) for i in range(count)]
+
+
+def build_models(arch, device, batch):
+    from pleas_merging_amd import resnet as zoo
+
+    models = []
+    gen = torch.Generator(device=device)
+    for seed in (0, 1):
+        torch.manual_seed(seed)
+        m = zoo.MODELS[arch](num_classes=1000).to(device)
+        calib = []
+        for i in range(4):
+            gen.manual_seed(900 + i)
+            calib.append(torch.randn(batch, 3, 224, 224, generator=gen, device=device))
+        zoo.calibrate_bn(m, calib)
+        models.append(m)
+    return models
+
+
+def run_job(spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, ratio, dp):
+    """The timed hot path.  Returns (merged model, perm, costs)."""
+    from pleas_merging_amd.methods.activation_matching import activation_matching
+    from pleas_merging_amd.methods.partial_matching import partial_merge
+    from pleas_merging_amd.methods.pleas_merging import PleasFitter
+
+    perm, costs = activation_matching(spec, m1, m2, match_loader, len(match_loader), output_costs=True)
+    m3 = partial_merge(spec, m1, m2, perm, costs, ratio)
+    fit = PleasFitter(m1, m2, m3, spec, perm, costs, ratio, n_pleas_sched, data_parallel=dp)
+    for x, _ in pleas_loader:
+        fit.step(x)
+    return fit.finish(), perm, costs
+
+
+def gram_flops_per_sample(spec, m1, device):
+    """Sum over tracked nodes of 2*C^2*HW; shapes from a meta trace."""
+    from pleas_merging_amd.core.compiler import trace_with_shapes
+
+    gm = trace_with_shapes(m1, ((1, 3, 224, 224),))
+    tracked = {ax.key for g in spec.values() for ax in g.node}
+    flops = byts = 0
+    for node in gm.graph.nodes:
+        if node.name in tracked:
+            shp = tuple(node.meta["tensor_meta"].shape)
+            c = shp[1]
+            hw = 1
+            for s in shp[2:]:
+                hw *= s
+            flops += 2 * c * c * hw
+            byts += 2 * c * hw * 4
+    return flops, byts
+
+
+def cpu_baseline(spec, arch, batch_full, sample_batch, n_match, n_pleas, ratio):
+    """Oracle (CPU restatement of the reference path) on this box's host cores, bounded sample:
+    1 matching batch + 1 PLeaS update at a reduced batch size, all LAPs; extrapolated linearly
+    in samples to the job that the GPU ran."""
+    from oracle import pleas_oracle as orc
+    from pleas_merging_amd import resnet as zoo
+
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    log("cpu baseline on %d cores" % cores)
+    models = []
+    for seed in (0, 1):
+        torch.manual_seed(seed)
+        m = zoo.MODELS[arch](num_classes=1000)
+        g = torch.Generator().manual_seed(900)
+        zoo.calibrate_bn(m, [torch.randn(sample_batch, 3, 224, 224, generator=g)])
+        models.append(m)
+    m1, m2 = models
+    g = torch.Generator().manual_seed(1000)
+    data = [(torch.randn(sample_batch, 3, 224, 224, generator=g), None) for _ in range(2)]
+    t0 = time.time()
+    costs = orc.matching_costs(spec, m1, m2, data[:1], 1, accumulate=True)
+    t_match = time.time() - t0
+    log("cpu: matching batch %.1fs" % t_match)
+    t0 = time.time()
+    perm = {k: orc.solve_lsa(v) for k, v in costs.items()}
+    t_lap = time.time() - t0
+    t0 = time.time()
+    m3 = orc.partial_merge(spec, m1, m2, perm, costs, ratio)
+    t_merge = time.time() - t0
+    t0 = time.time()
+    orc.train(data[1:2], m1, m2, m3, spec, perm, costs, ratio, 1)
+    t_step = time.time() - t0
+    log("cpu: PLeaS update %.1fs" % t_step)
+    scale = batch_full / sample_batch
+    total = n_match * t_match * scale + t_lap + t_merge + n_pleas * t_step * scale
+    return {
+        "value": round(total, 1), "unit": "s", "cores": cores, "kind": "port",
+        "sample": "oracle on %s pair: 1 matching batch (%.1fs) + 1 PLeaS update (%.1fs) at batch %d, all %d LAPs "
+                  "(%.2fs), merge (%.2fs); batches scaled x%.0f to batch %d, then x%d matching + x%d updates"
+                  % (arch, t_match, t_step, sample_batch, len(perm), t_lap, t_merge, scale, batch_full, n_match, n_pleas),
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    from pleas_merging_amd import build as hip_build, hip_ops
+    from pleas_merging_amd.core.compiler import get_permutation_spec
+
+    if rank == 0:
+        hip_build.build()
+    if world > 1:
+        dist.barrier()
+
+    n_match, n_pleas = split_steps(args.steps)
+    full = (n_match, n_pleas) == (FULL_MATCH, FULL_PLEAS)
+    n_sched = n_pleas - 1  # CosineAnnealingLR(T_max=MAX_STEPS) with MAX_STEPS + 1 updates
+    m1, m2 = build_models(args.arch, device, args.batch)
+    log("models built + BN calibrated")
+    spec = get_permutation_spec(m1, ((1, 3, 224, 224),))
+    pool = Pool(max(n_match, n_pleas, args.warmup + 1), args.batch, device)
+    dp = world > 1
+    log("spec (%d groups) + %d synthetic batches resident" % (len(spec), len(pool.items)))
+
+    # ---- warm-up: W matching batches + W updates on throw-away state (MIOpen find, allocator, graph build)
+    if args.warmup > 0:
+        run_job(spec, m1, m2, pool.loader(0, args.warmup * world), pool.loader(0, args.warmup), max(1, args.warmup - 1),
+                args.ratio, dp)
+
+    log("warm-up done")
+    # ---- timed region
+    hip_ops.profile_reset()
+    hip_ops.profile_enable(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    m3, perm, costs = run_job(spec, m1, m2, pool.loader(0, n_match), pool.loader(0, n_pleas), max(1, n_sched), args.ratio, dp)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    hip_ops.profile_enable(False)
+    log("timed region: %.3fs" % elapsed)
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        prof = hip_ops.profile_collect()  # {kernel: (launches, total_ms, flops, bytes)}
+        log("profile events collected")
+        dom = prof.get("gram_partial", (0, 0.0, 0.0, 0.0))
+        achieved = dom[2] / (dom[1] * 1e-3) / 1e12 if dom[1] > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "gram_traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        roofline = {
+            "bound": "mfma", "kernel": "gram_partial_kernel (fp32 MFMA 32x32x2)", "achieved": round(achieved, 2),
+            "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4),
+            "traffic": traffic, "launches": dom[0], "avg_launch_us": round(dom[1] * 1e3 / max(dom[0], 1), 2),
+            "algorithmic_flop_per_launch": round(dom[2] / max(dom[0], 1)),
+        }
+        steps = n_match + n_pleas
+        out = {
+            "metric": "wall-clock (s): ResNet-101 pair, 100-batch act-match + 400-step PLeaS, 1/8 GPU"
+            if args.arch == "resnet101" else "wall-clock (s): %s pair, act-match + PLeaS" % args.arch,
+            "value": round(elapsed, 3), "unit": "s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed * 1e3 / steps, 3), "higher_is_better": False, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "%s pair (random init, BN calibrated), %d matching batches + LAP (%d groups) + partial merge "
+                            "(ratio %.2f) + %d PLeaS Adam updates, batch %d x 3x224x224%s"
+                            % (args.arch, n_match, len(spec), args.ratio, n_pleas, args.batch,
+                               "" if full else " (SHORTENED job: --steps %d)" % args.steps),
+                "solver": "adam", "parallelism": "dp%d" % world,
+            },
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(spec, args.arch, args.batch, args.cpu_sample_batch, n_match, n_pleas,
+                                               args.ratio)
+        out["phases_ms"] = {k: {"launches": v[0], "total_ms": round(v[1], 2)} for k, v in sorted(prof.items())}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

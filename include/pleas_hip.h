@@ -117,6 +117,21 @@ size_t pleas_sqerr_ws_bytes(int64_t n);
 int pleas_sqerr(const float* a, const float* b, int64_t n, float scale, int accumulate, float* out, float dscale,
                 float* diff, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Opt-in live timing of the library's kernels with HIP events recorded on the launch stream
+ * (used by bench.py for the roofline figure; off by default, no cost when off).
+ * kernel ids: 0 gram_partial, 1 gram_finalize, 2 lsap, 3 merge_blocks, 4 masked_adam, 5 sqerr,
+ *             6 conv_fwd, 7 conv_wgrad, 8 normal_eq, 9 solve.
+ * pleas_prof_collect waits for the recorded events of that kernel and returns the number of
+ * launches, their summed duration, and the summed ALGORITHMIC flops / bytes of those launches.
+ */
+void pleas_prof_enable(int on);
+void pleas_prof_reset(void);
+int pleas_prof_collect(int kernel, int64_t* launches, double* total_ms, double* flops, double* bytes);
+
+/* Tuning hook for experiments: split-K target workgroup count and minimum K chunks per split. */
+void pleas_gram_tune(int target_blocks, int min_chunks_per_split);
+
 #ifdef __cplusplus
 }
 #endif

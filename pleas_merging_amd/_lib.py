@@ -30,7 +30,15 @@ SIGNATURES = {
     "pleas_sqerr_ws_bytes": (c_size_t, [c_int64]),
     "pleas_sqerr": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_int, c_void_p, c_float, c_void_p, c_void_p, c_size_t,
                             c_void_p]),
+    "pleas_prof_enable": (None, [c_int]),
+    "pleas_prof_reset": (None, []),
+    "pleas_prof_collect": (c_int, [c_int, POINTER(c_int64), POINTER(ctypes.c_double), POINTER(ctypes.c_double),
+                                   POINTER(ctypes.c_double)]),
+    "pleas_gram_tune": (None, [c_int, c_int]),
 }
+
+PROF_KERNELS = ["gram_partial", "gram_finalize", "lsap", "merge_blocks", "masked_adam", "sqerr", "conv_fwd",
+                "conv_wgrad", "normal_eq", "solve"]
 
 
 class PleasHipError(RuntimeError):

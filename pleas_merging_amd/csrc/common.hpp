@@ -36,4 +36,22 @@ inline int bad_arg(const char* what) {
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// ---- opt-in per-kernel timing with HIP events on the launch stream (pleas_prof_* in the C-ABI)
+enum ProfKernel { kProfGramPartial = 0, kProfGramFinalize, kProfLsap, kProfMergeBlocks, kProfMaskedAdam, kProfSqerr,
+                  kProfConvFwd, kProfConvWgrad, kProfNormalEq, kProfSolve, kProfCount };
+extern bool g_prof_on;
+void prof_begin(int kernel, double flops, double bytes, hipStream_t stream);
+void prof_end(hipStream_t stream);
+
+struct ProfScope {
+    hipStream_t s;
+    bool on;
+    ProfScope(int kernel, double flops, double bytes, hipStream_t stream) : s(stream), on(g_prof_on) {
+        if (on) prof_begin(kernel, flops, bytes, s);
+    }
+    ~ProfScope() {
+        if (on) prof_end(s);
+    }
+};
+
 }  // namespace pleas

@@ -3,12 +3,51 @@
 // layout allows, grid-strided over <= 2048 workgroups (8 per CU).
 #include <algorithm>
 #include <cmath>
+#include <mutex>
+#include <vector>
 
 #include "common.hpp"
 
 namespace pleas {
 
 thread_local char g_last_error[256] = "";
+
+// ---- profiling records: one (start, stop) event pair per profiled launch, resolved at collect time
+bool g_prof_on = false;
+struct ProfRec {
+    hipEvent_t a, b;
+    int kernel;
+    double flops, bytes;
+};
+static std::vector<ProfRec> g_prof_recs;
+static std::vector<hipEvent_t> g_prof_free;
+static std::mutex g_prof_mu;
+
+static hipEvent_t prof_event() {
+    if (!g_prof_free.empty()) {
+        hipEvent_t e = g_prof_free.back();
+        g_prof_free.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+void prof_begin(int kernel, double flops, double bytes, hipStream_t stream) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfRec r;
+    r.a = prof_event();
+    r.b = prof_event();
+    r.kernel = kernel;
+    r.flops = flops;
+    r.bytes = bytes;
+    hipEventRecord(r.a, stream);
+    g_prof_recs.push_back(r);
+}
+void prof_end(hipStream_t stream) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    hipEventRecord(g_prof_recs.back().b, stream);
+}
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -142,6 +181,35 @@ using namespace pleas;
 extern "C" const char* pleas_version(void) { return "pleas_hip 0.1.0 gfx950"; }
 extern "C" const char* pleas_last_error(void) { return g_last_error; }
 
+extern "C" void pleas_prof_enable(int on) { g_prof_on = on != 0; }
+
+extern "C" void pleas_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_prof_recs) {
+        g_prof_free.push_back(r.a);
+        g_prof_free.push_back(r.b);
+    }
+    g_prof_recs.clear();
+}
+
+extern "C" int pleas_prof_collect(int kernel, int64_t* launches, double* total_ms, double* flops, double* bytes) {
+    if (kernel < 0 || kernel >= kProfCount || !launches || !total_ms || !flops || !bytes) return bad_arg("prof_collect");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    *launches = 0;
+    *total_ms = *flops = *bytes = 0.0;
+    for (auto& r : g_prof_recs) {
+        if (r.kernel != kernel) continue;
+        PLEAS_HIP_CHECK(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        PLEAS_HIP_CHECK(hipEventElapsedTime(&ms, r.a, r.b));
+        *launches += 1;
+        *total_ms += ms;
+        *flops += r.flops;
+        *bytes += r.bytes;
+    }
+    return PLEAS_OK;
+}
+
 extern "C" int pleas_merge_blocks(const float* w1, const float* w2, float* out, int64_t outer, int rows_out,
                                   int cols_out, int64_t inner, int rows_src, int cols_src, const int32_t* row1,
                                   const int32_t* row2, const int32_t* col1, const int32_t* col2, int n_merged_rows,
@@ -155,6 +223,7 @@ extern "C" int pleas_merge_blocks(const float* w1, const float* w2, float* out, 
     if (total == 0) return PLEAS_OK;
     hipStream_t stream = (hipStream_t)stream_;
     const bool vec = inner % 4 == 0 && ((((uintptr_t)w1 | (uintptr_t)w2 | (uintptr_t)out) & 15) == 0);
+    ProfScope prof(kProfMergeBlocks, 0.0, 3.0 * total * sizeof(float), stream);
     if (vec)
         hipLaunchKernelGGL((merge_blocks_kernel<4>), dim3(ew_grid(total / 4)), dim3(kEwThreads), 0, stream, w1, w2, out,
                            outer, rows_out, cols_out, inner, rows_src, cols_src, row1, row2, col1, col2, n_merged_rows);
@@ -175,6 +244,7 @@ extern "C" int pleas_masked_adam(float* p, const float* g, const float* mask, fl
     const double bc2 = 1.0 - std::pow((double)b2, step);
     const double step_size = (double)lr / bc1;
     const double bc2_sqrt = std::sqrt(bc2);
+    ProfScope prof(kProfMaskedAdam, 0.0, 8.0 * n * sizeof(float), (hipStream_t)stream_);
     hipLaunchKernelGGL(masked_adam_kernel, dim3(ew_grid(n)), dim3(kEwThreads), 0, (hipStream_t)stream_, p, g, mask, m, v,
                        n, (float)(1.0 - (double)b1), b2, (float)(1.0 - (double)b2), (float)step_size,
                        (float)bc2_sqrt, eps);
@@ -194,6 +264,7 @@ extern "C" int pleas_sqerr(const float* a, const float* b, int64_t n, float scal
     if (!ws || ws_bytes < pleas_sqerr_ws_bytes(n)) return PLEAS_ENOMEM;
     hipStream_t stream = (hipStream_t)stream_;
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, kEwThreads), kSqBlocks));
+    ProfScope prof(kProfSqerr, 0.0, (diff ? 3.0 : 2.0) * n * sizeof(float), stream);
     hipLaunchKernelGGL(sqerr_partial_kernel, dim3(blocks), dim3(kEwThreads), 0, stream, a, b, n, dscale, diff,
                        (float*)ws);
     PLEAS_LAUNCH_CHECK("sqerr_partial_kernel");

@@ -285,6 +285,9 @@ extern "C" int pleas_gram_accum(const float* x, const float* y, int B, int C, in
     g.tiles = p.tiles;
     const dim3 grid((unsigned)(p.tiles * p.tiles * p.S));
     const size_t lds = (size_t)4 * p.tile * kLds * sizeof(float);
+    const double kk = (double)B * (double)HW;
+    {
+    ProfScope prof(kProfGramPartial, 2.0 * C * (double)C * kk, 2.0 * C * kk * sizeof(float), stream);
     if (p.tile == 128 && p.vec == 4)
         hipLaunchKernelGGL((gram_partial_kernel<128, 4>), grid, dim3(kThreads), lds, stream, g);
     else if (p.tile == 128)
@@ -293,7 +296,9 @@ extern "C" int pleas_gram_accum(const float* x, const float* y, int B, int C, in
         hipLaunchKernelGGL((gram_partial_kernel<64, 4>), grid, dim3(kThreads), lds, stream, g);
     else
         hipLaunchKernelGGL((gram_partial_kernel<64, 1>), grid, dim3(kThreads), lds, stream, g);
+    }
     PLEAS_LAUNCH_CHECK("gram_partial_kernel");
+    ProfScope prof2(kProfGramFinalize, 0.0, ((double)p.S + 2.0) * C * (double)C * sizeof(float), stream);
     const size_t total = (size_t)C * C;
     const unsigned fgrid = (unsigned)std::min<size_t>(ceil_div((int64_t)total, 256), 2048);
     hipLaunchKernelGGL(gram_finalize_kernel, dim3(fgrid), dim3(256), 0, stream, g.gpart, g.npart, acc, C, p.S, epilogue,

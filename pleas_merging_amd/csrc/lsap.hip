@@ -205,6 +205,7 @@ extern "C" int pleas_lsap_batched(const float* const* cost, const int* n, int np
         }
         batch.maximize = maximize;
         const size_t lds = (size_t)nmax * (3 * sizeof(double) + 6 * sizeof(int));
+        ProfScope prof(kProfLsap, 0.0, 0.0, stream);
         hipLaunchKernelGGL(lsap_kernel, dim3(cnt), dim3(kLsapThreads), lds, stream, batch);
         PLEAS_LAUNCH_CHECK("lsap_kernel");
     }

@@ -189,3 +189,24 @@ def sqerr(a: torch.Tensor, b: torch.Tensor, scale: float, out: torch.Tensor, acc
                                 diff.data_ptr() if diff is not None else None, ws.data_ptr(), ws.numel(), _stream())
     check(rc, "pleas_sqerr")
     return out
+
+
+# ---------------------------------------------------------------------------------------- live kernel timing
+def profile_enable(on: bool) -> None:
+    _lib.lib().pleas_prof_enable(int(bool(on)))
+
+
+def profile_reset() -> None:
+    _lib.lib().pleas_prof_reset()
+
+
+def profile_collect() -> dict:
+    """{kernel name: (launches, total_ms, algorithmic flops, algorithmic bytes)} since the last reset."""
+    out = {}
+    for kid, name in enumerate(_lib.PROF_KERNELS):
+        n, ms, fl, by = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        check(_lib.lib().pleas_prof_collect(kid, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)),
+              "pleas_prof_collect")
+        if n.value:
+            out[name] = (int(n.value), float(ms.value), float(fl.value), float(by.value))
+    return out

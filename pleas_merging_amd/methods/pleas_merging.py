@@ -133,10 +133,14 @@ class PleasFitter:
     uses it directly to time single steps."""
 
     def __init__(self, model1, model2, model3, spec, perm, costs, budget_ratios, max_steps: int, lr: float = 5e-4,
-                 separate_classifier=False, num_classes=1000, model_type="rn50", conv_backend: str = "auto"):
+                 separate_classifier=False, num_classes=1000, model_type="rn50", data_parallel: bool = False):
         from .. import hip_ops
+        from .activation_matching import _dist_info
 
         self.ops = hip_ops
+        # data parallel: every update splits the batch's samples over the ranks, gradients (one flat
+        # arena) are summed with ONE all-reduce, so all ranks apply the same full-batch update
+        self.rank, self.world = _dist_info() if data_parallel else (0, 1)
         self.model1, self.model2, self.model3 = model1, model2, model3
         self.device = next(iter(model1.parameters())).device
         if self.device.type != "cuda":
@@ -202,7 +206,7 @@ class PleasFitter:
             out = F.linear(ip, plan.w, plan.b)
         if out.shape != op.shape:
             raise RuntimeError("layer %s: merged output %s vs target %s" % (name, tuple(out.shape), tuple(op.shape)))
-        n = out.numel()
+        n = out.numel() * self.world  # the mean runs over the full (global) batch
         resid = torch.empty_like(out)
         ops.sqerr(out, op, 1.0 / n, self.loss_now[idx:idx + 1], accumulate=False, diff=resid, dscale=2.0 / n)
         if plan.is_conv:
@@ -221,6 +225,10 @@ class PleasFitter:
     def step(self, x: torch.Tensor) -> None:
         """One update: reference ``step`` (:234-302) + ``lr_sched.step()`` (:375)."""
         x = x.to(self.device, non_blocking=True)
+        if self.world > 1:
+            if x.shape[0] % self.world:
+                raise RuntimeError("batch of %d samples does not split over %d ranks" % (x.shape[0], self.world))
+            x = x.chunk(self.world)[self.rank]
         self.model1(x)
         self.model2(x)
         for idx, plan in enumerate(self.plans):
@@ -228,6 +236,11 @@ class PleasFitter:
                 print("Key error on %s" % plan.name)
                 continue
             self._fit_layer(idx, plan)
+        if self.world > 1:
+            import torch.distributed as dist
+
+            dist.all_reduce(self.g, op=dist.ReduceOp.SUM)
+            dist.all_reduce(self.loss_now, op=dist.ReduceOp.SUM)
         self.loss_sum.add_(self.loss_now)
         lr = self.lrs[min(self.step_count, len(self.lrs) - 1)]
         self.step_count += 1
