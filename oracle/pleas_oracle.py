@@ -405,7 +405,7 @@ def train(batches, model1, model2, model3, spec, perm, costs, ratios, max_steps:
             p.grad *= m
         opt.step()
         sched.step()
-        losses.append(float(total))
+        losses.append(float(total.detach()))
         acts1.clear()
         acts2.clear()
     sd = model3.state_dict()

@@ -1,2 +1,2 @@
 from pleas_merging_amd.methods.partial_matching import (  # noqa: F401
-    expand_ratios, get_blocks, build_partial_merge_model, partial_merge)
+    expand_ratios, get_blocks, spread_blocks, block_maps, merged_state, build_partial_merge_model, partial_merge)

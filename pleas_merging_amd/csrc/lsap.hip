@@ -9,9 +9,14 @@
 // which is the winner of scipy's sequential scan, and the
 // `remaining` list is maintained with the same reversed fill and swap-remove.
 //
-// Latency-bound by construction (one dependent row scan per tree-growth step): the design
-// goal is a short critical path per step -- one coalesced row read, one wave-shuffle
-// reduction, ONE workgroup barrier -- and full concurrency across the problems.
+// Latency-bound by construction (one dependent row scan per tree-growth step), so the design
+// goal is a short critical path per step:
+//   * each thread owns COLS columns whose state (column dual, tentative length, list position,
+//     assigned row) lives in REGISTERS; all its cost loads of a step are issued back to back;
+//   * the arg-min is a DPP row-scan inside each wave (no LDS round trips), one LDS slot per wave
+//     and ONE workgroup barrier per step; every thread then replays the same scalar bookkeeping,
+//     with a single writer per LDS word;
+//   * all problems run concurrently (largest first), one CU each.
 #include <algorithm>
 #include <vector>
 
@@ -21,7 +26,7 @@ namespace pleas {
 
 constexpr int kLsapThreads = 256;
 constexpr int kLsapWaves = kLsapThreads / 64;
-constexpr int kMaxBatch = 64;
+constexpr int kMaxBatch = 128;
 
 struct LsapBatch {
     const float* cost[kMaxBatch];
@@ -32,92 +37,140 @@ struct LsapBatch {
 
 struct Cand {
     double val;
-    int key;  // tie key, smaller wins
-    int col;
+    int key;  // (tie key << 11) | column ; smaller wins
 };
 
 __device__ __forceinline__ bool better(const Cand& a, const Cand& b) {  // a strictly better than b
     return a.val < b.val || (a.val == b.val && a.key < b.key);
 }
 
-__device__ __forceinline__ Cand shfl_xor_cand(const Cand& c, int off) {
-    Cand o;
-    o.val = __shfl_xor(c.val, off);
-    o.key = __shfl_xor(c.key, off);
-    o.col = __shfl_xor(c.col, off);
-    return o;
+// DPP move: lanes without a source keep their own value (harmless for a min reduction).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_mov(int x) {
+    return __builtin_amdgcn_update_dpp(x, x, CTRL, ROW_MASK, 0xF, false);
 }
 
-__global__ __launch_bounds__(kLsapThreads) void lsap_kernel(const LsapBatch batch) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lsap_smem[];
-    const int prob = blockIdx.x;
-    const int n = batch.n[prob];
-    const float* __restrict__ cost = batch.cost[prob];
-    const float sign = batch.maximize ? -1.f : 1.f;
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void dpp_min_step(Cand& c) {
+    Cand o;
+    const int lo = dpp_mov<CTRL, ROW_MASK>(__double2loint(c.val));
+    const int hi = dpp_mov<CTRL, ROW_MASK>(__double2hiint(c.val));
+    o.val = __hiloint2double(hi, lo);
+    o.key = dpp_mov<CTRL, ROW_MASK>(c.key);
+    if (better(o, c)) c = o;
+}
+
+// Wave-wide lexicographic min; the result is valid in lane 63 and broadcast from there.
+__device__ __forceinline__ Cand wave_min(Cand c) {
+    dpp_min_step<0x111, 0xF>(c);  // row_shr:1
+    dpp_min_step<0x112, 0xF>(c);  // row_shr:2
+    dpp_min_step<0x114, 0xF>(c);  // row_shr:4
+    dpp_min_step<0x118, 0xF>(c);  // row_shr:8  -> lane 15 of every row holds the row's min
+    dpp_min_step<0x142, 0xA>(c);  // row_bcast:15 into rows 1 and 3
+    dpp_min_step<0x143, 0xC>(c);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's min
+    Cand r;
+    r.val = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(c.val), 63),
+                             __builtin_amdgcn_readlane(__double2loint(c.val), 63));
+    r.key = __builtin_amdgcn_readlane(c.key, 63);
+    return r;
+}
+
+struct LsapShared {
+    double* u;         // row duals
+    double* shortest;  // tentative lengths, published at the end of a search
+    int* path;         // predecessor row per column
+    int* row4col;
+    int* col4row;
+    int* remaining;    // unscanned columns in scipy's order
+    int* rowlist;      // rows of the current tree, in visit order
+};
+
+// Column owned by (thread, slot k): contiguous VEC-wide runs so that cost loads are 16-B wide.
+template <int COLS>
+__device__ __forceinline__ int col_of(int tid, int k) {
+    constexpr int VEC = COLS < 4 ? COLS : 4;
+    return ((k / VEC) * kLsapThreads + tid) * VEC + (k % VEC);
+}
+
+template <int COLS>
+__device__ void lsap_solve(const LsapShared sh, const float* __restrict__ cost, const int n, const float sign,
+                           int64_t* __restrict__ out, Cand (*wave_best)[kLsapWaves]) {
+    constexpr int VEC = COLS < 4 ? COLS : 4;
     const int tid = threadIdx.x;
-
-    double* u = reinterpret_cast<double*>(lsap_smem);  // row duals
-    double* v = u + n;                                  // column duals
-    double* shortest = v + n;                           // tentative path length per column
-    int* path = reinterpret_cast<int*>(shortest + n);   // predecessor row per column
-    int* row4col = path + n;
-    int* col4row = row4col + n;
-    int* remaining = col4row + n;                       // unscanned columns, scipy's order
-    int* pos = remaining + n;                           // position of a column in `remaining`, -1 once scanned
-    int* rowseen = pos + n;                             // rows in the current tree
-    __shared__ Cand wave_best[2][kLsapWaves];
-
+    const bool vec_ok = (n % VEC == 0) && ((reinterpret_cast<uintptr_t>(cost) & 15) == 0);
+    double v[COLS], sj[COLS];
+    int pos[COLS], r4c[COLS];
+#pragma unroll
+    for (int k = 0; k < COLS; ++k) v[k] = 0.0;
     for (int t = tid; t < n; t += kLsapThreads) {
-        u[t] = 0.0;
-        v[t] = 0.0;
-        row4col[t] = -1;
-        col4row[t] = -1;
-        path[t] = -1;
+        sh.u[t] = 0.0;
+        sh.row4col[t] = -1;
+        sh.col4row[t] = -1;
+        sh.path[t] = -1;
     }
     __syncthreads();
 
     for (int cur = 0; cur < n; ++cur) {
-        for (int t = tid; t < n; t += kLsapThreads) {
-            remaining[t] = n - 1 - t;
-            pos[t] = n - 1 - t;  // column t sits at position n-1-t
-            shortest[t] = INFINITY;
-            rowseen[t] = 0;
+#pragma unroll
+        for (int k = 0; k < COLS; ++k) {
+            const int j = col_of<COLS>(tid, k);
+            pos[k] = j < n ? n - 1 - j : -1;  // reversed fill: column j sits at position n-1-j
+            sj[k] = INFINITY;
+            r4c[k] = j < n ? sh.row4col[j] : 0;
         }
+        for (int t = tid; t < n; t += kLsapThreads) sh.remaining[t] = n - 1 - t;
         __syncthreads();
 
         double dist = 0.0;
-        int i = cur, sink = -1, live = n;
-        int parity = 0;
+        int i = cur, sink = -1, live = n, nrows = 0, parity = 0;
         while (sink < 0) {
-            if (tid == 0) rowseen[i] = 1;
-            const double ui = u[i];
+            if (tid == 0) sh.rowlist[nrows] = i;
+            ++nrows;
+            const double ui = sh.u[i];
             const float* __restrict__ crow = cost + (size_t)i * n;
+            float c[COLS];
+            if (vec_ok) {
+#pragma unroll
+                for (int g = 0; g < COLS / VEC; ++g) {
+                    const int j0 = col_of<COLS>(tid, g * VEC);
+                    if constexpr (VEC == 4) {
+                        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (j0 < n) q = *reinterpret_cast<const float4*>(crow + j0);
+                        c[g * 4 + 0] = q.x, c[g * 4 + 1] = q.y, c[g * 4 + 2] = q.z, c[g * 4 + 3] = q.w;
+                    } else if constexpr (VEC == 2) {
+                        float2 q = make_float2(0.f, 0.f);
+                        if (j0 < n) q = *reinterpret_cast<const float2*>(crow + j0);
+                        c[g * 2 + 0] = q.x, c[g * 2 + 1] = q.y;
+                    } else {
+                        c[g] = j0 < n ? crow[j0] : 0.f;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < COLS; ++k) {
+                    const int j = col_of<COLS>(tid, k);
+                    c[k] = j < n ? crow[j] : 0.f;
+                }
+            }
             Cand best;
             best.val = INFINITY;
             best.key = 0x7fffffff;
-            best.col = -1;
-            for (int j = tid; j < n; j += kLsapThreads) {
-                const int pj = pos[j];
-                if (pj < 0) continue;
-                const double c = (double)(sign * crow[j]);
-                const double r = ((dist + c) - ui) - v[j];
-                double sj = shortest[j];
-                if (r < sj) {
-                    sj = r;
-                    shortest[j] = r;
-                    path[j] = i;
+#pragma unroll
+            for (int k = 0; k < COLS; ++k) {
+                const int j = col_of<COLS>(tid, k);
+                const bool livecol = pos[k] >= 0;
+                const double r = ((dist + (double)(sign * c[k])) - ui) - v[k];
+                if (livecol && r < sj[k]) {
+                    sj[k] = r;
+                    sh.path[j] = i;
                 }
                 Cand cand;
-                cand.val = sj;
-                cand.key = row4col[j] < 0 ? (n - 1 - pj) : (n + pj);
-                cand.col = j;
+                cand.val = livecol ? sj[k] : INFINITY;
+                const int tie = r4c[k] < 0 ? (n - 1 - pos[k]) : (n + pos[k]);
+                cand.key = livecol ? ((tie << 11) | j) : 0x7fffffff;
                 if (better(cand, best)) best = cand;
             }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const Cand o = shfl_xor_cand(best, off);
-                if (better(o, best)) best = o;
-            }
+            best = wave_min(best);
             if ((tid & 63) == 0) wave_best[parity][tid >> 6] = best;
             __syncthreads();  // the only barrier of a step
             best = wave_best[parity][0];
@@ -127,51 +180,81 @@ __global__ __launch_bounds__(kLsapThreads) void lsap_kernel(const LsapBatch batc
                 if (better(o, best)) best = o;
             }
             parity ^= 1;
-            // every thread now holds the same winner; bookkeeping is replicated, each LDS word has one writer
+            // Every thread holds the same winner and replays the same bookkeeping; each LDS word
+            // has one writer, and `remaining` slots written here are not read before the next barrier.
             dist = best.val;
-            const int j = best.col;
-            const int pj = best.key < n ? (n - 1 - best.key) : (best.key - n);
-            const int owner = row4col[j];
+            const int j = best.key & 2047;
+            const int tie = best.key >> 11;
+            const int pj = tie < n ? (n - 1 - tie) : (tie - n);
+            const int owner = sh.row4col[j];
             --live;
-            const int moved = remaining[live];
-            // Single-writer rule: pos[c] belongs to thread c % T (the only reader of pos[c] in the scan),
-            // `remaining` is written by thread 0 at a slot nobody reads before the next barrier.
-            if (tid == (j % kLsapThreads)) pos[j] = -1;
-            if (pj != live) {
-                if (tid == (moved % kLsapThreads)) pos[moved] = pj;
-                if (tid == 0) remaining[pj] = moved;
+            const int moved = sh.remaining[live];
+#pragma unroll
+            for (int k = 0; k < COLS; ++k) {
+                const int jj = col_of<COLS>(tid, k);
+                if (jj == j) pos[k] = -1;
+                else if (jj == moved && pj != live) pos[k] = pj;
             }
+            if (tid == 0 && pj != live) sh.remaining[pj] = moved;
             if (owner < 0)
                 sink = j;
             else
                 i = owner;
         }
 
-        // dual update (parallel), then augmentation (serial walk along the tree path)
-        for (int t = tid; t < n; t += kLsapThreads) {
-            if (t == cur)
-                u[t] += dist;
-            else if (rowseen[t])
-                u[t] += dist - shortest[col4row[t]];
+        // publish tentative lengths, then dual update (rows in LDS, columns in registers)
+#pragma unroll
+        for (int k = 0; k < COLS; ++k) {
+            const int j = col_of<COLS>(tid, k);
+            if (j < n) sh.shortest[j] = sj[k];
+            if (j < n && pos[k] < 0) v[k] -= dist - sj[k];
         }
-        for (int t = tid; t < n; t += kLsapThreads)
-            if (pos[t] < 0) v[t] -= dist - shortest[t];
         __syncthreads();
-        if (tid == 0) {
+        for (int t = tid; t < nrows; t += kLsapThreads) {
+            const int r = sh.rowlist[t];
+            sh.u[r] += (r == cur) ? dist : dist - sh.shortest[sh.col4row[r]];
+        }
+        __syncthreads();
+        if (tid == 0) {  // augment along the tree path back to `cur`
             int j = sink;
             for (;;) {
-                const int r = path[j];
-                row4col[j] = r;
-                const int prev = col4row[r];
-                col4row[r] = j;
+                const int r = sh.path[j];
+                sh.row4col[j] = r;
+                const int prev = sh.col4row[r];
+                sh.col4row[r] = j;
                 j = prev;
                 if (r == cur) break;
             }
         }
         __syncthreads();
     }
+    for (int t = tid; t < n; t += kLsapThreads) out[t] = sh.col4row[t];
+}
+
+__global__ __launch_bounds__(kLsapThreads) void lsap_kernel(const LsapBatch batch) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lsap_smem[];
+    __shared__ Cand wave_best[2][kLsapWaves];
+    const int prob = blockIdx.x;
+    const int n = batch.n[prob];
+    LsapShared sh;
+    sh.u = reinterpret_cast<double*>(lsap_smem);
+    sh.shortest = sh.u + n;
+    sh.path = reinterpret_cast<int*>(sh.shortest + n);
+    sh.row4col = sh.path + n;
+    sh.col4row = sh.row4col + n;
+    sh.remaining = sh.col4row + n;
+    sh.rowlist = sh.remaining + n;
+    const float sign = batch.maximize ? -1.f : 1.f;
+    const float* cost = batch.cost[prob];
     int64_t* out = batch.out[prob];
-    for (int t = tid; t < n; t += kLsapThreads) out[t] = col4row[t];
+    if (n <= kLsapThreads)
+        lsap_solve<1>(sh, cost, n, sign, out, wave_best);
+    else if (n <= 2 * kLsapThreads)
+        lsap_solve<2>(sh, cost, n, sign, out, wave_best);
+    else if (n <= 4 * kLsapThreads)
+        lsap_solve<4>(sh, cost, n, sign, out, wave_best);
+    else
+        lsap_solve<8>(sh, cost, n, sign, out, wave_best);
 }
 
 }  // namespace pleas
@@ -204,7 +287,7 @@ extern "C" int pleas_lsap_batched(const float* const* cost, const int* n, int np
             nmax = std::max(nmax, n[p]);
         }
         batch.maximize = maximize;
-        const size_t lds = (size_t)nmax * (3 * sizeof(double) + 6 * sizeof(int));
+        const size_t lds = (size_t)nmax * (2 * sizeof(double) + 5 * sizeof(int));
         ProfScope prof(kProfLsap, 0.0, 0.0, stream);
         hipLaunchKernelGGL(lsap_kernel, dim3(cnt), dim3(kLsapThreads), lds, stream, batch);
         PLEAS_LAUNCH_CHECK("lsap_kernel");

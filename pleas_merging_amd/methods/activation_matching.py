@@ -146,17 +146,39 @@ def _model_device(model: nn.Module) -> torch.device:
     return next(iter(model.parameters())).device
 
 
+def shard_batches(dataloader, num_batches: int, rank: int, world: int):
+    """Batches ``b`` with ``b % world == rank`` among the first ``num_batches`` of ``dataloader``
+    (whole batches only: the distance epilogue is per batch).  Consumes the loader
+    exactly like the reference's ``zip(dataloader, trange(num_batches))`` (:120)."""
+    for b, (batch, _) in enumerate(zip(dataloader, range(num_batches))):
+        if b % world == rank:
+            yield batch
+
+
+def allreduce_sum_(flat: torch.Tensor, world: int) -> torch.Tensor:
+    """The one exchange step of the matching path: sum the flat cost arena over ranks
+    (RCCL over xGMI under the ``nccl`` backend; gloo in the CPU tests)."""
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return flat
+
+
 def compute_matching_costs(spec: PermutationSpec, gm_cross: nn.Module, dataloader, num_batches: int,
-                           accumulate=True, device: Optional[torch.device] = None) -> Dict[Axis, torch.Tensor]:
+                           accumulate=True, device: Optional[torch.device] = None,
+                           shard: bool = True) -> Dict[Axis, torch.Tensor]:
     """Generic path over a module built by :func:`build_cross_module` with ANY ``cross_features``
     callable (reference: :103-136).  ``accumulate="reference"`` keeps only the last processed
     batch, which is what the reference computes (its membership test at :123-127 compares a
-    tuple with ``Axis`` keys and never succeeds); ``True`` sums over batches."""
+    tuple with ``Axis`` keys and never succeeds); ``True`` sums over batches (and shards them
+    over ranks when ``torch.distributed`` is initialised)."""
     if device is None:
         device = _model_device(gm_cross)
+    rank, world = _dist_info() if (shard and accumulate is True) else (0, 1)
     per_node: Dict[Axis, torch.Tensor] = {}
     with torch.inference_mode():
-        for (x, _), _ in zip(dataloader, range(num_batches)):
+        for x, _ in shard_batches(dataloader, num_batches, rank, world):
             _, cross = gm_cross(x.to(device))
             for (name, a), v in cross.items():
                 ax = Axis(name, a)
@@ -170,6 +192,10 @@ def compute_matching_costs(spec: PermutationSpec, gm_cross: nn.Module, dataloade
         for nax in group.node:
             if nax in per_node:
                 total = total + per_node[nax]
+        if world > 1:
+            if not torch.is_tensor(total):  # this rank saw no batch
+                total = torch.zeros(group.size, group.size, device=device)
+            allreduce_sum_(total, world)
         costs[key] = total
     return costs
 
@@ -190,16 +216,11 @@ def accumulate_costs_fused(spec: PermutationSpec, model1: nn.Module, model2: nn.
     gm = build_fused_module(spec, model1, model2, arena, epilogue)
     rank, world = _dist_info() if (shard and accumulate is True) else (0, 1)
     with torch.inference_mode():
-        for b, ((x, _), _) in enumerate(zip(dataloader, range(num_batches))):
-            if b % world != rank:
-                continue
+        for x, _ in shard_batches(dataloader, num_batches, rank, world):
             if accumulate is not True:
                 arena.zero_()
             gm(x.to(device, non_blocking=True))
-    if world > 1:
-        import torch.distributed as dist
-
-        dist.all_reduce(arena.flat, op=dist.ReduceOp.SUM)
+    allreduce_sum_(arena.flat, world)
     return dict(arena.view)
 
 

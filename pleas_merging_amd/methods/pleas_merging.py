@@ -128,6 +128,25 @@ def _fallback_out_width(separate_classifier: bool, model_type: str, num_classes:
     return widths[model_type]
 
 
+def dp_slice(x: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    """Rank's share of one batch under data-parallel PLeaS: contiguous, equal sample chunks."""
+    if world == 1:
+        return x
+    if x.shape[0] % world:
+        raise RuntimeError("batch of %d samples does not split over %d ranks" % (x.shape[0], world))
+    return x.chunk(world)[rank]
+
+
+def dp_sum_(flat: torch.Tensor, world: int) -> torch.Tensor:
+    """Sum of the flat gradient arena over ranks (ONE collective per update).  Each rank scales its
+    residual by 2 / (local numel * world), so the sum IS the gradient of the full-batch mean."""
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return flat
+
+
 class PleasFitter:
     """State of one PLeaS run: flat arenas + per-layer plans.  ``train`` drives it; the bench
     uses it directly to time single steps."""
@@ -225,10 +244,7 @@ class PleasFitter:
     def step(self, x: torch.Tensor) -> None:
         """One update: reference ``step`` (:234-302) + ``lr_sched.step()`` (:375)."""
         x = x.to(self.device, non_blocking=True)
-        if self.world > 1:
-            if x.shape[0] % self.world:
-                raise RuntimeError("batch of %d samples does not split over %d ranks" % (x.shape[0], self.world))
-            x = x.chunk(self.world)[self.rank]
+        x = dp_slice(x, self.rank, self.world)
         self.model1(x)
         self.model2(x)
         for idx, plan in enumerate(self.plans):
@@ -236,11 +252,8 @@ class PleasFitter:
                 print("Key error on %s" % plan.name)
                 continue
             self._fit_layer(idx, plan)
-        if self.world > 1:
-            import torch.distributed as dist
-
-            dist.all_reduce(self.g, op=dist.ReduceOp.SUM)
-            dist.all_reduce(self.loss_now, op=dist.ReduceOp.SUM)
+        dp_sum_(self.g, self.world)
+        dp_sum_(self.loss_now, self.world)
         self.loss_sum.add_(self.loss_now)
         lr = self.lrs[min(self.step_count, len(self.lrs) - 1)]
         self.step_count += 1

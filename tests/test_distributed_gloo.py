@@ -1,0 +1,89 @@
+"""world_size-2 tests on CPU (gloo) of the two exchange steps: batch-sharded cost accumulation
+(one all-reduce of the cost matrices) and sample-sharded PLeaS gradients (one all-reduce of the
+flat gradient arena).  The collectives are the same calls the RCCL path makes."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import REPO
+
+
+def _init(rank, world, port):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _matching_worker(rank, world, port, q):
+    _init(rank, world, port)
+    from conftest import Tiny
+    from oracle import pleas_oracle as orc
+    from pleas.core.solvers import scipy_solve_lsa
+    from pleas.methods.activation_matching import activation_matching, shard_batches
+
+    t = Tiny("tiny_basic.npz")
+    mine = [b for b, _ in enumerate(shard_batches(t.batches(), 4, rank, world))]
+    perm, costs = activation_matching(t.spec, t.m1, t.m2, t.batches(), 4, cross_features=orc.cross_features_cdist,
+                                      lsa_solver=scipy_solve_lsa, output_costs=True, accumulate=True)
+    want_p, want_c = orc.activation_matching(t.spec, t.m1, t.m2, t.batches(), 4, accumulate=True)
+    ok = len(mine) == 2
+    for k in t.spec:
+        ok &= bool(torch.allclose(costs[k], want_c[k], rtol=1e-5, atol=1e-4))
+        ok &= bool((perm[k] == want_p[k]).all())
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def _gradient_worker(rank, world, port, q):
+    _init(rank, world, port)
+    import torch.nn.functional as F
+
+    from pleas.methods.pleas_merging import dp_slice, dp_sum_
+
+    g = torch.Generator().manual_seed(0)
+    x, target = torch.randn(8, 6, 9, 9, generator=g), torch.randn(8, 5, 9, 9, generator=g)
+    w = torch.randn(5, 6, 3, 3, generator=g, requires_grad=True)
+    ((F.conv2d(x, w, padding=1) - target) ** 2).mean().backward()  # full-batch gradient of the PLeaS objective
+    xs, ts = dp_slice(x, rank, world), dp_slice(target, rank, world)
+    out = F.conv2d(xs, w.detach(), padding=1)
+    resid = 2.0 * (out - ts) / (out.numel() * world)
+    gw = torch.ops.aten.convolution_backward(resid, xs, w.detach(), None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                             [False, True, False])[1]
+    flat = gw.reshape(-1).clone()
+    dp_sum_(flat, world)
+    q.put((rank, bool(torch.allclose(flat.view_as(w), w.grad, rtol=1e-5, atol=1e-7))))
+    dist.destroy_process_group()
+
+
+def _run(worker, port):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(results) == [(0, True), (1, True)], results
+
+
+def test_sharded_cost_accumulation_gloo():
+    _run(_matching_worker, 29611)
+
+
+def test_sharded_pleas_gradient_gloo():
+    _run(_gradient_worker, 29612)
+
+
+def test_dp_slice_rejects_ragged_batches():
+    from pleas.methods.pleas_merging import dp_slice
+
+    with pytest.raises(RuntimeError):
+        dp_slice(torch.zeros(5, 3), 0, 2)
+    assert dp_slice(torch.arange(8).view(8, 1), 1, 2).flatten().tolist() == [4, 5, 6, 7]

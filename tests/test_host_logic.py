@@ -1,0 +1,204 @@
+"""CPU tests (no GPU): host-side logic of the drop-in API, the C-ABI surface, loud failure."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, REPO
+from oracle import pleas_oracle as orc
+from pleas_merging_amd.core.utils import Axis, PermutationGroup, spec_to_json
+
+
+# ------------------------------------------------------------------ spec builder (G1)
+@pytest.mark.parametrize("name", ["resnet18", "resnet50", "resnet101", "resnet50_identity_fc"])
+def test_spec_matches_reference_fixture(name):
+    from pleas.core.compiler import get_permutation_spec
+    from pleas_merging_amd import resnet as zoo
+
+    m = getattr(zoo, name.split("_")[0])()
+    if name.endswith("identity_fc"):
+        m.fc = torch.nn.Identity()
+    spec = get_permutation_spec(m, ((1, 3, 224, 224),))
+    gold = json.load(open(os.path.join(GOLDEN, "spec_%s.json" % name)))["spec"]
+    assert spec_to_json(spec) == gold  # same keys, same ORDER, same sizes / state / node sets
+
+
+def test_spec_function_invariance(tiny_bottleneck):
+    from pleas.core.compiler import check_permutation_spec, get_permutation_spec
+
+    m = tiny_bottleneck.m1
+    spec = get_permutation_spec(m, ((2, 3, 32, 32),))
+    assert spec_to_json(spec) == spec_to_json(tiny_bottleneck.spec)
+    assert check_permutation_spec(m, spec, torch.randn(2, 3, 32, 32))
+
+
+def test_unsupported_op_raises():
+    from pleas.core.compiler import get_permutation_spec
+
+    class Odd(torch.nn.Module):
+        def forward(self, x):
+            return torch.cumsum(x, 1)
+
+    with pytest.raises(NotImplementedError):
+        get_permutation_spec(Odd(), ((2, 4),))
+
+
+# ------------------------------------------------------------------ types / permutations
+def test_axis_and_perm_helpers(tiny_basic):
+    from pleas.core.utils import apply_perm, invert_perm, make_identity_perm, make_random_perm, perm_eq
+
+    assert str(Axis("layer1.0.conv1.weight", 0)) == "layer1.0.conv1.weight:0"
+    assert Axis("a", 1) == Axis("a", 1) and ("a", 1) not in {Axis("a", 1): 0}  # the reference's F2 trap
+    spec = tiny_basic.spec
+    p = make_random_perm(spec, torch.Generator().manual_seed(0))
+    assert perm_eq(invert_perm(invert_perm(p)), p)
+    sd = tiny_basic.m1.state_dict()
+    back = apply_perm(invert_perm(p), spec, apply_perm(p, spec, sd))
+    assert all(torch.equal(back[k], sd[k]) for k in sd)
+    assert perm_eq(make_identity_perm(spec), {k: torch.arange(g.size) for k, g in spec.items()})
+    with pytest.raises(AssertionError):
+        apply_perm(p, spec, tiny_basic.m1, inplace=False)
+
+
+# ------------------------------------------------------------------ plug points on CPU callables
+def test_activation_matching_generic_path_cpu(tiny_bottleneck):
+    from pleas.core.solvers import scipy_solve_lsa
+    from pleas.methods.activation_matching import activation_matching
+
+    t = tiny_bottleneck
+    perm, costs = activation_matching(t.spec, t.m1, t.m2, t.batches(), 3, cross_features=orc.cross_features_cdist,
+                                      lsa_solver=scipy_solve_lsa, output_costs=True, accumulate="reference")
+    for k in t.spec:
+        assert (perm[k] == t.per_key("am_perm")[k]).all()
+        assert torch.allclose(costs[k], t.per_key("am_cost")[k], rtol=1e-5, atol=1e-5)
+
+
+def test_weight_matching_host_loop_cpu(tiny_basic):
+    from pleas.core.solvers import scipy_solve_lsa
+    from pleas.methods.weight_matching import weight_matching
+
+    t = tiny_basic
+    perm, costs = weight_matching(t.spec, t.m1.state_dict(), t.m2.state_dict(), max_iter=100, seed=0, verbose=False,
+                                  lsa_solver=scipy_solve_lsa, cross_weights=orc.cross_features_inner_product,
+                                  return_costs=True)
+    for k in t.spec:
+        assert (perm[k] == torch.from_numpy(t.z["wm_perm/%s" % k])).all()
+        assert torch.allclose(costs[k], torch.from_numpy(t.z["wm_cost/%s" % k]), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("ratio", [0.0, 0.5, 1.0])
+def test_get_blocks_cpu_tensors(tiny_basic, ratio):
+    from pleas.methods.partial_matching import block_maps, get_blocks
+
+    t = tiny_basic
+    blocks = get_blocks(t.spec, t.per_key("am_perm"), t.per_key("am_cost"), ratio, False)
+    tag = "r%03d" % int(ratio * 100)
+    for k in t.spec:
+        for j in range(4):
+            assert (blocks[k][j] == torch.from_numpy(t.z["blocks_%s/%s/%d" % (tag, k, j)])).all()
+        r1, r2, nm = block_maps(blocks[k], "cpu")
+        assert nm == len(blocks[k][0]) and len(r1) == len(r2) == nm + 2 * len(blocks[k][2])
+        assert (r1[nm:nm + len(blocks[k][2])] >= 0).all() and (r1[nm + len(blocks[k][2]):] == -1).all()
+
+
+def test_gradient_mask_matches_oracle(tiny_basic):
+    from pleas.methods.partial_matching import get_blocks, spread_blocks
+    from pleas.methods.pleas_merging import get_gradient_mask
+
+    t = tiny_basic
+    blocks = spread_blocks(t.spec, get_blocks(t.spec, t.per_key("am_perm"), t.per_key("am_cost"), 0.5, False))
+    m3 = orc.partial_merge(t.spec, t.m1, t.m2, t.per_key("am_perm"), t.per_key("am_cost"), 0.5)
+    layers = {n: m for n, m in m3.named_modules() if isinstance(m, (torch.nn.Conv2d, torch.nn.Linear))}
+    got, want = get_gradient_mask(blocks, layers), orc.gradient_masks(blocks, layers)
+    assert len(got) == len(want) and all(torch.equal(a, b) for a, b in zip(got, want))
+    assert any((m == 0).any() for m in got)  # ratio 0.5 really freezes blocks
+
+
+def test_cosine_lrs_equal_torch_scheduler():
+    from pleas.methods.pleas_merging import cosine_lrs  # noqa: F401
+    from pleas_merging_amd.methods.pleas_merging import cosine_lrs
+
+    for t_max in (1, 5, 20, 400):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.Adam([p], lr=5e-4)
+        sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, t_max)
+        want = []
+        for _ in range(t_max + 1):
+            want.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sched.step()
+        assert cosine_lrs(5e-4, t_max, t_max + 1) == want
+
+
+# ------------------------------------------------------------------ C-ABI surface
+def _declared_symbols():
+    text = open(os.path.join(REPO, "include", "pleas_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pleas_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from pleas_merging_amd import _lib, build
+
+    if not os.path.exists(_lib.LIB_PATH):
+        build.build()
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared_symbols()
+    assert len(names) >= 12
+    for name in names:
+        assert hasattr(handle, name), "libpleas_hip.so lacks %s declared in include/pleas_hip.h" % name
+    assert set(_lib.SIGNATURES) == set(names), set(_lib.SIGNATURES) ^ set(names)
+    handle.pleas_version.restype = ctypes.c_char_p
+    assert b"gfx950" in handle.pleas_version()
+
+
+def test_argument_errors_without_gpu():
+    """Host-side validation returns error codes before anything touches a device."""
+    from pleas_merging_amd import _lib
+
+    lib = _lib.lib()
+    assert lib.pleas_gram_accum(None, None, 1, 4, 4, 0, 0, None, None, 0, None) == -22
+    assert b"null" in lib.pleas_last_error()
+    assert lib.pleas_gram_ws_bytes(16, 256, 196) >= 256 * 256 * 4
+    assert lib.pleas_gram_ws_bytes(0, 256, 196) == 0
+    n = (ctypes.c_int * 1)(4096)
+    ptr = (ctypes.c_void_p * 1)(8)
+    assert lib.pleas_lsap_batched(ptr, n, 1, 1, ptr, None) == -22  # n > PLEAS_LSAP_MAX_N
+    assert lib.pleas_masked_adam(None, None, None, None, None, 4, 1e-3, 0.9, 0.999, 1e-8, 1, None) == -22
+
+
+def test_product_path_fails_loudly_on_cpu(tiny_basic):
+    from pleas.methods.activation_matching import activation_matching, cross_features_cdist
+    from pleas.methods.partial_matching import partial_merge
+    from pleas.methods.pleas_merging import train
+    from pleas.methods.weight_matching import weight_matching
+    from pleas_merging_amd.hip_ops import PleasHipError
+
+    t = tiny_basic
+    with pytest.raises(PleasHipError):
+        cross_features_cdist(torch.randn(2, 4, 3, 3), torch.randn(2, 4, 3, 3), 1)
+    with pytest.raises(RuntimeError):
+        activation_matching(t.spec, t.m1, t.m2, t.batches(), 1)
+    with pytest.raises(PleasHipError):
+        weight_matching(t.spec, t.m1.state_dict(), t.m2.state_dict(), verbose=False)
+    if not torch.cuda.is_available():
+        with pytest.raises((PleasHipError, RuntimeError, AssertionError)):
+            partial_merge(t.spec, t.m1, t.m2, t.per_key("am_perm"), t.per_key("am_cost"), 0.5)
+    m3 = orc.partial_merge(t.spec, t.m1, t.m2, t.per_key("am_perm"), t.per_key("am_cost"), 0.5)
+    with pytest.raises(PleasHipError):
+        train(t.batches("xt"), t.m1, t.m2, m3, t.spec, t.per_key("am_perm"), t.per_key("am_cost"), 0.5, False, 2, None,
+              num_classes=10)
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under pleas_merging_amd/ or pleas/ may import it."""
+    for root in ("pleas_merging_amd", "pleas"):
+        for dirpath, _, files in os.walk(os.path.join(REPO, root)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".hpp", ".h")):
+                    text = open(os.path.join(dirpath, f)).read()
+                    assert "oracle" not in text.replace("oracle/", "").lower() or f == "build.py", os.path.join(dirpath, f)
