@@ -86,28 +86,41 @@ __global__ __launch_bounds__(kThreads) void gram_partial_kernel(const GramGeom g
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    // Row validity is fixed per thread; loads are UNCONDITIONAL from clamped (always valid) addresses
+    // and masked when written to LDS, so all loads of a chunk stay in flight behind the MFMAs
+    // (a predicated load makes hipcc branch and wait vmcnt(0) per load).
+    unsigned rows_ok_a = 0, rows_ok_b = 0;
+    size_t row_off_a[PASSES], row_off_b[PASSES];
+#pragma unroll
+    for (int q = 0; q < PASSES; ++q) {
+        const int row = srow + q * ROWS_PER_PASS;
+        const int gi = i0 + row, gj = j0 + row;
+        if (gi < g.C) rows_ok_a |= 1u << q;
+        if (gj < g.C) rows_ok_b |= 1u << q;
+        row_off_a[q] = (size_t)min(gi, g.C - 1) * g.HW;
+        row_off_b[q] = (size_t)min(gj, g.C - 1) * g.HW;
+    }
+    bool staged_kin = false;
     auto load_chunk = [&](int c) {
         const uint32_t k = (uint32_t)c * kBK + scol;
         const bool kin = k < g.Ktot;
         const uint32_t n = kin ? k / g.HW : 0u;
         const uint32_t p = kin ? k - n * g.HW : 0u;
         const size_t base = (size_t)n * g.C * g.HW + p;
+        staged_kin = kin;
 #pragma unroll
         for (int q = 0; q < PASSES; ++q) {
-            const int row = srow + q * ROWS_PER_PASS;
-            const int gi = i0 + row, gj = j0 + row;
             if constexpr (VEC == 4) {
-                f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
-                if (kin && gi < g.C) va = *reinterpret_cast<const f32x4*>(g.x + base + (size_t)gi * g.HW);
-                if (kin && gj < g.C) vb = *reinterpret_cast<const f32x4*>(g.y + base + (size_t)gj * g.HW);
+                const f32x4 va = *reinterpret_cast<const f32x4*>(g.x + base + row_off_a[q]);
+                const f32x4 vb = *reinterpret_cast<const f32x4*>(g.y + base + row_off_b[q]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     ra.v[q][e] = va[e];
                     rb.v[q][e] = vb[e];
                 }
             } else {
-                ra.v[q][0] = (kin && gi < g.C) ? g.x[base + (size_t)gi * g.HW] : 0.f;
-                rb.v[q][0] = (kin && gj < g.C) ? g.y[base + (size_t)gj * g.HW] : 0.f;
+                ra.v[q][0] = g.x[base + row_off_a[q]];
+                rb.v[q][0] = g.y[base + row_off_b[q]];
             }
         }
     };
@@ -117,6 +130,13 @@ __global__ __launch_bounds__(kThreads) void gram_partial_kernel(const GramGeom g
 #pragma unroll
         for (int q = 0; q < PASSES; ++q) {
             const int row = srow + q * ROWS_PER_PASS;
+            const bool oka = staged_kin && ((rows_ok_a >> q) & 1u);
+            const bool okb = staged_kin && ((rows_ok_b >> q) & 1u);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                ra.v[q][e] = oka ? ra.v[q][e] : 0.f;
+                rb.v[q][e] = okb ? rb.v[q][e] : 0.f;
+            }
             if constexpr (VEC == 4) {
                 f32x4 va = {ra.v[q][0], ra.v[q][1], ra.v[q][2], ra.v[q][3]};
                 f32x4 vb = {rb.v[q][0], rb.v[q][1], rb.v[q][2], rb.v[q][3]};
@@ -161,13 +181,19 @@ __global__ __launch_bounds__(kThreads) void gram_partial_kernel(const GramGeom g
         store_chunk(0);
     }
     __syncthreads();
+#ifndef PLEAS_GRAM_ABLATE
+#define PLEAS_GRAM_ABLATE 0
+#endif
     for (int c = c_begin; c < c_end; ++c) {
         const int buf = (c - c_begin) & 1;
         const bool more = c + 1 < c_end;
-        if (more) load_chunk(c + 1);
-        compute(buf);
-        if (more) store_chunk(buf ^ 1);
-        __syncthreads();
+        // ablation builds (tools/hipbench): 1 = no global loads, 2 = no MFMA, 3 = no LDS restage/barrier
+        if (more && PLEAS_GRAM_ABLATE != 1 && PLEAS_GRAM_ABLATE != 3) load_chunk(c + 1);
+        if (PLEAS_GRAM_ABLATE != 2) compute(PLEAS_GRAM_ABLATE == 3 ? 0 : buf);
+        if (PLEAS_GRAM_ABLATE != 3) {
+            if (more) store_chunk(buf ^ 1);
+            __syncthreads();
+        }
     }
 
     // ---- partial tile -> workspace slab `split`
