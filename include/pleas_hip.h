@@ -57,6 +57,31 @@ size_t pleas_gram_ws_bytes(int B, int C, int64_t HW);
 int pleas_gram_accum(const float* x, const float* y, int B, int C, int64_t HW, int epilogue, int accumulate,
                      float* acc, void* ws, size_t ws_bytes, void* stream);
 
+/* Grouped form: ALL tracked nodes of one batch in one contraction grid plus one reduce grid.
+ *
+ * Replaces one whole iteration of the hot loop at activation_matching.py:120-127 plus the
+ * per-group sum at :129-134: node i contributes epilogue(x_i, y_i) to the matrix of its group.
+ * nodes[i]      : HOST array; x, y as in pleas_gram_accum ([B][C][HW] views), group index
+ * group_acc[g]  : DEVICE C_g x C_g fp32 matrices (HOST array of pointers); group_C[g] HOST sizes
+ * accumulate    : 0 -> group matrices are overwritten by this batch's sum, 1 -> added to
+ * Work is cut into (node, tile, K-range) items of near-equal length, sorted longest first; each
+ * node's partial products go to its own slab in `ws`, and the reduce grid sums slabs and nodes in a
+ * FIXED order (deterministic, no atomics).  ws >= pleas_gram_batch_ws_bytes(...).
+ * The work list is cached per (shape sequence, ws, group matrices); only operand pointers change
+ * from batch to batch.
+ */
+typedef struct pleas_gram_node {
+    const float* x;
+    const float* y;
+    int B;
+    int C;
+    int64_t HW;
+    int group;
+} pleas_gram_node;
+size_t pleas_gram_batch_ws_bytes(const pleas_gram_node* nodes, int n_nodes, const int* group_C, int n_groups);
+int pleas_gram_batch(const pleas_gram_node* nodes, int n_nodes, float* const* group_acc, const int* group_C,
+                     int n_groups, int epilogue, int accumulate, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Batched linear assignment (square, dense), one workgroup per problem.
  *
@@ -131,6 +156,7 @@ int pleas_prof_collect(int kernel, int64_t* launches, double* total_ms, double* 
 
 /* Tuning hook for experiments: split-K target workgroup count and minimum K chunks per split. */
 void pleas_gram_tune(int target_blocks, int min_chunks_per_split);
+void pleas_gram_batch_tune(int item_chunks);
 
 #ifdef __cplusplus
 }

@@ -35,7 +35,16 @@ SIGNATURES = {
     "pleas_prof_collect": (c_int, [c_int, POINTER(c_int64), POINTER(ctypes.c_double), POINTER(ctypes.c_double),
                                    POINTER(ctypes.c_double)]),
     "pleas_gram_tune": (None, [c_int, c_int]),
+    "pleas_gram_batch_tune": (None, [c_int]),
+    "pleas_gram_batch_ws_bytes": (c_size_t, [c_void_p, c_int, POINTER(c_int), c_int]),
+    "pleas_gram_batch": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_int), c_int, c_int, c_int, c_void_p,
+                                 c_size_t, c_void_p]),
 }
+
+
+class GramNode(ctypes.Structure):
+    """struct pleas_gram_node"""
+    _fields_ = [("x", c_void_p), ("y", c_void_p), ("B", c_int), ("C", c_int), ("HW", c_int64), ("group", c_int)]
 
 PROF_KERNELS = ["gram_partial", "gram_finalize", "lsap", "merge_blocks", "masked_adam", "sqerr", "conv_fwd",
                 "conv_wgrad", "normal_eq", "solve"]

@@ -18,6 +18,8 @@
 // Roofline: per node 2*C^2*K flop over 2*C*K*4 bytes = C/4 flop/B:
 // fp32-MFMA-bound for C >= 128 (157 TFLOP/s), HBM-bound for C <= 64.
 #include <algorithm>
+#include <mutex>
+#include <vector>
 
 #include "common.hpp"
 
@@ -49,27 +51,21 @@ struct Stage {
     float v[PASSES][VEC];
 };
 
+// One workgroup's share: output tile (tm, tn) over K chunks [c_begin, c_end) -> slab `split`.
 template <int TILE, int VEC>
-__global__ __launch_bounds__(kThreads) void gram_partial_kernel(const GramGeom g) {
+__device__ __forceinline__ void gram_tile(const GramGeom& g, float* smem, const int tm, const int tn, const int split,
+                                          const int c_begin, const int c_end) {
     constexpr int MT = TILE / 64;                    // 32x32 MFMA tiles per wave per side
     constexpr int LANES_PER_ROW = kBK / VEC;         // 8 (16-B loads) or 32 (4-B loads)
     constexpr int ROWS_PER_PASS = kThreads / LANES_PER_ROW;
     constexpr int PASSES = TILE / ROWS_PER_PASS;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                         // [2][TILE][kLds]
     float* Bs = smem + 2 * TILE * kLds;       // [2][TILE][kLds]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    int bid = blockIdx.x;
-    const int tn = bid % g.tiles;
-    bid /= g.tiles;
-    const int tm = bid % g.tiles;
-    const int split = bid / g.tiles;
     const int i0 = tm * TILE, j0 = tn * TILE;
-    const int c_begin = split * g.chunks_per_split;
-    const int c_end = min(c_begin + g.chunks_per_split, g.nchunks);
 
     const int srow = tid / LANES_PER_ROW;
     const int scol = (tid % LANES_PER_ROW) * VEC;
@@ -226,6 +222,111 @@ __global__ __launch_bounds__(kThreads) void gram_partial_kernel(const GramGeom g
     }
 }
 
+// Single-node launch: grid = tiles x tiles x S.
+template <int TILE, int VEC>
+__global__ __launch_bounds__(kThreads) void gram_partial_kernel(const GramGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int bid = blockIdx.x;
+    const int tn = bid % g.tiles;
+    bid /= g.tiles;
+    const int tm = bid % g.tiles;
+    const int split = bid / g.tiles;
+    const int c_begin = split * g.chunks_per_split;
+    gram_tile<TILE, VEC>(g, smem, tm, tn, split, c_begin, min(c_begin + g.chunks_per_split, g.nchunks));
+}
+
+// ---- grouped launch: every tracked node of a batch in ONE grid --------------------------------
+struct GramNodeDev {      // device node table entry
+    const float* x;
+    const float* y;
+    float* gpart;         // [S][C][C] slabs of this node
+    float* npart;         // [S][2][C]
+    int C;
+    uint32_t HW;
+    uint32_t Ktot;
+    int variant;          // 0: <128,4>  1: <128,1>  2: <64,4>  3: <64,1>
+    int S;
+    int group;
+    int pad[2];
+};
+struct GramItemDev {      // one workgroup of the grouped launch
+    int node, tm, tn, split, c_begin, c_end, pad0, pad1;
+};
+
+__global__ __launch_bounds__(kThreads) void gram_batch_kernel(const GramNodeDev* __restrict__ nodes,
+                                                              const GramItemDev* __restrict__ items) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const GramItemDev it = items[blockIdx.x];
+    const GramNodeDev nd = nodes[it.node];
+    GramGeom g;
+    g.x = nd.x;
+    g.y = nd.y;
+    g.gpart = nd.gpart;
+    g.npart = nd.npart;
+    g.C = nd.C;
+    g.HW = nd.HW;
+    g.Ktot = nd.Ktot;
+    g.nchunks = 0;
+    g.chunks_per_split = 0;
+    g.tiles = 0;
+    switch (nd.variant) {  // block-uniform
+        case 0: gram_tile<128, 4>(g, smem, it.tm, it.tn, it.split, it.c_begin, it.c_end); break;
+        case 1: gram_tile<128, 1>(g, smem, it.tm, it.tn, it.split, it.c_begin, it.c_end); break;
+        case 2: gram_tile<64, 4>(g, smem, it.tm, it.tn, it.split, it.c_begin, it.c_end); break;
+        default: gram_tile<64, 1>(g, smem, it.tm, it.tn, it.split, it.c_begin, it.c_end); break;
+    }
+}
+
+// Writes the per-batch operand pointers into the device node table (kernel arguments carry them,
+// so no host staging buffer has to outlive the call).
+constexpr int kPtrBatch = 224;
+struct GramPtrBatch {
+    int base, count;
+    const float* x[kPtrBatch];
+    const float* y[kPtrBatch];
+};
+__global__ void gram_set_ptrs_kernel(GramNodeDev* __restrict__ nodes, const GramPtrBatch b) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < b.count) {
+        nodes[b.base + t].x = b.x[t];
+        nodes[b.base + t].y = b.y[t];
+    }
+}
+
+// Per group: acc (+)= sum over its nodes (fixed order) of epilogue(sum over slabs of G, norms).
+// One thread per element; blocks are mapped to (group, local block) through a table.
+struct GramGroupDev {
+    float* acc;
+    int C;
+    int node_begin, node_end;  // range in the group-ordered node index list
+    int blk_begin;             // first block of this group in the reduce grid
+    int pad;
+};
+__global__ __launch_bounds__(256) void gram_group_reduce_kernel(const GramNodeDev* __restrict__ nodes,
+                                                                const GramGroupDev* __restrict__ groups,
+                                                                const int* __restrict__ group_nodes,
+                                                                const int* __restrict__ blk_group, int epilogue,
+                                                                int accumulate) {
+    const int gidx = blk_group[blockIdx.x];
+    const GramGroupDev gr = groups[gidx];
+    const size_t total = (size_t)gr.C * gr.C;
+    const size_t idx = (size_t)(blockIdx.x - gr.blk_begin) * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int i = (int)(idx / gr.C), j = (int)(idx - (size_t)i * gr.C);
+    float out = accumulate ? gr.acc[idx] : 0.f;
+    for (int t = gr.node_begin; t < gr.node_end; ++t) {
+        const GramNodeDev nd = nodes[group_nodes[t]];
+        float gsum = 0.f, nx = 0.f, ny = 0.f;
+        for (int s = 0; s < nd.S; ++s) {
+            gsum += nd.gpart[(size_t)s * total + idx];
+            nx += nd.npart[((size_t)s * 2 + 0) * gr.C + i];
+            ny += nd.npart[((size_t)s * 2 + 1) * gr.C + j];
+        }
+        out += epilogue == PLEAS_EPI_NEG_CDIST ? -sqrtf(fmaxf(nx + ny - 2.f * gsum, 0.f)) : gsum;
+    }
+    gr.acc[idx] = out;
+}
+
 // Ordered reduction of the split-K slabs + epilogue + accumulation into the group matrix.
 __global__ __launch_bounds__(256) void gram_finalize_kernel(const float* __restrict__ gpart,
                                                             const float* __restrict__ npart, float* __restrict__ acc,
@@ -330,5 +431,228 @@ extern "C" int pleas_gram_accum(const float* x, const float* y, int B, int C, in
     hipLaunchKernelGGL(gram_finalize_kernel, dim3(fgrid), dim3(256), 0, stream, g.gpart, g.npart, acc, C, p.S, epilogue,
                        accumulate);
     PLEAS_LAUNCH_CHECK("gram_finalize_kernel");
+    return PLEAS_OK;
+}
+
+// =========================================================================================
+// Grouped launch: all tracked nodes of one batch -> one contraction grid + one reduce grid.
+// =========================================================================================
+namespace pleas {
+
+static int g_item_chunks = 112;  // K chunks per work item (K = 3584): nodes with longer K are split
+
+struct BatchPlan {
+    std::vector<int64_t> key;
+    std::vector<GramNodeDev> nodes;
+    std::vector<GramItemDev> items;
+    std::vector<GramGroupDev> groups;
+    std::vector<int> group_nodes, blk_group;
+    size_t off_nodes = 0, off_items = 0, off_groups = 0, off_gn = 0, off_bg = 0, off_slabs = 0, total = 0;
+    int reduce_blocks = 0;
+    size_t lds = 0;
+    double flops = 0, bytes = 0, slab_bytes = 0;
+    bool uploaded = false;
+};
+static BatchPlan g_bplan;
+static std::mutex g_bplan_mu;
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Layout + work list for a node sequence; device pointers are filled relative to `ws` later.
+static int build_batch_plan(BatchPlan& P, const pleas_gram_node* nd, int n, float* const* group_acc, const int* group_C,
+                            int n_groups) {
+    P.nodes.assign(n, GramNodeDev());
+    P.items.clear();
+    P.groups.assign(n_groups, GramGroupDev());
+    P.group_nodes.clear();
+    P.blk_group.clear();
+    P.flops = P.bytes = P.slab_bytes = 0;
+    P.lds = 0;
+    std::vector<size_t> slab_off(n);
+    size_t slabs = 0;
+    struct Work { double w; GramItemDev it; };
+    std::vector<Work> work;
+    for (int i = 0; i < n; ++i) {
+        const int B = nd[i].B, C = nd[i].C;
+        const int64_t HW = nd[i].HW;
+        if (B <= 0 || C <= 0 || HW <= 0 || (int64_t)B * HW >= (1ll << 31)) return bad_arg("gram_batch: node shape");
+        if (nd[i].group < 0 || nd[i].group >= n_groups || group_C[nd[i].group] != C) return bad_arg("gram_batch: node group");
+        const int tile = C > 64 ? 128 : 64;
+        const int vec = (HW % 4 == 0) ? 4 : 1;  // operand alignment is checked per call
+        const int tiles = (int)ceil_div(C, tile);
+        const int nchunks = (int)ceil_div((int64_t)B * HW, kBK);
+        const int S = (int)ceil_div(nchunks, g_item_chunks);
+        const int cps = (int)ceil_div(nchunks, S);
+        GramNodeDev& d = P.nodes[i];
+        d.C = C;
+        d.HW = (uint32_t)HW;
+        d.Ktot = (uint32_t)((int64_t)B * HW);
+        d.variant = (tile == 128 ? 0 : 2) + (vec == 4 ? 0 : 1);
+        d.S = S;
+        d.group = nd[i].group;
+        slab_off[i] = slabs;
+        slabs += (size_t)S * ((size_t)C * C + 2 * (size_t)C);
+        P.lds = std::max(P.lds, (size_t)4 * tile * kLds * sizeof(float));
+        const double kk = (double)B * (double)HW;
+        P.flops += 2.0 * C * (double)C * kk;
+        P.bytes += 2.0 * C * kk * sizeof(float);
+        for (int s = 0; s < S; ++s)
+            for (int tm = 0; tm < tiles; ++tm)
+                for (int tn = 0; tn < tiles; ++tn) {
+                    Work w;
+                    w.it = GramItemDev{i, tm, tn, s, s * cps, std::min((s + 1) * cps, nchunks), 0, 0};
+                    w.w = (double)(w.it.c_end - w.it.c_begin) * tile * tile;
+                    work.push_back(w);
+                }
+    }
+    std::stable_sort(work.begin(), work.end(), [](const Work& a, const Work& b) { return a.w > b.w; });
+    P.items.reserve(work.size());
+    for (auto& w : work) P.items.push_back(w.it);
+    // groups: node lists in first-appearance order, reduce blocks of 256 elements
+    int blk = 0;
+    for (int g = 0; g < n_groups; ++g) {
+        GramGroupDev& G = P.groups[g];
+        G.acc = group_acc[g];
+        G.C = group_C[g];
+        G.node_begin = (int)P.group_nodes.size();
+        for (int i = 0; i < n; ++i)
+            if (nd[i].group == g) P.group_nodes.push_back(i);
+        G.node_end = (int)P.group_nodes.size();
+        G.blk_begin = blk;
+        const int nb = G.node_end > G.node_begin ? (int)ceil_div((int64_t)G.C * G.C, 256) : 0;
+        for (int b = 0; b < nb; ++b) P.blk_group.push_back(g);
+        blk += nb;
+    }
+    P.reduce_blocks = blk;
+    size_t off = 0;
+    P.off_nodes = off;
+    off = align_up(off + P.nodes.size() * sizeof(GramNodeDev), 256);
+    P.off_items = off;
+    off = align_up(off + P.items.size() * sizeof(GramItemDev), 256);
+    P.off_groups = off;
+    off = align_up(off + P.groups.size() * sizeof(GramGroupDev), 256);
+    P.off_gn = off;
+    off = align_up(off + P.group_nodes.size() * sizeof(int), 256);
+    P.off_bg = off;
+    off = align_up(off + P.blk_group.size() * sizeof(int), 256);
+    P.off_slabs = off;
+    P.slab_bytes = (double)slabs * sizeof(float);
+    P.total = off + slabs * sizeof(float);
+    // slab offsets (in floats, relative to the slab region); absolute pointers are set at upload
+    for (int i = 0; i < n; ++i) {
+        P.nodes[i].gpart = reinterpret_cast<float*>(slab_off[i]);
+        P.nodes[i].npart = reinterpret_cast<float*>(slab_off[i] + (size_t)P.nodes[i].S * P.nodes[i].C * P.nodes[i].C);
+    }
+    P.uploaded = false;
+    return PLEAS_OK;
+}
+
+static std::vector<int64_t> batch_key(const pleas_gram_node* nd, int n, float* const* group_acc, const int* group_C,
+                                      int n_groups, const void* ws) {
+    std::vector<int64_t> k;
+    k.reserve(4 * n + 2 * n_groups + 3);
+    k.push_back(n);
+    k.push_back(n_groups);
+    k.push_back((int64_t)(uintptr_t)ws);
+    k.push_back(g_item_chunks);
+    for (int i = 0; i < n; ++i) {
+        k.push_back(nd[i].B);
+        k.push_back(nd[i].C);
+        k.push_back(nd[i].HW);
+        k.push_back(nd[i].group);
+    }
+    for (int g = 0; g < n_groups; ++g) {
+        k.push_back(group_C[g]);
+        k.push_back((int64_t)(uintptr_t)group_acc[g]);
+    }
+    return k;
+}
+
+}  // namespace pleas
+
+extern "C" void pleas_gram_batch_tune(int item_chunks) {
+    if (item_chunks > 0) g_item_chunks = item_chunks;
+}
+
+extern "C" size_t pleas_gram_batch_ws_bytes(const pleas_gram_node* nodes, int n_nodes, const int* group_C, int n_groups) {
+    if (!nodes || n_nodes <= 0 || !group_C || n_groups <= 0) return 0;
+    BatchPlan tmp;
+    std::vector<float*> acc(n_groups, nullptr);
+    if (build_batch_plan(tmp, nodes, n_nodes, acc.data(), group_C, n_groups) != PLEAS_OK) return 0;
+    return tmp.total;
+}
+
+extern "C" int pleas_gram_batch(const pleas_gram_node* nodes, int n_nodes, float* const* group_acc, const int* group_C,
+                                int n_groups, int epilogue, int accumulate, void* ws, size_t ws_bytes, void* stream_) {
+    if (!nodes || n_nodes <= 0 || !group_acc || !group_C || n_groups <= 0) return bad_arg("gram_batch: empty input");
+    if (epilogue != PLEAS_EPI_INNER && epilogue != PLEAS_EPI_NEG_CDIST) return bad_arg("epilogue");
+    for (int i = 0; i < n_nodes; ++i) {
+        if (!nodes[i].x || !nodes[i].y) return bad_arg("gram_batch: null operand");
+        if (nodes[i].HW % 4 == 0 && ((((uintptr_t)nodes[i].x | (uintptr_t)nodes[i].y) & 15) != 0))
+            return bad_arg("gram_batch: operands must be 16-byte aligned");
+    }
+    for (int g = 0; g < n_groups; ++g)
+        if (!group_acc[g]) return bad_arg("gram_batch: null group matrix");
+    hipStream_t stream = (hipStream_t)stream_;
+    std::lock_guard<std::mutex> lk(g_bplan_mu);
+    BatchPlan& P = g_bplan;
+    std::vector<int64_t> key = batch_key(nodes, n_nodes, group_acc, group_C, n_groups, ws);
+    if (key != P.key) {
+        const int rc = build_batch_plan(P, nodes, n_nodes, group_acc, group_C, n_groups);
+        if (rc != PLEAS_OK) return rc;
+        P.key.swap(key);
+    }
+    if (!ws || ws_bytes < P.total) {
+        std::snprintf(g_last_error, sizeof(g_last_error), "gram_batch workspace too small: need %zu bytes", P.total);
+        P.key.clear();
+        return PLEAS_ENOMEM;
+    }
+    char* base = (char*)ws;
+    if (!P.uploaded) {  // static tables: once per (shape sequence, workspace, group matrices)
+        float* slab0 = reinterpret_cast<float*>(base + P.off_slabs);
+        std::vector<GramNodeDev> abs_nodes = P.nodes;
+        for (auto& d : abs_nodes) {
+            d.gpart = slab0 + reinterpret_cast<size_t>(d.gpart);
+            d.npart = slab0 + reinterpret_cast<size_t>(d.npart);
+        }
+        PLEAS_HIP_CHECK(hipMemcpyAsync(base + P.off_nodes, abs_nodes.data(), abs_nodes.size() * sizeof(GramNodeDev),
+                                       hipMemcpyHostToDevice, stream));
+        PLEAS_HIP_CHECK(hipMemcpyAsync(base + P.off_items, P.items.data(), P.items.size() * sizeof(GramItemDev),
+                                       hipMemcpyHostToDevice, stream));
+        PLEAS_HIP_CHECK(hipMemcpyAsync(base + P.off_groups, P.groups.data(), P.groups.size() * sizeof(GramGroupDev),
+                                       hipMemcpyHostToDevice, stream));
+        PLEAS_HIP_CHECK(hipMemcpyAsync(base + P.off_gn, P.group_nodes.data(), P.group_nodes.size() * sizeof(int),
+                                       hipMemcpyHostToDevice, stream));
+        PLEAS_HIP_CHECK(hipMemcpyAsync(base + P.off_bg, P.blk_group.data(), P.blk_group.size() * sizeof(int),
+                                       hipMemcpyHostToDevice, stream));
+        PLEAS_HIP_CHECK(hipStreamSynchronize(stream));  // host vectors may now change; happens once per plan
+        P.uploaded = true;
+    }
+    GramNodeDev* dnodes = reinterpret_cast<GramNodeDev*>(base + P.off_nodes);
+    for (int b0 = 0; b0 < n_nodes; b0 += kPtrBatch) {
+        GramPtrBatch pb;
+        pb.base = b0;
+        pb.count = std::min(kPtrBatch, n_nodes - b0);
+        for (int t = 0; t < pb.count; ++t) {
+            pb.x[t] = nodes[b0 + t].x;
+            pb.y[t] = nodes[b0 + t].y;
+        }
+        hipLaunchKernelGGL(gram_set_ptrs_kernel, dim3(1), dim3(256), 0, stream, dnodes, pb);
+        PLEAS_LAUNCH_CHECK("gram_set_ptrs_kernel");
+    }
+    {
+        ProfScope prof(kProfGramPartial, P.flops, P.bytes, stream);
+        hipLaunchKernelGGL(gram_batch_kernel, dim3((unsigned)P.items.size()), dim3(kThreads), P.lds, stream, dnodes,
+                           reinterpret_cast<const GramItemDev*>(base + P.off_items));
+    }
+    PLEAS_LAUNCH_CHECK("gram_batch_kernel");
+    {
+        ProfScope prof(kProfGramFinalize, 0.0, P.slab_bytes, stream);
+        hipLaunchKernelGGL(gram_group_reduce_kernel, dim3((unsigned)P.reduce_blocks), dim3(256), 0, stream, dnodes,
+                           reinterpret_cast<const GramGroupDev*>(base + P.off_groups),
+                           reinterpret_cast<const int*>(base + P.off_gn), reinterpret_cast<const int*>(base + P.off_bg),
+                           epilogue, accumulate);
+    }
+    PLEAS_LAUNCH_CHECK("gram_group_reduce_kernel");
     return PLEAS_OK;
 }

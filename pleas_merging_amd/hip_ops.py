@@ -97,6 +97,61 @@ def cross_features_inner_product(x: torch.Tensor, y: torch.Tensor, a: int) -> to
     return gram_accum(x, y, a, out, EPI_INNER, accumulate=False)
 
 
+class GramBatch:
+    """Collects the tracked nodes of one forward pass and contracts them all in ONE grouped launch
+    (``pleas_gram_batch``): ``add`` while the models run, ``flush`` once per batch.
+
+    The operand tensors must stay unmodified until ``flush`` (the twin graph therefore runs ReLU
+    out of place); they are released right after the launch is queued.
+    """
+
+    def __init__(self, group_mats: Sequence[torch.Tensor], epilogue: int):
+        _need_gpu(*group_mats)
+        self.mats = list(group_mats)
+        self.epilogue = epilogue
+        k = len(self.mats)
+        self._acc = (ctypes.c_void_p * k)(*[m.data_ptr() for m in self.mats])
+        self._gc = (ctypes.c_int * k)(*[m.shape[0] for m in self.mats])
+        self._keep: list = []
+        self._meta: list = []
+        self._arr = None
+        self._ws = None
+        self.device = self.mats[0].device
+
+    def add(self, x: torch.Tensor, y: torch.Tensor, axis: int, group: int) -> None:
+        if x.shape != y.shape or not x.is_cuda or x.dtype != torch.float32 or y.dtype != torch.float32:
+            raise PleasHipError("GramBatch.add: fp32 CUDA operands of equal shape expected")
+        x, y = x.contiguous(), y.contiguous()
+        self._keep.append((x, y))
+        self._meta.append(_as_bchw(x, axis) + (group,))
+
+    def flush(self, accumulate: bool = True) -> None:
+        n = len(self._keep)
+        if n == 0:
+            return
+        if self._arr is None or len(self._arr) != n:
+            self._arr = (_lib.GramNode * n)()
+        arr = self._arr
+        for i, ((x, y), (B, C, HW, g)) in enumerate(zip(self._keep, self._meta)):
+            a = arr[i]
+            a.x, a.y, a.B, a.C, a.HW, a.group = x.data_ptr(), y.data_ptr(), B, C, HW, g
+        lib = _lib.lib()
+        if self._ws is None:
+            need = int(lib.pleas_gram_batch_ws_bytes(arr, n, self._gc, len(self.mats)))
+            if need == 0:
+                raise PleasHipError("pleas_gram_batch_ws_bytes rejected the node list: %s" % lib.pleas_last_error().decode())
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)  # dedicated: tables live in it
+        rc = lib.pleas_gram_batch(arr, n, self._acc, self._gc, len(self.mats), self.epilogue, int(bool(accumulate)),
+                                  self._ws.data_ptr(), self._ws.numel(), _stream())
+        if rc == -12:  # node list changed shape: size the workspace again
+            self._ws = None
+            self.flush(accumulate)
+            return
+        check(rc, "pleas_gram_batch")
+        self._keep.clear()
+        self._meta.clear()
+
+
 # ---------------------------------------------------------------------------------------- LAP
 def solve_lsa_batched(costs: Sequence[torch.Tensor], maximize: bool = True) -> List[torch.Tensor]:
     """All assignment problems of a model pair in one launch; returns device int64 vectors."""

@@ -40,10 +40,14 @@ _register_fused()
 
 
 # ------------------------------------------------------------------------------------------ twin graph
-def _build_twin(model1: nn.Module, model2: nn.Module, axes: Iterable[Axis], emit: Callable):
+def _build_twin(model1: nn.Module, model2: nn.Module, axes: Iterable[Axis], emit: Callable,
+                keep_inputs: bool = False):
     """Twin graph of ``model1``/``model2``; ``emit(graph, name, axis, node1, node2)`` adds the call
-    made right after tracked node ``name`` and returns the fx node that holds its value."""
+    made right after tracked node ``name`` and returns the fx node that holds its value.
+    ``keep_inputs`` runs in-place activations out of place (same values, new tensor), so that tracked
+    activations stay intact until the end of the forward pass."""
     traced = torch.fx.symbolic_trace(model1)
+    submods = dict(traced.named_modules())
     want: Dict[str, List[int]] = {}
     for ax in axes:
         if ax.axis not in want.setdefault(ax.key, []):
@@ -63,7 +67,14 @@ def _build_twin(model1: nn.Module, model2: nn.Module, axes: Iterable[Axis], emit
             result = ([env[0][ret], env[1][ret]], cross)
             continue
         made = []
+        inplace_act = (keep_inputs and node.op == "call_module" and isinstance(submods[node.target], nn.ReLU)
+                       and submods[node.target].inplace)
         for side in (0, 1):
+            if inplace_act:
+                new = twin.call_function(torch.relu, (env[side][node.args[0]],))
+                env[side][node] = new
+                made.append(new)
+                continue
             new = twin.node_copy(node, lambda n, side=side: env[side][n])
             if node.op in ("call_module", "get_attr"):
                 new.target = "%d.%s" % (side, node.target)
@@ -108,29 +119,40 @@ class GroupArena:
 
 
 class _FusedSink:
-    """Callable placed in the twin graph: accumulates one node's cross features into its group."""
+    """Callables placed in the twin graph.  ``grouped=True`` (default): a sink only hands the node's
+    two activations to a :class:`GramBatch`; ONE grouped launch per batch contracts all nodes.
+    ``grouped=False``: every sink launches ``pleas_gram_accum`` into its group matrix right away."""
 
-    def __init__(self, arena: GroupArena, node_group: Dict[Axis, Axis], epilogue: int):
+    def __init__(self, arena: GroupArena, node_group: Dict[Axis, Axis], epilogue: int, grouped: bool):
         from .. import hip_ops
 
         self._accum = hip_ops.gram_accum
         self.arena, self.node_group, self.epilogue = arena, node_group, epilogue
+        self.group_index = {key: i for i, key in enumerate(arena.keys)}
+        self.batch = hip_ops.GramBatch([arena.view[k] for k in arena.keys], epilogue) if grouped else None
 
     def bind(self, node_name: str):
-        def sink(x, y, a, _name=node_name):
-            self._accum(x, y, a, self.arena.view[self.node_group[Axis(_name, a)]], self.epilogue, True)
-            return None
+        if self.batch is not None:
+            def sink(x, y, a, _name=node_name):
+                self.batch.add(x, y, a, self.group_index[self.node_group[Axis(_name, a)]])
+                return None
+        else:
+            def sink(x, y, a, _name=node_name):
+                self._accum(x, y, a, self.arena.view[self.node_group[Axis(_name, a)]], self.epilogue, True)
+                return None
 
         sink.__name__ = sink.__qualname__ = "gram_sink_%s" % node_name
         return sink
 
 
-def build_fused_module(spec: PermutationSpec, model1: nn.Module, model2: nn.Module, arena: GroupArena, epilogue: int):
-    """Twin graph whose sinks add straight into the group arena (the HIP fast path)."""
+def build_fused_module(spec: PermutationSpec, model1: nn.Module, model2: nn.Module, arena: GroupArena, epilogue: int,
+                       grouped: bool = True):
+    """Twin graph whose sinks feed the group arena (the HIP fast path).  Returns (module, sinks)."""
     node_group = {nax: key for key, group in spec.items() for nax in group.node}
-    sinks = _FusedSink(arena, node_group, epilogue)
-    return _build_twin(model1, model2, list(node_group.keys()),
-                       lambda g, name, a, n1, n2: g.call_function(sinks.bind(name), (n1, n2, a)))
+    sinks = _FusedSink(arena, node_group, epilogue, grouped)
+    gm = _build_twin(model1, model2, list(node_group.keys()),
+                     lambda g, name, a, n1, n2: g.call_function(sinks.bind(name), (n1, n2, a)), keep_inputs=grouped)
+    return gm, sinks
 
 
 # ------------------------------------------------------------------------------------------ cost accumulation
@@ -201,7 +223,8 @@ def compute_matching_costs(spec: PermutationSpec, gm_cross: nn.Module, dataloade
 
 
 def accumulate_costs_fused(spec: PermutationSpec, model1: nn.Module, model2: nn.Module, dataloader, num_batches: int,
-                           epilogue: int, accumulate=True, shard: bool = True) -> Dict[Axis, torch.Tensor]:
+                           epilogue: int, accumulate=True, shard: bool = True,
+                           grouped: bool = True) -> Dict[Axis, torch.Tensor]:
     """HIP fast path: every tracked node adds into its group matrix while the forwards run.
 
     Data parallel: with ``torch.distributed`` initialised (one process per GPU, RCCL), rank r
@@ -213,13 +236,15 @@ def accumulate_costs_fused(spec: PermutationSpec, model1: nn.Module, model2: nn.
     if device.type != "cuda":
         raise RuntimeError("activation_matching: models must be on the GPU for the HIP path (got %s)" % device)
     arena = GroupArena(spec, device)
-    gm = build_fused_module(spec, model1, model2, arena, epilogue)
+    gm, sinks = build_fused_module(spec, model1, model2, arena, epilogue, grouped)
     rank, world = _dist_info() if (shard and accumulate is True) else (0, 1)
     with torch.inference_mode():
         for x, _ in shard_batches(dataloader, num_batches, rank, world):
             if accumulate is not True:
                 arena.zero_()
             gm(x.to(device, non_blocking=True))
+            if sinks.batch is not None:
+                sinks.batch.flush(accumulate=True)
     allreduce_sum_(arena.flat, world)
     return dict(arena.view)
 
@@ -236,17 +261,19 @@ def solve_all(costs: Dict[Axis, torch.Tensor], lsa_solver: Callable) -> Permutat
 
 def activation_matching(spec: PermutationSpec, model1: nn.Module, model2: nn.Module, dataloader, num_batches=1000,
                         cross_features=cross_features_cdist, lsa_solver=hip_solve_lsa, output_costs=False,
-                        accumulate=True):
+                        accumulate=True, grouped=True):
     """Permutation of ``model2``'s units that best matches ``model1``'s activations.
 
-    Reference: :139-177 (same positional arguments; ``accumulate`` is the only addition,
-    ``"reference"`` reproduces the shipped last-batch-only costs).  Returns ``perm``
+    Reference: :139-177 (same positional arguments; additions: ``accumulate`` -- ``"reference"``
+    reproduces the shipped last-batch-only costs -- and ``grouped`` -- one contraction launch per
+    batch (default) instead of one per tracked node).  Returns ``perm``
     (CPU int64 per group) or ``(perm, costs)`` with fp32 costs on the compute device.
     Does not change the models' train/eval mode and does not move them.
     """
     epilogue = _FUSED_EPILOGUE.get(cross_features)
     if epilogue is not None:
-        costs = accumulate_costs_fused(spec, model1, model2, dataloader, num_batches, epilogue, accumulate)
+        costs = accumulate_costs_fused(spec, model1, model2, dataloader, num_batches, epilogue, accumulate,
+                                       grouped=grouped)
     else:
         axes = [ax for group in spec.values() for ax in group.node]
         gm = build_cross_module(model1, model2, axes, cross_features)

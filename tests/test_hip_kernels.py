@@ -212,3 +212,40 @@ def test_sqerr(ops):
     assert torch.allclose(diff.cpu(), 2 * (a - b) / a.numel(), rtol=1e-6, atol=1e-12)
     ops.sqerr(a.cuda(), b.cuda(), 1.0 / a.numel(), out, accumulate=True)
     assert abs(float(out) - 2 * float(((a - b) ** 2).mean())) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------ grouped gram launch
+def test_gram_batch_matches_per_node_sums(ops):
+    """One grouped launch over nodes of mixed shapes/groups == sum of single-node launches."""
+    g = torch.Generator().manual_seed(11)
+    shapes = [((4, 8, 6, 6), 0), ((4, 8, 3, 3), 0), ((4, 130, 9, 9), 1), ((4, 130, 5, 5), 1), ((4, 64, 28, 28), 2),
+              ((4, 256, 14, 14), 3), ((4, 256, 14, 14), 3), ((4, 256), 3), ((2, 64, 112, 112), 2)]
+    sizes = {0: 8, 1: 130, 2: 64, 3: 256}
+    for epi in (ops.EPI_NEG_CDIST, ops.EPI_INNER):
+        mats = [torch.full((sizes[k], sizes[k]), 0.25, device="cuda") for k in range(4)]
+        want = [m.clone() for m in mats]
+        batch = ops.GramBatch(mats, epi)
+        for rep in range(2):  # second round reuses the cached plan with new operand pointers
+            for shp, grp in shapes:
+                x = torch.randn(shp, generator=g).cuda()
+                y = (0.5 * x.cpu() + torch.randn(shp, generator=g)).cuda()
+                batch.add(x, y, 1, grp)
+                ops.gram_accum(x, y, 1, want[grp], epi, accumulate=True)
+            batch.flush(accumulate=True)
+        for got, ref in zip(mats, want):
+            assert _rel(got, ref) < 1e-5, _rel(got, ref)  # different K splits: only rounding may differ
+
+
+def test_gram_batch_deterministic_and_overwrite(ops):
+    x, y = torch.randn(8, 256, 14, 14).cuda(), torch.randn(8, 256, 14, 14).cuda()
+    outs = []
+    for _ in range(2):
+        m = torch.full((256, 256), 7.0, device="cuda")
+        b = ops.GramBatch([m], ops.EPI_NEG_CDIST)
+        b.add(x, y, 1, 0)
+        b.add(y, x, 1, 0)
+        b.flush(accumulate=False)
+        outs.append(m.clone())
+    assert torch.equal(outs[0], outs[1])
+    ref = ops.cross_features_cdist(x, y, 1) + ops.cross_features_cdist(y, x, 1)
+    assert torch.allclose(outs[0], ref, rtol=1e-5, atol=1e-4)

@@ -171,3 +171,14 @@ def test_spec_function_invariance_on_gpu(tiny_basic):
     m = copy.deepcopy(tiny_basic.m1).cuda()
     spec = get_permutation_spec(m, ((2, 3, 32, 32),))
     assert check_permutation_spec(m, spec, torch.randn(2, 3, 32, 32).cuda())
+
+
+def test_grouped_equals_per_node_launches(tiny_bottleneck):
+    from pleas.methods.activation_matching import activation_matching
+
+    t = tiny_bottleneck
+    m1, m2 = _cuda_pair(t)
+    pa, ca = activation_matching(t.spec, m1, m2, t.batches(), 3, output_costs=True, grouped=True)
+    pb, cb = activation_matching(t.spec, m1, m2, t.batches(), 3, output_costs=True, grouped=False)
+    for k in t.spec:
+        assert _rel(ca[k], cb[k]) < 1e-6 and (pa[k] == pb[k]).all()
