@@ -67,8 +67,9 @@ int pleas_gram_accum(const float* x, const float* y, int B, int C, int64_t HW, i
  * Work is cut into (node, tile, K-range) items of near-equal length, sorted longest first; each
  * node's partial products go to its own slab in `ws`, and the reduce grid sums slabs and nodes in a
  * FIXED order (deterministic, no atomics).  ws >= pleas_gram_batch_ws_bytes(...).
- * The work list is cached per (shape sequence, ws, group matrices); only operand pointers change
- * from batch to batch.
+ * The work list is cached per (shape sequence, ws, group matrices) and its device tables live at the
+ * start of `ws`: pass ws_fresh = 1 on the first call with a workspace (or whenever its content may
+ * have been overwritten since the previous call), 0 otherwise; then only operand pointers are sent.
  */
 typedef struct pleas_gram_node {
     const float* x;
@@ -80,7 +81,7 @@ typedef struct pleas_gram_node {
 } pleas_gram_node;
 size_t pleas_gram_batch_ws_bytes(const pleas_gram_node* nodes, int n_nodes, const int* group_C, int n_groups);
 int pleas_gram_batch(const pleas_gram_node* nodes, int n_nodes, float* const* group_acc, const int* group_C,
-                     int n_groups, int epilogue, int accumulate, void* ws, size_t ws_bytes, void* stream);
+                     int n_groups, int epilogue, int accumulate, void* ws, size_t ws_bytes, int ws_fresh, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Batched linear assignment (square, dense), one workgroup per problem.
@@ -143,6 +144,39 @@ int pleas_sqerr(const float* a, const float* b, int64_t n, float scale, int accu
                 float* diff, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * PLeaS layer fitting: fused target/residual/loss pass and grouped weight-gradient launch.
+ *
+ * Replaces, for merging='perm_gradmask': the output half of get_model_orig_activations
+ *   (pleas_merging.py:116-123, :147), the per-layer MSE (:282) and the whole autograd backward
+ *   of the merged layers (:287).
+ *
+ * pleas_target_residual: out = merged layer output [N][C][HW]; o1, o2 = source layer outputs
+ *   [N][Csrc][HW]; row1/row2/n_merged = block maps as in pleas_merge_blocks.
+ *   resid = dscale * (out - target)   (resid may alias out);   partials[0..*n_partials) receive this
+ *   call's per-workgroup sums of (out - target)^2 (*n_partials <= pleas_target_residual_max_partials()).
+ * pleas_loss_final: loss[l] = scale[l] * sum(partials[l*stride .. +n_partials[l]))  (all DEVICE arrays).
+ * pleas_wgrad_batch: for every layer  grad[co][ci][kh][kw] = sum_{n,oh,ow} resid[n][co][oh][ow] *
+ *   ip[n][ci][oh*stride+kh-pad][ow*stride+kw-pad]  (a Linear layer is Hin=Win=KH=KW=1).
+ *   layers: HOST array; resid/ip/grad DEVICE pointers (16-byte aligned); ws >= pleas_wgrad_batch_ws_bytes.
+ *   Deterministic; the work list is cached per (geometry sequence, ws); ws_fresh as in pleas_gram_batch.
+ */
+typedef struct pleas_wgrad_layer {
+    const float* resid; /* [N][Cout][Hout*Wout] */
+    const float* ip;    /* [N][Cin][Hin][Win]   */
+    float* grad;        /* [Cout][Cin][KH][KW]  */
+    int N, Cout, Cin, Hin, Win, KH, KW, stride, pad;
+} pleas_wgrad_layer;
+int pleas_target_residual(const float* out, const float* o1, const float* o2, const int32_t* row1, const int32_t* row2,
+                          int n_merged, int N, int C, int Csrc, int64_t HW, float dscale, float* resid, float* partials,
+                          int* n_partials, void* stream);
+int pleas_target_residual_max_partials(void);
+int pleas_loss_final(const float* partials, const int* n_partials, const float* scale, int stride, int n_layers,
+                     float* loss, void* stream);
+size_t pleas_wgrad_batch_ws_bytes(const pleas_wgrad_layer* layers, int n_layers);
+int pleas_wgrad_batch(const pleas_wgrad_layer* layers, int n_layers, void* ws, size_t ws_bytes, int ws_fresh,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Opt-in live timing of the library's kernels with HIP events recorded on the launch stream
  * (used by bench.py for the roofline figure; off by default, no cost when off).
  * kernel ids: 0 gram_partial, 1 gram_finalize, 2 lsap, 3 merge_blocks, 4 masked_adam, 5 sqerr,
@@ -157,6 +191,7 @@ int pleas_prof_collect(int kernel, int64_t* launches, double* total_ms, double* 
 /* Tuning hook for experiments: split-K target workgroup count and minimum K chunks per split. */
 void pleas_gram_tune(int target_blocks, int min_chunks_per_split);
 void pleas_gram_batch_tune(int item_chunks);
+void pleas_wgrad_tune(int item_chunks);
 
 #ifdef __cplusplus
 }

@@ -36,10 +36,23 @@ SIGNATURES = {
                                    POINTER(ctypes.c_double)]),
     "pleas_gram_tune": (None, [c_int, c_int]),
     "pleas_gram_batch_tune": (None, [c_int]),
+    "pleas_wgrad_tune": (None, [c_int]),
+    "pleas_target_residual": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                      c_int64, c_float, c_void_p, c_void_p, POINTER(c_int), c_void_p]),
+    "pleas_target_residual_max_partials": (c_int, []),
+    "pleas_loss_final": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "pleas_wgrad_batch_ws_bytes": (c_size_t, [c_void_p, c_int]),
+    "pleas_wgrad_batch": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "pleas_gram_batch_ws_bytes": (c_size_t, [c_void_p, c_int, POINTER(c_int), c_int]),
     "pleas_gram_batch": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_int), c_int, c_int, c_int, c_void_p,
-                                 c_size_t, c_void_p]),
+                                 c_size_t, c_int, c_void_p]),
 }
+
+
+class WgradLayer(ctypes.Structure):
+    """struct pleas_wgrad_layer"""
+    _fields_ = [("resid", c_void_p), ("ip", c_void_p), ("grad", c_void_p), ("N", c_int), ("Cout", c_int), ("Cin", c_int),
+                ("Hin", c_int), ("Win", c_int), ("KH", c_int), ("KW", c_int), ("stride", c_int), ("pad", c_int)]
 
 
 class GramNode(ctypes.Structure):

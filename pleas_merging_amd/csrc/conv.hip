@@ -1,0 +1,541 @@
+// PLeaS layer fitting on gfx950: weight gradients of ALL merged layers of one update in one
+// grouped fp32-MFMA launch, plus the fused target / residual / loss pass.
+//
+// Replaces, per layer and per update, the autograd backward of
+//     loss_l = mean((layer(ip) - op)^2)          pleas/methods/pleas_merging.py:281-287
+// i.e.  gW[co][ci][kh][kw] = sum_{n,oh,ow} resid[n][co][oh][ow] * ip[n][ci][oh*s+kh-p][ow*s+kw-p]
+// with  resid = 2 (out - op) / numel,  op = block-merged source outputs (:116-147).
+//
+// Formulation: for a FIXED kernel position r = (kh, kw) the gradient slice gW[:, :, r] is an NT
+// contraction over the flattened pixel index P = (n, oh, ow) between
+//     X = resid viewed [N][Cout][HWo]        (rows = co, P contiguous)  and
+//     Y_r = the r-shifted, strided view of ip (rows = ci, P contiguous for stride 1),
+// exactly the structure of the matching contraction (gram.hip): both operands are read in place
+// from NCHW, no im2col buffer, no NHWC transposes.  A work item is (layer, co-tile, ci-tile, r,
+// P-range); items of all layers are sorted longest-first into one grid.  Layers whose P range fits
+// one item write their gradient directly; longer ones write slabs that a second grid sums in a
+// fixed order (deterministic, no atomics).
+//
+// Roofline: 2*Cout*Cin*KH*KW*N*HWo flop per layer and update (ResNet-101, batch 16: 2.5e11 flop per
+// update over all layers), fp32 MFMA bound (157.3 TFLOP/s).
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
+#include "common.hpp"
+
+namespace pleas {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int cBK = 32;
+constexpr int cLds = 36;
+constexpr int cThreads = 256;
+
+struct WgradLayerDev {
+    const float* resid;  // [N][Cout][HWo]
+    const float* ip;     // [N][Cin][Hin][Win]
+    float* out;          // gradient, standard [Cout][Cin][KH][KW]
+    float* slab;         // [S][Cout][R*Cin] when S > 1
+    int Cout, Cin, Hin, Win, Hout, Wout, KH, KW, stride, pad;
+    uint32_t HWo, Ktot;  // Ktot = N * HWo
+    int S;
+    int variant;         // bit0: TM==64, bit1: TN==64, bit2: X scalar loads, bit3: Y shifted (scalar) loader
+};
+struct WgradItemDev {
+    int layer, tm, tn, r, split, c_begin, c_end, pad;
+};
+
+template <int TM, int TN, int VECX, bool YSHIFT>
+__device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradItemDev& it, float* smem) {
+    constexpr int MTM = TM / 64, MTN = TN / 64;
+    constexpr int VECY = YSHIFT ? 1 : VECX;
+    constexpr int LPR_X = cBK / VECX, RPP_X = cThreads / LPR_X, PASS_X = TM / RPP_X;
+    constexpr int LPR_Y = cBK / VECY, RPP_Y = cThreads / LPR_Y, PASS_Y = TN / RPP_Y;
+    float* As = smem;                    // [2][TM][cLds]
+    float* Bs = smem + 2 * TM * cLds;    // [2][TN][cLds]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i0 = it.tm * TM, j0 = it.tn * TN;
+    const int kh = it.r / L.KW, kw = it.r - kh * L.KW;
+    const int dh = kh - L.pad, dw = kw - L.pad;
+    const uint32_t HWi = (uint32_t)L.Hin * L.Win;
+
+    const int xrow = tid / LPR_X, xcol = (tid % LPR_X) * VECX;
+    const int yrow = tid / LPR_Y, ycol = (tid % LPR_Y) * VECY;
+    float rx[PASS_X][VECX], ry[PASS_Y][VECY];
+    unsigned okx = 0, oky = 0;
+    uint32_t offx[PASS_X], offy[PASS_Y];  // < 2^32: one sample's C*HW slab
+#pragma unroll
+    for (int q = 0; q < PASS_X; ++q) {
+        const int gi = i0 + xrow + q * RPP_X;
+        if (gi < L.Cout) okx |= 1u << q;
+        offx[q] = (uint32_t)min(gi, L.Cout - 1) * L.HWo;
+    }
+#pragma unroll
+    for (int q = 0; q < PASS_Y; ++q) {
+        const int gj = j0 + yrow + q * RPP_Y;
+        if (gj < L.Cin) oky |= 1u << q;
+        offy[q] = (uint32_t)min(gj, L.Cin - 1) * HWi;
+    }
+    f32x16 acc[MTM][MTN];
+#pragma unroll
+    for (int a = 0; a < MTM; ++a)
+#pragma unroll
+        for (int b = 0; b < MTN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    bool kinx = false, kiny = false;
+    auto load_chunk = [&](int c) {
+        {   // X: residual rows, direct
+            const uint32_t P = (uint32_t)c * cBK + xcol;
+            kinx = P < L.Ktot;
+            const uint32_t n = kinx ? P / L.HWo : 0u;
+            const uint32_t p = kinx ? P - n * L.HWo : 0u;
+            const size_t base = (size_t)n * L.Cout * L.HWo + p;
+#pragma unroll
+            for (int q = 0; q < PASS_X; ++q) {
+                if constexpr (VECX == 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(L.resid + base + offx[q]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rx[q][e] = v[e];
+                } else {
+                    rx[q][0] = L.resid[base + offx[q]];
+                }
+            }
+        }
+        {   // Y: input rows, shifted by the kernel position (or direct for 1x1 stride 1)
+            const uint32_t P = (uint32_t)c * cBK + ycol;
+            bool in = P < L.Ktot;
+            const uint32_t n = in ? P / L.HWo : 0u;
+            const uint32_t p = in ? P - n * L.HWo : 0u;
+            size_t base;
+            if constexpr (YSHIFT) {
+                const int oh = (int)(p / (uint32_t)L.Wout), ow = (int)(p - (uint32_t)oh * L.Wout);
+                const int ih = oh * L.stride + dh, iw = ow * L.stride + dw;
+                in = in && ih >= 0 && ih < L.Hin && iw >= 0 && iw < L.Win;
+                base = (size_t)n * L.Cin * HWi + (in ? (size_t)ih * L.Win + iw : 0);
+            } else {
+                base = (size_t)n * L.Cin * HWi + p;
+            }
+            kiny = in;
+#pragma unroll
+            for (int q = 0; q < PASS_Y; ++q) {
+                if constexpr (VECY == 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(L.ip + base + offy[q]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ry[q][e] = v[e];
+                } else {
+                    ry[q][0] = L.ip[base + offy[q]];
+                }
+            }
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        float* a = As + buf * TM * cLds;
+        float* b = Bs + buf * TN * cLds;
+#pragma unroll
+        for (int q = 0; q < PASS_X; ++q) {
+            const bool ok = kinx && ((okx >> q) & 1u);
+            const int row = xrow + q * RPP_X;
+            if constexpr (VECX == 4) {
+                f32x4 v = {ok ? rx[q][0] : 0.f, ok ? rx[q][1] : 0.f, ok ? rx[q][2] : 0.f, ok ? rx[q][3] : 0.f};
+                *reinterpret_cast<f32x4*>(a + row * cLds + xcol) = v;
+            } else {
+                a[row * cLds + xcol] = ok ? rx[q][0] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PASS_Y; ++q) {
+            const bool ok = kiny && ((oky >> q) & 1u);
+            const int row = yrow + q * RPP_Y;
+            if constexpr (VECY == 4) {
+                f32x4 v = {ok ? ry[q][0] : 0.f, ok ? ry[q][1] : 0.f, ok ? ry[q][2] : 0.f, ok ? ry[q][3] : 0.f};
+                *reinterpret_cast<f32x4*>(b + row * cLds + ycol) = v;
+            } else {
+                b[row * cLds + ycol] = ok ? ry[q][0] : 0.f;
+            }
+        }
+    };
+    auto compute = [&](int buf) {
+        const float* a = As + buf * TM * cLds + (wm * (TM / 2) + (lane & 31)) * cLds + 4 * (lane >> 5);
+        const float* b = Bs + buf * TN * cLds + (wn * (TN / 2) + (lane & 31)) * cLds + 4 * (lane >> 5);
+#pragma unroll
+        for (int kk = 0; kk < cBK / 8; ++kk) {
+            f32x4 fa[MTM], fb[MTN];
+#pragma unroll
+            for (int s = 0; s < MTM; ++s) fa[s] = *reinterpret_cast<const f32x4*>(a + s * 32 * cLds + kk * 8);
+#pragma unroll
+            for (int s = 0; s < MTN; ++s) fb[s] = *reinterpret_cast<const f32x4*>(b + s * 32 * cLds + kk * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int sm = 0; sm < MTM; ++sm)
+#pragma unroll
+                    for (int sn = 0; sn < MTN; ++sn)
+                        acc[sm][sn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sm][e], fb[sn][e], acc[sm][sn], 0, 0, 0);
+        }
+    };
+
+    if (it.c_begin < it.c_end) {
+        load_chunk(it.c_begin);
+        store_chunk(0);
+    }
+    __syncthreads();
+    for (int c = it.c_begin; c < it.c_end; ++c) {
+        const int buf = (c - it.c_begin) & 1;
+        const bool more = c + 1 < it.c_end;
+        if (more) load_chunk(c + 1);
+        compute(buf);
+        if (more) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: direct (S == 1) into the standard [Cout][Cin][R] gradient, else into this split's slab
+    const int R = L.KH * L.KW;
+#pragma unroll
+    for (int sm = 0; sm < MTM; ++sm)
+#pragma unroll
+        for (int sn = 0; sn < MTN; ++sn) {
+            const int ci = j0 + wn * (TN / 2) + sn * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = i0 + wm * (TM / 2) + sm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (co < L.Cout && ci < L.Cin) {
+                    if (L.S == 1)
+                        L.out[((size_t)co * L.Cin + ci) * R + it.r] = acc[sm][sn][r];
+                    else
+                        L.slab[((size_t)it.split * L.Cout + co) * ((size_t)R * L.Cin) + (size_t)it.r * L.Cin + ci] =
+                            acc[sm][sn][r];
+                }
+            }
+        }
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void wgrad_dispatch(const WgradLayerDev& L, const WgradItemDev& it, float* smem) {
+    const bool xs = L.variant & 4, ys = L.variant & 8;
+    if (!xs && !ys) wgrad_tile<TM, TN, 4, false>(L, it, smem);
+    else if (!xs && ys) wgrad_tile<TM, TN, 4, true>(L, it, smem);
+    else if (xs && !ys) wgrad_tile<TM, TN, 1, false>(L, it, smem);
+    else wgrad_tile<TM, TN, 1, true>(L, it, smem);
+}
+
+__global__ __launch_bounds__(cThreads) void wgrad_batch_kernel(const WgradLayerDev* __restrict__ layers,
+                                                               const WgradItemDev* __restrict__ items) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const WgradItemDev it = items[blockIdx.x];
+    const WgradLayerDev L = layers[it.layer];
+    switch (L.variant & 3) {  // block-uniform
+        case 0: wgrad_dispatch<128, 128>(L, it, smem); break;
+        case 1: wgrad_dispatch<64, 128>(L, it, smem); break;
+        case 2: wgrad_dispatch<128, 64>(L, it, smem); break;
+        default: wgrad_dispatch<64, 64>(L, it, smem); break;
+    }
+}
+
+// per-update operand pointers -> device layer table (carried in kernel arguments)
+constexpr int cPtrBatch = 150;
+struct WgradPtrBatch {
+    int base, count;
+    const float* resid[cPtrBatch];
+    const float* ip[cPtrBatch];
+    float* out[cPtrBatch];
+};
+__global__ void wgrad_set_ptrs_kernel(WgradLayerDev* __restrict__ layers, const WgradPtrBatch b) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < b.count) {
+        layers[b.base + t].resid = b.resid[t];
+        layers[b.base + t].ip = b.ip[t];
+        layers[b.base + t].out = b.out[t];
+    }
+}
+
+// Slab reduce for layers with S > 1: out[(co*Cin+ci)*R + r] = sum_s slab[s][co][r*Cin+ci]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradLayerDev* __restrict__ layers,
+                                                           const int* __restrict__ blk_layer,
+                                                           const int* __restrict__ blk_begin) {
+    const int li = blk_layer[blockIdx.x];
+    const WgradLayerDev L = layers[li];
+    const int R = L.KH * L.KW;
+    const size_t per = (size_t)L.Cout * L.Cin * R;
+    const size_t idx = (size_t)(blockIdx.x - blk_begin[blockIdx.x]) * blockDim.x + threadIdx.x;  // internal (co, r, ci)
+    if (idx >= per) return;
+    const size_t rowlen = (size_t)R * L.Cin;
+    const int co = (int)(idx / rowlen);
+    const int rem = (int)(idx - (size_t)co * rowlen);
+    const int r = rem / L.Cin, ci = rem - r * L.Cin;
+    float s = 0.f;
+    for (int k = 0; k < L.S; ++k) s += L.slab[(size_t)k * per + idx];
+    L.out[((size_t)co * L.Cin + ci) * R + r] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused regression target + residual + loss partials for one layer:
+//   t      = coef(c) * ( [row1[c] >= 0] o1[n][row1[c]][p] + [row2[c] >= 0] o2[n][row2[c]][p] )
+//   resid  = dscale * (out - t)            (written over `out` when resid == out)
+//   part[blockIdx] = sum over this block of (out - t)^2
+// Replaces pleas_merging.py:116-123 + :147 (index_select x4 + cat for the outputs), :282 and the first
+// node of its backward.
+constexpr int kTrBlocks = 512;
+__global__ __launch_bounds__(256) void target_residual_kernel(const float* __restrict__ out, const float* __restrict__ o1,
+                                                              const float* __restrict__ o2, const int32_t* __restrict__ row1,
+                                                              const int32_t* __restrict__ row2, int n_merged, int N, int C,
+                                                              int Csrc, int64_t HW, float dscale, float* __restrict__ resid,
+                                                              float* __restrict__ part) {
+    const int64_t total = (int64_t)N * C * HW;
+    float s = 0.f;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = idx % HW;
+        const int64_t t = idx / HW;
+        const int c = (int)(t % C);
+        const int64_t n = t / C;
+        const int r1 = row1[c], r2 = row2[c];
+        float a = 0.f, b = 0.f;
+        if (r1 >= 0) a = o1[(n * Csrc + r1) * HW + p];
+        if (r2 >= 0) b = o2[(n * Csrc + r2) * HW + p];
+        const float tgt = (a + b) * (c < n_merged ? 0.5f : 1.0f);
+        const float d = out[idx] - tgt;
+        s = fmaf(d, d, s);
+        resid[idx] = dscale * d;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    __shared__ float wsum[4];
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+// loss[l] = scale[l] * sum(part[l][0..nparts[l]))  for all layers of an update in one launch
+__global__ __launch_bounds__(64) void loss_final_kernel(const float* __restrict__ part, const int* __restrict__ nparts,
+                                                        const float* __restrict__ scale, int stride,
+                                                        float* __restrict__ loss) {
+    const int l = blockIdx.x;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts[l]; i += 64) s += (double)part[(size_t)l * stride + i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if (threadIdx.x == 0) loss[l] = (float)(s * (double)scale[l]);
+}
+
+// ------------------------------------------------------------------------------------------------ host plan
+static int g_wgrad_item_chunks = 112;
+
+struct WgradPlan {
+    std::vector<int64_t> key;
+    std::vector<WgradLayerDev> layers;
+    std::vector<WgradItemDev> items;
+    std::vector<int> blk_layer, blk_begin;
+    size_t off_layers = 0, off_items = 0, off_bl = 0, off_bb = 0, off_slabs = 0, total = 0, lds = 0;
+    double flops = 0, bytes = 0;
+    bool uploaded = false;
+};
+static WgradPlan g_wplan;
+static std::mutex g_wplan_mu;
+
+static size_t walign(size_t v) { return (v + 255) / 256 * 256; }
+
+static int build_wgrad_plan(WgradPlan& P, const pleas_wgrad_layer* ly, int n) {
+    P.layers.assign(n, WgradLayerDev());
+    P.items.clear();
+    P.blk_layer.clear();
+    P.blk_begin.clear();
+    P.flops = P.bytes = 0;
+    P.lds = 0;
+    std::vector<size_t> slab_off(n, 0);
+    size_t slabs = 0;
+    struct Work { double w; WgradItemDev it; };
+    std::vector<Work> work;
+    int blk = 0;
+    for (int i = 0; i < n; ++i) {
+        const pleas_wgrad_layer& l = ly[i];
+        if (l.N <= 0 || l.Cout <= 0 || l.Cin <= 0 || l.Hin <= 0 || l.Win <= 0 || l.KH <= 0 || l.KW <= 0 || l.stride <= 0 ||
+            l.pad < 0)
+            return bad_arg("wgrad: layer geometry");
+        const int Hout = (l.Hin + 2 * l.pad - l.KH) / l.stride + 1, Wout = (l.Win + 2 * l.pad - l.KW) / l.stride + 1;
+        if (Hout <= 0 || Wout <= 0) return bad_arg("wgrad: empty output");
+        const int64_t HWo = (int64_t)Hout * Wout, HWi = (int64_t)l.Hin * l.Win, K = (int64_t)l.N * HWo;
+        if (K >= (1ll << 31)) return bad_arg("wgrad: N*Hout*Wout must be < 2^31");
+        WgradLayerDev& d = P.layers[i];
+        d.Cout = l.Cout; d.Cin = l.Cin; d.Hin = l.Hin; d.Win = l.Win; d.Hout = Hout; d.Wout = Wout;
+        d.KH = l.KH; d.KW = l.KW; d.stride = l.stride; d.pad = l.pad;
+        d.HWo = (uint32_t)HWo;
+        d.Ktot = (uint32_t)K;
+        const int R = l.KH * l.KW;
+        const int TM = l.Cout > 64 ? 128 : 64, TN = l.Cin > 64 ? 128 : 64;
+        const bool ydirect = R == 1 && l.stride == 1 && l.pad == 0;
+        const bool xvec = HWo % 4 == 0;
+        // direct Y shares X's vector width, so it also needs HWi == HWo (true for 1x1 stride 1)
+        d.variant = (TM == 64 ? 1 : 0) | (TN == 64 ? 2 : 0) | (xvec ? 0 : 4) | (ydirect ? 0 : 8);
+        (void)HWi;
+        const int nchunks = (int)ceil_div(K, cBK);
+        const int S = (int)ceil_div(nchunks, g_wgrad_item_chunks);
+        const int cps = (int)ceil_div(nchunks, S);
+        d.S = S;
+        if (S > 1) {
+            slab_off[i] = slabs;
+            slabs += (size_t)S * l.Cout * l.Cin * R;
+            const int nb = (int)ceil_div((int64_t)l.Cout * l.Cin * R, 256);
+            for (int b = 0; b < nb; ++b) {
+                P.blk_layer.push_back(i);
+                P.blk_begin.push_back(blk);
+            }
+            blk += nb;
+        }
+        P.lds = std::max(P.lds, (size_t)2 * (TM + TN) * cLds * sizeof(float));
+        P.flops += 2.0 * l.Cout * (double)l.Cin * R * (double)K;
+        P.bytes += ((double)l.Cout * K + (double)l.Cin * l.N * HWi) * sizeof(float);
+        const int tms = (int)ceil_div(l.Cout, TM), tns = (int)ceil_div(l.Cin, TN);
+        for (int s = 0; s < S; ++s)
+            for (int r = 0; r < R; ++r)
+                for (int tm = 0; tm < tms; ++tm)
+                    for (int tn = 0; tn < tns; ++tn) {
+                        Work w;
+                        w.it = WgradItemDev{i, tm, tn, r, s, s * cps, std::min((s + 1) * cps, nchunks), 0};
+                        w.w = (double)(w.it.c_end - w.it.c_begin) * TM * TN;
+                        work.push_back(w);
+                    }
+    }
+    std::stable_sort(work.begin(), work.end(), [](const Work& a, const Work& b) { return a.w > b.w; });
+    P.items.reserve(work.size());
+    for (auto& w : work) P.items.push_back(w.it);
+    size_t off = 0;
+    P.off_layers = off;
+    off = walign(off + P.layers.size() * sizeof(WgradLayerDev));
+    P.off_items = off;
+    off = walign(off + P.items.size() * sizeof(WgradItemDev));
+    P.off_bl = off;
+    off = walign(off + P.blk_layer.size() * sizeof(int));
+    P.off_bb = off;
+    off = walign(off + P.blk_begin.size() * sizeof(int));
+    P.off_slabs = off;
+    P.total = off + slabs * sizeof(float);
+    for (int i = 0; i < n; ++i) P.layers[i].slab = reinterpret_cast<float*>(slab_off[i]);
+    P.uploaded = false;
+    return PLEAS_OK;
+}
+
+static std::vector<int64_t> wgrad_key(const pleas_wgrad_layer* ly, int n, const void* ws) {
+    std::vector<int64_t> k;
+    k.push_back(n);
+    k.push_back((int64_t)(uintptr_t)ws);
+    k.push_back(g_wgrad_item_chunks);
+    for (int i = 0; i < n; ++i) {
+        const pleas_wgrad_layer& l = ly[i];
+        for (int v : {l.N, l.Cout, l.Cin, l.Hin, l.Win, l.KH, l.KW, l.stride, l.pad}) k.push_back(v);
+    }
+    return k;
+}
+
+}  // namespace pleas
+
+using namespace pleas;
+
+extern "C" void pleas_wgrad_tune(int item_chunks) {
+    if (item_chunks > 0) g_wgrad_item_chunks = item_chunks;
+}
+
+extern "C" size_t pleas_wgrad_batch_ws_bytes(const pleas_wgrad_layer* layers, int n_layers) {
+    if (!layers || n_layers <= 0) return 0;
+    WgradPlan tmp;
+    if (build_wgrad_plan(tmp, layers, n_layers) != PLEAS_OK) return 0;
+    return tmp.total;
+}
+
+extern "C" int pleas_wgrad_batch(const pleas_wgrad_layer* layers, int n_layers, void* ws, size_t ws_bytes, int ws_fresh,
+                                 void* stream_) {
+    if (!layers || n_layers <= 0) return bad_arg("wgrad: empty layer list");
+    for (int i = 0; i < n_layers; ++i) {
+        if (!layers[i].resid || !layers[i].ip || !layers[i].grad) return bad_arg("wgrad: null pointer");
+        if ((((uintptr_t)layers[i].resid | (uintptr_t)layers[i].ip) & 15) != 0) return bad_arg("wgrad: 16-byte alignment");
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    std::lock_guard<std::mutex> lk(g_wplan_mu);
+    WgradPlan& P = g_wplan;
+    std::vector<int64_t> key = wgrad_key(layers, n_layers, ws);
+    if (key != P.key) {
+        const int rc = build_wgrad_plan(P, layers, n_layers);
+        if (rc != PLEAS_OK) return rc;
+        P.key.swap(key);
+    }
+    if (ws_fresh) P.uploaded = false;  // caller says the tables inside ws are not (or no longer) there
+    if (!ws || ws_bytes < P.total) {
+        std::snprintf(g_last_error, sizeof(g_last_error), "wgrad workspace too small: need %zu bytes", P.total);
+        P.key.clear();
+        return PLEAS_ENOMEM;
+    }
+    char* base = (char*)ws;
+    if (!P.uploaded) {
+        float* slab0 = reinterpret_cast<float*>(base + P.off_slabs);
+        std::vector<WgradLayerDev> abs_layers = P.layers;
+        for (auto& d : abs_layers) d.slab = slab0 + reinterpret_cast<size_t>(d.slab);
+        PLEAS_HIP_CHECK(hipMemcpyAsync(base + P.off_layers, abs_layers.data(), abs_layers.size() * sizeof(WgradLayerDev),
+                                       hipMemcpyHostToDevice, stream));
+        PLEAS_HIP_CHECK(hipMemcpyAsync(base + P.off_items, P.items.data(), P.items.size() * sizeof(WgradItemDev),
+                                       hipMemcpyHostToDevice, stream));
+        if (!P.blk_layer.empty()) {
+            PLEAS_HIP_CHECK(hipMemcpyAsync(base + P.off_bl, P.blk_layer.data(), P.blk_layer.size() * sizeof(int),
+                                           hipMemcpyHostToDevice, stream));
+            PLEAS_HIP_CHECK(hipMemcpyAsync(base + P.off_bb, P.blk_begin.data(), P.blk_begin.size() * sizeof(int),
+                                           hipMemcpyHostToDevice, stream));
+        }
+        PLEAS_HIP_CHECK(hipStreamSynchronize(stream));
+        P.uploaded = true;
+    }
+    WgradLayerDev* dl = reinterpret_cast<WgradLayerDev*>(base + P.off_layers);
+    for (int b0 = 0; b0 < n_layers; b0 += cPtrBatch) {
+        WgradPtrBatch pb;
+        pb.base = b0;
+        pb.count = std::min(cPtrBatch, n_layers - b0);
+        for (int t = 0; t < pb.count; ++t) {
+            pb.resid[t] = layers[b0 + t].resid;
+            pb.ip[t] = layers[b0 + t].ip;
+            pb.out[t] = layers[b0 + t].grad;
+        }
+        hipLaunchKernelGGL(wgrad_set_ptrs_kernel, dim3(1), dim3(256), 0, stream, dl, pb);
+        PLEAS_LAUNCH_CHECK("wgrad_set_ptrs_kernel");
+    }
+    {
+        ProfScope prof(kProfConvWgrad, P.flops, P.bytes, stream);
+        hipLaunchKernelGGL(wgrad_batch_kernel, dim3((unsigned)P.items.size()), dim3(cThreads), P.lds, stream, dl,
+                           reinterpret_cast<const WgradItemDev*>(base + P.off_items));
+        PLEAS_LAUNCH_CHECK("wgrad_batch_kernel");
+        if (!P.blk_layer.empty()) {
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)P.blk_layer.size()), dim3(256), 0, stream, dl,
+                               reinterpret_cast<const int*>(base + P.off_bl),
+                               reinterpret_cast<const int*>(base + P.off_bb));
+            PLEAS_LAUNCH_CHECK("wgrad_reduce_kernel");
+        }
+    }
+    return PLEAS_OK;
+}
+
+extern "C" int pleas_target_residual(const float* out, const float* o1, const float* o2, const int32_t* row1,
+                                     const int32_t* row2, int n_merged, int N, int C, int Csrc, int64_t HW, float dscale,
+                                     float* resid, float* partials, int* n_partials, void* stream_) {
+    if (!out || !o1 || !o2 || !row1 || !row2 || !resid || !partials || !n_partials) return bad_arg("target_residual: null");
+    if (N <= 0 || C <= 0 || Csrc <= 0 || HW <= 0) return bad_arg("target_residual: shape");
+    const int64_t total = (int64_t)N * C * HW;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(total, 256), kTrBlocks));
+    *n_partials = blocks;
+    hipStream_t stream = (hipStream_t)stream_;
+    ProfScope prof(kProfSqerr, 0.0, 4.0 * total * sizeof(float), stream);
+    hipLaunchKernelGGL(target_residual_kernel, dim3(blocks), dim3(256), 0, stream, out, o1, o2, row1, row2, n_merged, N, C,
+                       Csrc, HW, dscale, resid, partials);
+    PLEAS_LAUNCH_CHECK("target_residual_kernel");
+    return PLEAS_OK;
+}
+
+extern "C" int pleas_target_residual_max_partials(void) { return kTrBlocks; }
+
+extern "C" int pleas_loss_final(const float* partials, const int* n_partials, const float* scale, int stride, int n_layers,
+                                float* loss, void* stream_) {
+    if (!partials || !n_partials || !scale || !loss || n_layers <= 0 || stride <= 0) return bad_arg("loss_final");
+    hipLaunchKernelGGL(loss_final_kernel, dim3(n_layers), dim3(64), 0, (hipStream_t)stream_, partials, n_partials, scale,
+                       stride, loss);
+    PLEAS_LAUNCH_CHECK("loss_final_kernel");
+    return PLEAS_OK;
+}

@@ -583,7 +583,8 @@ extern "C" size_t pleas_gram_batch_ws_bytes(const pleas_gram_node* nodes, int n_
 }
 
 extern "C" int pleas_gram_batch(const pleas_gram_node* nodes, int n_nodes, float* const* group_acc, const int* group_C,
-                                int n_groups, int epilogue, int accumulate, void* ws, size_t ws_bytes, void* stream_) {
+                                int n_groups, int epilogue, int accumulate, void* ws, size_t ws_bytes, int ws_fresh,
+                                void* stream_) {
     if (!nodes || n_nodes <= 0 || !group_acc || !group_C || n_groups <= 0) return bad_arg("gram_batch: empty input");
     if (epilogue != PLEAS_EPI_INNER && epilogue != PLEAS_EPI_NEG_CDIST) return bad_arg("epilogue");
     for (int i = 0; i < n_nodes; ++i) {
@@ -602,6 +603,7 @@ extern "C" int pleas_gram_batch(const pleas_gram_node* nodes, int n_nodes, float
         if (rc != PLEAS_OK) return rc;
         P.key.swap(key);
     }
+    if (ws_fresh) P.uploaded = false;  // caller says the tables inside ws are not (or no longer) there
     if (!ws || ws_bytes < P.total) {
         std::snprintf(g_last_error, sizeof(g_last_error), "gram_batch workspace too small: need %zu bytes", P.total);
         P.key.clear();

@@ -141,8 +141,10 @@ class GramBatch:
             if need == 0:
                 raise PleasHipError("pleas_gram_batch_ws_bytes rejected the node list: %s" % lib.pleas_last_error().decode())
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)  # dedicated: tables live in it
+            self._fresh = 1
         rc = lib.pleas_gram_batch(arr, n, self._acc, self._gc, len(self.mats), self.epilogue, int(bool(accumulate)),
-                                  self._ws.data_ptr(), self._ws.numel(), _stream())
+                                  self._ws.data_ptr(), self._ws.numel(), self._fresh, _stream())
+        self._fresh = 0
         if rc == -12:  # node list changed shape: size the workspace again
             self._ws = None
             self.flush(accumulate)
@@ -244,6 +246,88 @@ def sqerr(a: torch.Tensor, b: torch.Tensor, scale: float, out: torch.Tensor, acc
                                 diff.data_ptr() if diff is not None else None, ws.data_ptr(), ws.numel(), _stream())
     check(rc, "pleas_sqerr")
     return out
+
+
+# ---------------------------------------------------------------------------------------- PLeaS layer fitting
+def target_residual(out: torch.Tensor, o1: torch.Tensor, o2: torch.Tensor, row1: torch.Tensor, row2: torch.Tensor,
+                    n_merged: int, dscale: float, partials: torch.Tensor, resid: Optional[torch.Tensor] = None) -> int:
+    """resid = dscale * (out - blockmerge(o1, o2)); per-workgroup sums of squares -> ``partials``.
+    ``resid`` defaults to ``out`` (in place).  Returns the number of partials written."""
+    _need_gpu(out, o1, o2, partials)
+    if resid is None:
+        resid = out
+    if not (out.is_contiguous() and o1.is_contiguous() and o2.is_contiguous() and resid.is_contiguous()):
+        raise PleasHipError("target_residual operands must be contiguous")
+    N, C = out.shape[0], out.shape[1]
+    HW = math.prod(out.shape[2:])
+    if o1.shape != o2.shape or o1.shape[0] != N or math.prod(o1.shape[2:]) != HW or row1.numel() != C:
+        raise PleasHipError("target_residual: shapes of merged output, source outputs and maps disagree")
+    n = ctypes.c_int(0)
+    rc = _lib.lib().pleas_target_residual(out.data_ptr(), o1.data_ptr(), o2.data_ptr(), row1.data_ptr(), row2.data_ptr(),
+                                          int(n_merged), N, C, o1.shape[1], HW, dscale, resid.data_ptr(),
+                                          partials.data_ptr(), ctypes.byref(n), _stream())
+    check(rc, "pleas_target_residual")
+    return n.value
+
+
+def target_residual_max_partials() -> int:
+    return int(_lib.lib().pleas_target_residual_max_partials())
+
+
+def loss_final(partials: torch.Tensor, n_partials: torch.Tensor, scale: torch.Tensor, loss: torch.Tensor) -> None:
+    """loss[l] = scale[l] * sum(partials[l, :n_partials[l]]) for all layers in one launch."""
+    L, stride = partials.shape
+    rc = _lib.lib().pleas_loss_final(partials.data_ptr(), n_partials.data_ptr(), scale.data_ptr(), stride, L,
+                                     loss.data_ptr(), _stream())
+    check(rc, "pleas_loss_final")
+
+
+class WgradBatch:
+    """Weight gradients of all merged layers of one update in ONE grouped launch (``pleas_wgrad_batch``).
+    ``add`` per layer (operands must stay unmodified until ``flush``), ``flush`` once per update."""
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self._keep: list = []
+        self._geo: list = []
+        self._arr = None
+        self._ws = None
+
+    def add(self, resid: torch.Tensor, ip: torch.Tensor, grad: torch.Tensor, kernel=(1, 1), stride: int = 1,
+            pad: int = 0) -> None:
+        if not (resid.is_contiguous() and ip.is_contiguous() and grad.is_contiguous()):
+            raise PleasHipError("WgradBatch.add: contiguous tensors expected")
+        N, Cout, Cin = resid.shape[0], resid.shape[1], ip.shape[1]
+        Hin, Win = (ip.shape[2], ip.shape[3]) if ip.dim() == 4 else (1, 1)
+        self._keep.append((resid, ip, grad))
+        self._geo.append((N, Cout, Cin, Hin, Win, kernel[0], kernel[1], stride, pad))
+
+    def flush(self) -> None:
+        n = len(self._keep)
+        if n == 0:
+            return
+        if self._arr is None or len(self._arr) != n:
+            self._arr = (_lib.WgradLayer * n)()
+        for i, ((resid, ip, grad), geo) in enumerate(zip(self._keep, self._geo)):
+            a = self._arr[i]
+            a.resid, a.ip, a.grad = resid.data_ptr(), ip.data_ptr(), grad.data_ptr()
+            a.N, a.Cout, a.Cin, a.Hin, a.Win, a.KH, a.KW, a.stride, a.pad = geo
+        lib = _lib.lib()
+        if self._ws is None:
+            need = int(lib.pleas_wgrad_batch_ws_bytes(self._arr, n))
+            if need == 0:
+                raise PleasHipError("pleas_wgrad_batch_ws_bytes rejected the layer list: %s" % lib.pleas_last_error().decode())
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._fresh = 1
+        rc = lib.pleas_wgrad_batch(self._arr, n, self._ws.data_ptr(), self._ws.numel(), self._fresh, _stream())
+        self._fresh = 0
+        if rc == -12:
+            self._ws = None
+            self.flush()
+            return
+        check(rc, "pleas_wgrad_batch")
+        self._keep.clear()
+        self._geo.clear()
 
 
 # ---------------------------------------------------------------------------------------- live kernel timing

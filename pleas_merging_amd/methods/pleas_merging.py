@@ -16,9 +16,13 @@ MI355X design of one Adam step
     AND output (the reference re-runs every source layer a second time, :113-114);
   * ``ip``/``op`` are assembled by one ``pleas_merge_blocks`` launch each (reference: 8
     ``index_select`` + 2 ``cat`` per layer);
-  * the merged layer's forward and weight-gradient are the only grads computed (autograd in the
-    reference also back-propagates into both source layers); the loss value and the scaled
-    residual ``2 (out - op) / numel`` come from one ``pleas_sqerr`` pass;
+  * the regression target is never materialised: ``pleas_target_residual`` gathers/averages the
+    source outputs on the fly, turns the merged layer's output into the scaled residual
+    ``2 (out - op) / numel`` in place and emits the loss partials (one launch per layer);
+  * the weight gradients of ALL merged layers are ONE grouped fp32-MFMA launch
+    (``pleas_wgrad_batch``) that reads residuals and inputs in place from NCHW (autograd in the
+    reference also back-propagates into both source layers, and the vendor path needs NHWC
+    transposes);
   * all parameters, gradients, masks and Adam moments live in flat fp32 arenas, so the masked
     Adam update of the whole model is ONE ``pleas_masked_adam`` launch.
 """
@@ -209,36 +213,52 @@ class PleasFitter:
         self.step_count = 0
         self.loss_now = torch.zeros(len(self.plans), dtype=torch.float32, device=dev)   # this step, per layer
         self.loss_sum = torch.zeros(len(self.plans), dtype=torch.float32, device=dev)   # since last report
+        self.loss_parts = torch.zeros(len(self.plans), hip_ops.target_residual_max_partials(), dtype=torch.float32,
+                                      device=dev)
+        self.loss_nparts = torch.zeros(len(self.plans), dtype=torch.int32, device=dev)
+        self.loss_scale = torch.zeros(len(self.plans), dtype=torch.float32, device=dev)
+        self.loss_meta_host = [None] * len(self.plans)
+        self.wgrad = hip_ops.WgradBatch(dev)
 
-    # -- one layer: residual + weight gradient ------------------------------------------------
+    # -- one layer: merged input, merged-layer forward, fused target/residual, queue the weight gradient
     def _fit_layer(self, idx: int, plan: _LayerPlan) -> None:
         ops = self.ops
         name = plan.name
         ip1, ip2 = self.tap1.inputs[name], self.tap2.inputs[name]
         o1, o2 = self.tap1.outputs[name], self.tap2.outputs[name]
         ip = ops.merge_blocks(ip1, ip2, 1, *plan.in_maps)
-        op = ops.merge_blocks(o1, o2, 1, *plan.out_maps)
         mod = plan.mod
         if plan.is_conv:
             out = F.conv2d(ip, plan.w, plan.b, mod.stride, mod.padding, mod.dilation, mod.groups)
         else:
             out = F.linear(ip, plan.w, plan.b)
-        if out.shape != op.shape:
-            raise RuntimeError("layer %s: merged output %s vs target %s" % (name, tuple(out.shape), tuple(op.shape)))
+        r1, r2, nm = plan.out_maps
+        if out.shape[1] != r1.numel() or out.shape[2:] != o1.shape[2:]:
+            raise RuntimeError("layer %s: merged output %s vs target blocks %d x %s" %
+                               (name, tuple(out.shape), r1.numel(), tuple(o1.shape[2:])))
         n = out.numel() * self.world  # the mean runs over the full (global) batch
-        resid = torch.empty_like(out)
-        ops.sqerr(out, op, 1.0 / n, self.loss_now[idx:idx + 1], accumulate=False, diff=resid, dscale=2.0 / n)
-        if plan.is_conv:
+        # out <- 2 (out - target) / n in place; per-workgroup sums of squares -> this layer's partial row
+        nparts = ops.target_residual(out, o1.contiguous(), o2.contiguous(), r1, r2, nm, 2.0 / n, self.loss_parts[idx])
+        if self.loss_meta_host[idx] != (nparts, n):
+            self.loss_meta_host[idx] = (nparts, n)
+            self.loss_nparts[idx] = nparts
+            self.loss_scale[idx] = 1.0 / n
+        resid = out
+        hip_ok = plan.is_conv and mod.groups == 1 and mod.dilation == (1, 1) and mod.stride[0] == mod.stride[1] \
+            and mod.padding[0] == mod.padding[1] and ip.shape[1] >= 16
+        if hip_ok:
+            self.wgrad.add(resid, ip, plan.gw, tuple(mod.kernel_size), mod.stride[0], mod.padding[0])
+        elif not plan.is_conv and ip.dim() == 2:
+            self.wgrad.add(resid, ip, plan.gw)
+        elif plan.is_conv:  # stem (3 input channels) and exotic geometries: vendor kernel
             gw = torch.ops.aten.convolution_backward(resid, ip, plan.w, None, mod.stride, mod.padding, mod.dilation,
                                                      False, [0, 0], mod.groups, [False, True, False])[1]
             plan.gw.copy_(gw)
-            if plan.gb is not None:
-                plan.gb.copy_(resid.sum((0, 2, 3)))
         else:
-            r2, i2 = resid.reshape(-1, resid.shape[-1]), ip.reshape(-1, ip.shape[-1])
-            torch.mm(r2.t(), i2, out=plan.gw)
-            if plan.gb is not None:
-                plan.gb.copy_(r2.sum(0))
+            r2d, i2d = resid.reshape(-1, resid.shape[-1]), ip.reshape(-1, ip.shape[-1])
+            torch.mm(r2d.t(), i2d, out=plan.gw)
+        if plan.gb is not None:
+            plan.gb.copy_(resid.sum((0, 2, 3)) if plan.is_conv else resid.reshape(-1, resid.shape[-1]).sum(0))
 
     @torch.no_grad()
     def step(self, x: torch.Tensor) -> None:
@@ -252,6 +272,8 @@ class PleasFitter:
                 print("Key error on %s" % plan.name)
                 continue
             self._fit_layer(idx, plan)
+        self.wgrad.flush()  # ONE grouped MFMA launch: weight gradients of every merged layer
+        self.ops.loss_final(self.loss_parts, self.loss_nparts, self.loss_scale, self.loss_now)
         dp_sum_(self.g, self.world)
         dp_sum_(self.loss_now, self.world)
         self.loss_sum.add_(self.loss_now)

@@ -249,3 +249,68 @@ def test_gram_batch_deterministic_and_overwrite(ops):
     assert torch.equal(outs[0], outs[1])
     ref = ops.cross_features_cdist(x, y, 1) + ops.cross_features_cdist(y, x, 1)
     assert torch.allclose(outs[0], ref, rtol=1e-5, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------ PLeaS layer kernels
+WGRAD_CASES = [
+    # N, Cout, Cin, H, W, k, stride, pad
+    (4, 256, 64, 14, 14, 1, 1, 0),     # 1x1: direct loader, TN = 64
+    (4, 64, 256, 14, 14, 1, 1, 0),     # TM = 64
+    (3, 96, 80, 7, 7, 1, 1, 0),        # HW = 49: scalar loads, ragged tiles
+    (4, 128, 128, 14, 14, 3, 1, 1),    # 3x3 shifted loader, padding
+    (2, 40, 24, 9, 11, 3, 1, 1),       # ragged everything, non-square image
+    (4, 128, 64, 28, 28, 3, 2, 1),     # 3x3 stride 2
+    (4, 256, 128, 28, 28, 1, 2, 0),    # 1x1 stride 2 (downsample)
+    (2, 64, 64, 56, 56, 3, 1, 1),      # long pixel axis -> split into slabs + reduce
+    (16, 64, 32, 1, 1, 1, 1, 0),       # linear-like (HW = 1)
+]
+
+
+@pytest.mark.parametrize("N,Cout,Cin,H,W,k,stride,pad", WGRAD_CASES)
+def test_wgrad_batch_matches_torch(ops, N, Cout, Cin, H, W, k, stride, pad):
+    g = torch.Generator().manual_seed(N * Cout + Cin + k)
+    ip = torch.randn(N, Cin, H, W, generator=g)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    resid = torch.randn(N, Cout, Ho, Wo, generator=g)
+    w = torch.zeros(Cout, Cin, k, k)
+    want = torch.ops.aten.convolution_backward(resid.double(), ip.double(), w.double(), None, [stride, stride], [pad, pad],
+                                               [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    batch = ops.WgradBatch(torch.device("cuda"))
+    grad = torch.full((Cout, Cin, k, k), float("nan"), device="cuda")
+    grad2 = torch.full((Cout, Cin, k, k), float("nan"), device="cuda")
+    batch.add(resid.cuda(), ip.cuda(), grad, (k, k), stride, pad)
+    batch.add((2 * resid).cuda(), ip.cuda(), grad2, (k, k), stride, pad)   # two layers in one launch
+    batch.flush()
+    assert _rel(grad.cpu(), want) < 3e-6
+    assert _rel(grad2.cpu(), 2 * want) < 3e-6
+
+
+def test_wgrad_linear(ops):
+    g = torch.Generator().manual_seed(1)
+    ip, resid = torch.randn(16, 300, generator=g), torch.randn(16, 70, generator=g)
+    grad = torch.empty(70, 300, device="cuda")
+    batch = ops.WgradBatch(torch.device("cuda"))
+    batch.add(resid.cuda(), ip.cuda(), grad)
+    batch.flush()
+    assert _rel(grad.cpu(), resid.double().t() @ ip.double()) < 2e-6
+
+
+def test_target_residual_and_loss(ops):
+    g = torch.Generator().manual_seed(2)
+    o1, o2 = torch.randn(3, 9, 5, 5, generator=g), torch.randn(3, 9, 5, 5, generator=g)
+    b = (torch.tensor([0, 2, 4, 6]), torch.tensor([1, 3, 5, 7]), torch.tensor([1, 3, 5, 7, 8]),
+         torch.tensor([0, 2, 4, 6, 8]))
+    from pleas_merging_amd.methods.partial_matching import block_maps
+
+    r1, r2, nm = block_maps(b, "cuda")
+    target = torch.cat([(o1[:, b[0]] + o2[:, b[1]]) / 2, o1[:, b[2]], o2[:, b[3]]], 1)
+    out = torch.randn(target.shape, generator=g)
+    n = out.numel()
+    parts = torch.zeros(2, ops.target_residual_max_partials(), device="cuda")
+    buf = out.clone().cuda()
+    cnt = ops.target_residual(buf, o1.cuda(), o2.cuda(), r1, r2, nm, 2.0 / n, parts[1])
+    assert torch.allclose(buf.cpu(), 2 * (out - target) / n, rtol=1e-6, atol=1e-9)
+    loss = torch.zeros(2, device="cuda")
+    ops.loss_final(parts, torch.tensor([0, cnt], dtype=torch.int32, device="cuda"),
+                   torch.tensor([1.0, 1.0 / n], device="cuda"), loss)
+    assert float(loss[0]) == 0.0 and abs(float(loss[1]) - float(((out - target) ** 2).mean())) < 1e-5
