@@ -69,6 +69,9 @@ def parse():
     ap.add_argument("--ratio", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-batch", type=int, default=2)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
+                                                      "the multi-rank logic on a single GPU)")
+    ap.add_argument("--all-ranks-on-gpu0", action="store_true", help="rehearsal only: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -194,7 +197,12 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.all_ranks_on_gpu0:
+            local = 0
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local)
@@ -253,7 +261,7 @@ def main():
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         roofline = {
-            "bound": "mfma", "kernel": "gram_partial_kernel (fp32 MFMA 32x32x2)", "achieved": round(achieved, 2),
+            "bound": "mfma", "kernel": "gram_batch_kernel (grouped fp32 MFMA 32x32x2 contraction, one launch per matching batch)", "achieved": round(achieved, 2),
             "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4),
             "traffic": traffic, "launches": dom[0], "avg_launch_us": round(dom[1] * 1e3 / max(dom[0], 1), 2),
             "algorithmic_flop_per_launch": round(dom[2] / max(dom[0], 1)),

@@ -279,27 +279,58 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradLayerDev* 
 //   part[blockIdx] = sum over this block of (out - t)^2
 // Replaces pleas_merging.py:116-123 + :147 (index_select x4 + cat for the outputs), :282 and the first
 // node of its backward.
-constexpr int kTrBlocks = 512;
+constexpr int kTrBlocks = 2048;
+template <int VEC>
 __global__ __launch_bounds__(256) void target_residual_kernel(const float* __restrict__ out, const float* __restrict__ o1,
                                                               const float* __restrict__ o2, const int32_t* __restrict__ row1,
-                                                              const int32_t* __restrict__ row2, int n_merged, int N, int C,
-                                                              int Csrc, int64_t HW, float dscale, float* __restrict__ resid,
-                                                              float* __restrict__ part) {
-    const int64_t total = (int64_t)N * C * HW;
+                                                              const int32_t* __restrict__ row2, int n_merged, int C, int Csrc,
+                                                              uint32_t HW, uint32_t total_v, float dscale,
+                                                              float* __restrict__ resid, float* __restrict__ part) {
+    // flattened [N*C][HW] view, VEC elements per thread per step; a VEC-wide piece never crosses a row
+    // (HW % VEC == 0), so one 32-bit division per piece locates its (n, c) row
+    const uint32_t hw_v = HW / VEC;
     float s = 0.f;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t p = idx % HW;
-        const int64_t t = idx / HW;
-        const int c = (int)(t % C);
-        const int64_t n = t / C;
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total_v; v += gridDim.x * blockDim.x) {
+        const uint32_t row = v / hw_v, pv = v - row * hw_v;
+        const uint32_t n = row / (uint32_t)C, c = row - n * (uint32_t)C;
         const int r1 = row1[c], r2 = row2[c];
-        float a = 0.f, b = 0.f;
-        if (r1 >= 0) a = o1[(n * Csrc + r1) * HW + p];
-        if (r2 >= 0) b = o2[(n * Csrc + r2) * HW + p];
-        const float tgt = (a + b) * (c < n_merged ? 0.5f : 1.0f);
-        const float d = out[idx] - tgt;
-        s = fmaf(d, d, s);
-        resid[idx] = dscale * d;
+        const float coef = (int)c < n_merged ? 0.5f : 1.0f;
+        float a[VEC], b[VEC], o[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a[e] = b[e] = 0.f;
+        const size_t po = (size_t)pv * VEC;
+        if constexpr (VEC == 4) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(out + (size_t)row * HW + po);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = q[e];
+            if (r1 >= 0) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(o1 + ((size_t)n * Csrc + r1) * HW + po);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = t[e];
+            }
+            if (r2 >= 0) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(o2 + ((size_t)n * Csrc + r2) * HW + po);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b[e] = t[e];
+            }
+        } else {
+            o[0] = out[(size_t)row * HW + po];
+            if (r1 >= 0) a[0] = o1[((size_t)n * Csrc + r1) * HW + po];
+            if (r2 >= 0) b[0] = o2[((size_t)n * Csrc + r2) * HW + po];
+        }
+        float d[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            d[e] = o[e] - (a[e] + b[e]) * coef;
+            s = fmaf(d[e], d[e], s);
+            d[e] *= dscale;
+        }
+        if constexpr (VEC == 4) {
+            f32x4 q = {d[0], d[1], d[2], d[3]};
+            *reinterpret_cast<f32x4*>(resid + (size_t)row * HW + po) = q;
+        } else {
+            resid[(size_t)row * HW + po] = d[0];
+        }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
@@ -519,12 +550,20 @@ extern "C" int pleas_target_residual(const float* out, const float* o1, const fl
     if (!out || !o1 || !o2 || !row1 || !row2 || !resid || !partials || !n_partials) return bad_arg("target_residual: null");
     if (N <= 0 || C <= 0 || Csrc <= 0 || HW <= 0) return bad_arg("target_residual: shape");
     const int64_t total = (int64_t)N * C * HW;
-    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(total, 256), kTrBlocks));
+    if (total >= (1ll << 32)) return bad_arg("target_residual: more than 2^32 elements");
+    const bool vec = HW % 4 == 0 &&
+                     ((((uintptr_t)out | (uintptr_t)o1 | (uintptr_t)o2 | (uintptr_t)resid) & 15) == 0);
+    const int64_t pieces = vec ? total / 4 : total;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(pieces, 256), kTrBlocks));
     *n_partials = blocks;
     hipStream_t stream = (hipStream_t)stream_;
     ProfScope prof(kProfSqerr, 0.0, 4.0 * total * sizeof(float), stream);
-    hipLaunchKernelGGL(target_residual_kernel, dim3(blocks), dim3(256), 0, stream, out, o1, o2, row1, row2, n_merged, N, C,
-                       Csrc, HW, dscale, resid, partials);
+    if (vec)
+        hipLaunchKernelGGL((target_residual_kernel<4>), dim3(blocks), dim3(256), 0, stream, out, o1, o2, row1, row2, n_merged,
+                           C, Csrc, (uint32_t)HW, (uint32_t)pieces, dscale, resid, partials);
+    else
+        hipLaunchKernelGGL((target_residual_kernel<1>), dim3(blocks), dim3(256), 0, stream, out, o1, o2, row1, row2, n_merged,
+                           C, Csrc, (uint32_t)HW, (uint32_t)pieces, dscale, resid, partials);
     PLEAS_LAUNCH_CHECK("target_residual_kernel");
     return PLEAS_OK;
 }
