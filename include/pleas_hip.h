@@ -190,7 +190,7 @@ int pleas_prof_collect(int kernel, int64_t* launches, double* total_ms, double* 
 
 /* Tuning hook for experiments: split-K target workgroup count and minimum K chunks per split. */
 void pleas_gram_tune(int target_blocks, int min_chunks_per_split);
-void pleas_gram_batch_tune(int item_chunks);
+void pleas_gram_batch_tune(int item_chunks, int xcd_order);
 void pleas_wgrad_tune(int item_chunks);
 
 #ifdef __cplusplus

@@ -439,7 +439,8 @@ extern "C" int pleas_gram_accum(const float* x, const float* y, int B, int C, in
 // =========================================================================================
 namespace pleas {
 
-static int g_item_chunks = 112;  // K chunks per work item (K = 3584): nodes with longer K are split
+static int g_item_chunks = 112;
+static int g_xcd_order = 1;  // K chunks per work item (K = 3584): nodes with longer K are split
 
 struct BatchPlan {
     std::vector<int64_t> key;
@@ -508,6 +509,31 @@ static int build_batch_plan(BatchPlan& P, const pleas_gram_node* nd, int n, floa
     std::stable_sort(work.begin(), work.end(), [](const Work& a, const Work& b) { return a.w > b.w; });
     P.items.reserve(work.size());
     for (auto& w : work) P.items.push_back(w.it);
+    // XCD-aware tile order: workgroups b and b+8 share an XCD (private L2).  Inside every run of
+    // items that belongs to one (node, split), give each XCD a compact sr x sc block of output
+    // tiles, so the operand rows a tile row / column needs are fetched by one L2 instead of eight.
+    if (g_xcd_order) {
+        size_t pos = 0;
+        while (pos < P.items.size()) {
+            size_t end = pos;
+            while (end < P.items.size() && P.items[end].node == P.items[pos].node && P.items[end].split == P.items[pos].split)
+                ++end;
+            const int t = (int)ceil_div(P.nodes[P.items[pos].node].C, P.nodes[P.items[pos].node].variant < 2 ? 128 : 64);
+            if ((int)(end - pos) == t * t && t >= 4 && (t & (t - 1)) == 0) {
+                int sr = 1, sc = 1;  // sr * sc = t*t/8, as square as possible, sc >= sr
+                for (int area = t * t / 8; sr * sc < area;) (sc <= sr ? sc : sr) *= 2;
+                if (sr > sc) std::swap(sr, sc);
+                const int blocks_c = t / sc;
+                int seen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (size_t g = pos; g < end; ++g) {
+                    const int xcd = (int)(g % 8), k = seen[xcd]++;
+                    P.items[g].tm = (xcd / blocks_c) * sr + k / sc;
+                    P.items[g].tn = (xcd % blocks_c) * sc + k % sc;
+                }
+            }
+            pos = end;
+        }
+    }
     // groups: node lists in first-appearance order, reduce blocks of 256 elements
     int blk = 0;
     for (int g = 0; g < n_groups; ++g) {
@@ -554,7 +580,7 @@ static std::vector<int64_t> batch_key(const pleas_gram_node* nd, int n, float* c
     k.push_back(n);
     k.push_back(n_groups);
     k.push_back((int64_t)(uintptr_t)ws);
-    k.push_back(g_item_chunks);
+    k.push_back(g_item_chunks * 2 + g_xcd_order);
     for (int i = 0; i < n; ++i) {
         k.push_back(nd[i].B);
         k.push_back(nd[i].C);
@@ -570,8 +596,9 @@ static std::vector<int64_t> batch_key(const pleas_gram_node* nd, int n, float* c
 
 }  // namespace pleas
 
-extern "C" void pleas_gram_batch_tune(int item_chunks) {
+extern "C" void pleas_gram_batch_tune(int item_chunks, int xcd_order) {
     if (item_chunks > 0) g_item_chunks = item_chunks;
+    if (xcd_order >= 0) g_xcd_order = xcd_order;
 }
 
 extern "C" size_t pleas_gram_batch_ws_bytes(const pleas_gram_node* nodes, int n_nodes, const int* group_C, int n_groups) {
