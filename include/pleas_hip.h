@@ -165,7 +165,10 @@ typedef struct pleas_wgrad_layer {
     const float* ip;    /* [N][Cin][Hin][Win]   */
     float* grad;        /* [Cout][Cin][KH][KW]  */
     int N, Cout, Cin, Hin, Win, KH, KW, stride, pad;
+    int flags;          /* PLEAS_WGRAD_* */
 } pleas_wgrad_layer;
+#define PLEAS_WGRAD_ACCUMULATE 1  /* grad += instead of grad = (normal equations: B^T over many batches) */
+#define PLEAS_WGRAD_KPOS_MAJOR 2  /* write grad as [Cout][KH*KW][Cin] (kernel-position-major columns) */
 int pleas_target_residual(const float* out, const float* o1, const float* o2, const int32_t* row1, const int32_t* row2,
                           int n_merged, int N, int C, int Csrc, int64_t HW, float dscale, float* resid, float* partials,
                           int* n_partials, void* stream);
@@ -175,6 +178,24 @@ int pleas_loss_final(const float* partials, const int* n_partials, const float* 
 size_t pleas_wgrad_batch_ws_bytes(const pleas_wgrad_layer* layers, int n_layers);
 int pleas_wgrad_batch(const pleas_wgrad_layer* layers, int n_layers, void* ws, size_t ws_bytes, int ws_fresh,
                       void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Normal equations of the per-layer PLeaS objective (closed form of what the reference's Adam
+ * loop, pleas_merging.py:281-291 + :357-358, approximates):  W^T = A^-1 B  with
+ *   A = sum_batches U^T U   (K x K, K = KH*KW*Cin, index k = (kh*KW + kw)*Cin + ci)
+ *   B^T = sum_batches op . U  -> pleas_wgrad_batch(resid := op, flags = ACCUMULATE | KPOS_MAJOR).
+ * pleas_normal_eq_accum adds one batch's U^T U of EVERY listed layer into its A (LOWER triangle of
+ * 64/128-wide block tiles only; the strict upper part of A is left untouched), one grouped
+ * fp32-MFMA launch, U = im2col(ip) never materialised.  ws / ws_fresh as in pleas_gram_batch.
+ */
+typedef struct pleas_neq_layer {
+    const float* ip; /* [N][Cin][Hin][Win] merged layer input */
+    float* A;        /* [K][K] fp32, accumulated in place */
+    int N, Cin, Hin, Win, KH, KW, stride, pad;
+} pleas_neq_layer;
+size_t pleas_normal_eq_ws_bytes(const pleas_neq_layer* layers, int n_layers);
+int pleas_normal_eq_accum(const pleas_neq_layer* layers, int n_layers, void* ws, size_t ws_bytes, int ws_fresh,
+                          void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Opt-in live timing of the library's kernels with HIP events recorded on the launch stream

@@ -41,6 +41,8 @@ SIGNATURES = {
                                       c_int64, c_float, c_void_p, c_void_p, POINTER(c_int), c_void_p]),
     "pleas_target_residual_max_partials": (c_int, []),
     "pleas_loss_final": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "pleas_normal_eq_ws_bytes": (c_size_t, [c_void_p, c_int]),
+    "pleas_normal_eq_accum": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "pleas_wgrad_batch_ws_bytes": (c_size_t, [c_void_p, c_int]),
     "pleas_wgrad_batch": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "pleas_gram_batch_ws_bytes": (c_size_t, [c_void_p, c_int, POINTER(c_int), c_int]),
@@ -49,10 +51,17 @@ SIGNATURES = {
 }
 
 
+class NeqLayer(ctypes.Structure):
+    """struct pleas_neq_layer"""
+    _fields_ = [("ip", c_void_p), ("A", c_void_p), ("N", c_int), ("Cin", c_int), ("Hin", c_int), ("Win", c_int),
+                ("KH", c_int), ("KW", c_int), ("stride", c_int), ("pad", c_int)]
+
+
 class WgradLayer(ctypes.Structure):
     """struct pleas_wgrad_layer"""
     _fields_ = [("resid", c_void_p), ("ip", c_void_p), ("grad", c_void_p), ("N", c_int), ("Cout", c_int), ("Cin", c_int),
-                ("Hin", c_int), ("Win", c_int), ("KH", c_int), ("KW", c_int), ("stride", c_int), ("pad", c_int)]
+                ("Hin", c_int), ("Win", c_int), ("KH", c_int), ("KW", c_int), ("stride", c_int), ("pad", c_int),
+                ("flags", c_int)]
 
 
 class GramNode(ctypes.Structure):

@@ -42,6 +42,8 @@ struct WgradLayerDev {
     uint32_t HWo, Ktot;  // Ktot = N * HWo
     int S;
     int variant;         // bit0: TM==64, bit1: TN==64, bit2: X scalar loads, bit3: Y shifted (scalar) loader
+    int flags;           // PLEAS_WGRAD_ACCUMULATE | PLEAS_WGRAD_KPOS_MAJOR
+    int pad0;
 };
 struct WgradItemDev {
     int layer, tm, tn, r, split, c_begin, c_end, pad;
@@ -204,9 +206,12 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradIt
             for (int r = 0; r < 16; ++r) {
                 const int co = i0 + wm * (TM / 2) + sm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (co < L.Cout && ci < L.Cin) {
-                    if (L.S == 1)
-                        L.out[((size_t)co * L.Cin + ci) * R + it.r] = acc[sm][sn][r];
-                    else
+                    if (L.S == 1) {
+                        const size_t o = (L.flags & PLEAS_WGRAD_KPOS_MAJOR)
+                                             ? (size_t)co * ((size_t)R * L.Cin) + (size_t)it.r * L.Cin + ci
+                                             : ((size_t)co * L.Cin + ci) * R + it.r;
+                        L.out[o] = (L.flags & PLEAS_WGRAD_ACCUMULATE) ? L.out[o] + acc[sm][sn][r] : acc[sm][sn][r];
+                    } else
                         L.slab[((size_t)it.split * L.Cout + co) * ((size_t)R * L.Cin) + (size_t)it.r * L.Cin + ci] =
                             acc[sm][sn][r];
                 }
@@ -269,7 +274,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradLayerDev* 
     const int r = rem / L.Cin, ci = rem - r * L.Cin;
     float s = 0.f;
     for (int k = 0; k < L.S; ++k) s += L.slab[(size_t)k * per + idx];
-    L.out[((size_t)co * L.Cin + ci) * R + r] = s;
+    const size_t o = (L.flags & PLEAS_WGRAD_KPOS_MAJOR) ? idx : ((size_t)co * L.Cin + ci) * R + r;
+    L.out[o] = (L.flags & PLEAS_WGRAD_ACCUMULATE) ? L.out[o] + s : s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -395,6 +401,7 @@ static int build_wgrad_plan(WgradPlan& P, const pleas_wgrad_layer* ly, int n) {
         d.KH = l.KH; d.KW = l.KW; d.stride = l.stride; d.pad = l.pad;
         d.HWo = (uint32_t)HWo;
         d.Ktot = (uint32_t)K;
+        d.flags = l.flags;
         const int R = l.KH * l.KW;
         const int TM = l.Cout > 64 ? 128 : 64, TN = l.Cin > 64 ? 128 : 64;
         const bool ydirect = R == 1 && l.stride == 1 && l.pad == 0;
@@ -456,7 +463,7 @@ static std::vector<int64_t> wgrad_key(const pleas_wgrad_layer* ly, int n, const 
     k.push_back(g_wgrad_item_chunks);
     for (int i = 0; i < n; ++i) {
         const pleas_wgrad_layer& l = ly[i];
-        for (int v : {l.N, l.Cout, l.Cin, l.Hin, l.Win, l.KH, l.KW, l.stride, l.pad}) k.push_back(v);
+        for (int v : {l.N, l.Cout, l.Cin, l.Hin, l.Win, l.KH, l.KW, l.stride, l.pad, l.flags}) k.push_back(v);
     }
     return k;
 }

@@ -1,0 +1,395 @@
+// Normal equations of the PLeaS layer objective on gfx950: A += U^T U for ALL merged layers of one
+// batch in one grouped fp32-MFMA launch (the right-hand side B^T += op . U is pleas_wgrad_batch with
+// PLEAS_WGRAD_ACCUMULATE | PLEAS_WGRAD_KPOS_MAJOR).
+//
+// The reference minimises  sum_batches mean((L(ip) - op)^2)  per layer with 401 Adam steps
+// (pleas/methods/pleas_merging.py:281-291, :357-358); its closed form is  W^T = A^-1 B  with
+// U = im2col(ip) (rows = samples x output pixels, columns = kernel position x input channel).
+//
+// U is never materialised.  Column k = (r, ci) of U is the r-shifted (strided) view of input
+// channel ci, so the block of A between kernel positions (rx, ry) is an NT contraction over the
+// flattened pixel index P = (n, oh, ow) of two shifted views of the SAME tensor, read in place
+// from NCHW.  Only block tiles of the LOWER triangle are computed (A is symmetric).  Work items
+// (layer, tile row, tile column, P range) of all layers form one grid sorted longest-first; P ranges
+// longer than one item go through slabs and an ordered reduce (deterministic, no atomics).
+//
+// Algorithmic work: K^2 * N*HWo flop per layer and batch for the triangle (K = KH*KW*Cin);
+// ResNet-101, batch 16: 6.7e11 flop per batch (4.18e10 per sample), MFMA bound.
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
+#include "common.hpp"
+
+namespace pleas {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int nBK = 32;
+constexpr int nLds = 36;
+constexpr int nThreads = 256;
+
+struct NeqLayerDev {
+    const float* ip;  // [N][Cin][Hin][Win]
+    float* A;         // [K][K], K = R*Cin, kernel-position-major index k = r*Cin + ci
+    float* slab;      // [S][items of this layer][T*T] when S > 1 (indexed through item.slot)
+    int Cin, Hin, Win, Hout, Wout, KH, KW, stride, pad;
+    uint32_t HWo, Ktot;
+    int S, K;
+    int variant;      // bit0: 64-wide tiles, bit1: scalar loads, bit2: shifted loader
+};
+struct NeqItemDev {
+    int layer, tm, tn, rx, ry, split, c_begin, c_end, slot, pad0;
+};
+
+template <int T, int VEC, bool SHIFT>
+__device__ __forceinline__ void neq_tile(const NeqLayerDev& L, const NeqItemDev& it, float* smem) {
+    constexpr int MT = T / 64;
+    constexpr int LPR = nBK / VEC, RPP = nThreads / LPR, PASS = T / RPP;
+    float* As = smem;
+    float* Bs = smem + 2 * T * nLds;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i0 = it.tm * T, j0 = it.tn * T;
+    const uint32_t HWi = (uint32_t)L.Hin * L.Win;
+    const int khx = it.rx / L.KW, kwx = it.rx - khx * L.KW, khy = it.ry / L.KW, kwy = it.ry - khy * L.KW;
+    const int dhx = khx - L.pad, dwx = kwx - L.pad, dhy = khy - L.pad, dwy = kwy - L.pad;
+    const int srow = tid / LPR, scol = (tid % LPR) * VEC;
+    float ra[PASS][VEC], rb[PASS][VEC];
+    unsigned oka = 0, okb = 0;
+    uint32_t offa[PASS], offb[PASS];
+#pragma unroll
+    for (int q = 0; q < PASS; ++q) {
+        const int gi = i0 + srow + q * RPP, gj = j0 + srow + q * RPP;
+        if (gi < L.Cin) oka |= 1u << q;
+        if (gj < L.Cin) okb |= 1u << q;
+        offa[q] = (uint32_t)min(gi, L.Cin - 1) * HWi;
+        offb[q] = (uint32_t)min(gj, L.Cin - 1) * HWi;
+    }
+    f32x16 acc[MT][MT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    bool ina = false, inb = false;
+    auto load_chunk = [&](int c) {
+        const uint32_t P = (uint32_t)c * nBK + scol;
+        const bool in = P < L.Ktot;
+        const uint32_t n = in ? P / L.HWo : 0u;
+        const uint32_t p = in ? P - n * L.HWo : 0u;
+        size_t basea, baseb;
+        if constexpr (SHIFT) {
+            const int oh = (int)(p / (uint32_t)L.Wout), ow = (int)(p - (uint32_t)oh * L.Wout);
+            const int iha = oh * L.stride + dhx, iwa = ow * L.stride + dwx;
+            const int ihb = oh * L.stride + dhy, iwb = ow * L.stride + dwy;
+            ina = in && iha >= 0 && iha < L.Hin && iwa >= 0 && iwa < L.Win;
+            inb = in && ihb >= 0 && ihb < L.Hin && iwb >= 0 && iwb < L.Win;
+            basea = (size_t)n * L.Cin * HWi + (ina ? (size_t)iha * L.Win + iwa : 0);
+            baseb = (size_t)n * L.Cin * HWi + (inb ? (size_t)ihb * L.Win + iwb : 0);
+        } else {
+            ina = inb = in;
+            basea = baseb = (size_t)n * L.Cin * HWi + p;
+        }
+#pragma unroll
+        for (int q = 0; q < PASS; ++q) {
+            if constexpr (VEC == 4) {
+                const f32x4 va = *reinterpret_cast<const f32x4*>(L.ip + basea + offa[q]);
+                const f32x4 vb = *reinterpret_cast<const f32x4*>(L.ip + baseb + offb[q]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ra[q][e] = va[e];
+                    rb[q][e] = vb[e];
+                }
+            } else {
+                ra[q][0] = L.ip[basea + offa[q]];
+                rb[q][0] = L.ip[baseb + offb[q]];
+            }
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        float* a = As + buf * T * nLds;
+        float* b = Bs + buf * T * nLds;
+#pragma unroll
+        for (int q = 0; q < PASS; ++q) {
+            const bool fa = ina && ((oka >> q) & 1u), fb = inb && ((okb >> q) & 1u);
+            const int row = srow + q * RPP;
+            if constexpr (VEC == 4) {
+                f32x4 va = {fa ? ra[q][0] : 0.f, fa ? ra[q][1] : 0.f, fa ? ra[q][2] : 0.f, fa ? ra[q][3] : 0.f};
+                f32x4 vb = {fb ? rb[q][0] : 0.f, fb ? rb[q][1] : 0.f, fb ? rb[q][2] : 0.f, fb ? rb[q][3] : 0.f};
+                *reinterpret_cast<f32x4*>(a + row * nLds + scol) = va;
+                *reinterpret_cast<f32x4*>(b + row * nLds + scol) = vb;
+            } else {
+                a[row * nLds + scol] = fa ? ra[q][0] : 0.f;
+                b[row * nLds + scol] = fb ? rb[q][0] : 0.f;
+            }
+        }
+    };
+    auto compute = [&](int buf) {
+        const float* a = As + buf * T * nLds + (wm * (T / 2) + (lane & 31)) * nLds + 4 * (lane >> 5);
+        const float* b = Bs + buf * T * nLds + (wn * (T / 2) + (lane & 31)) * nLds + 4 * (lane >> 5);
+#pragma unroll
+        for (int kk = 0; kk < nBK / 8; ++kk) {
+            f32x4 fa[MT], fb[MT];
+#pragma unroll
+            for (int s = 0; s < MT; ++s) {
+                fa[s] = *reinterpret_cast<const f32x4*>(a + s * 32 * nLds + kk * 8);
+                fb[s] = *reinterpret_cast<const f32x4*>(b + s * 32 * nLds + kk * 8);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int sm = 0; sm < MT; ++sm)
+#pragma unroll
+                    for (int sn = 0; sn < MT; ++sn)
+                        acc[sm][sn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sm][e], fb[sn][e], acc[sm][sn], 0, 0, 0);
+        }
+    };
+    if (it.c_begin < it.c_end) {
+        load_chunk(it.c_begin);
+        store_chunk(0);
+    }
+    __syncthreads();
+    for (int c = it.c_begin; c < it.c_end; ++c) {
+        const int buf = (c - it.c_begin) & 1;
+        const bool more = c + 1 < it.c_end;
+        if (more) load_chunk(c + 1);
+        compute(buf);
+        if (more) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+    // epilogue: S == 1 -> A += tile ; else tile -> this (slot, split) slab
+    float* slab = L.S > 1 ? L.slab + ((size_t)it.slot * L.S + it.split) * (T * T) : nullptr;
+#pragma unroll
+    for (int sm = 0; sm < MT; ++sm)
+#pragma unroll
+        for (int sn = 0; sn < MT; ++sn) {
+            const int lj = wn * (T / 2) + sn * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int li = wm * (T / 2) + sm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (slab) {
+                    slab[li * T + lj] = acc[sm][sn][r];
+                } else if (i0 + li < L.Cin && j0 + lj < L.Cin) {
+                    float* o = L.A + ((size_t)it.rx * L.Cin + i0 + li) * L.K + (size_t)it.ry * L.Cin + j0 + lj;
+                    *o += acc[sm][sn][r];
+                }
+            }
+        }
+}
+
+__global__ __launch_bounds__(nThreads) void neq_batch_kernel(const NeqLayerDev* __restrict__ layers,
+                                                             const NeqItemDev* __restrict__ items) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const NeqItemDev it = items[blockIdx.x];
+    const NeqLayerDev L = layers[it.layer];
+    switch (L.variant) {
+        case 0: neq_tile<128, 4, false>(L, it, smem); break;
+        case 1: neq_tile<64, 4, false>(L, it, smem); break;
+        case 2: neq_tile<128, 1, false>(L, it, smem); break;
+        case 3: neq_tile<64, 1, false>(L, it, smem); break;
+        case 6: neq_tile<128, 1, true>(L, it, smem); break;
+        default: neq_tile<64, 1, true>(L, it, smem); break;
+    }
+}
+
+// A += sum over splits of the slabs (one block per (slot) tile, threads over the T*T tile)
+struct NeqReduceDev {
+    int layer, tm, tn, rx, ry, slot, T, pad;
+};
+__global__ __launch_bounds__(256) void neq_reduce_kernel(const NeqLayerDev* __restrict__ layers,
+                                                         const NeqReduceDev* __restrict__ red) {
+    const NeqReduceDev rd = red[blockIdx.x];
+    const NeqLayerDev L = layers[rd.layer];
+    const int TT = rd.T * rd.T;
+    for (int e = threadIdx.x; e < TT; e += blockDim.x) {
+        const int li = e / rd.T, lj = e - li * rd.T;
+        const int gi = rd.tm * rd.T + li, gj = rd.tn * rd.T + lj;
+        if (gi >= L.Cin || gj >= L.Cin) continue;
+        float s = 0.f;
+        for (int k = 0; k < L.S; ++k) s += L.slab[((size_t)rd.slot * L.S + k) * TT + e];
+        L.A[((size_t)rd.rx * L.Cin + gi) * L.K + (size_t)rd.ry * L.Cin + gj] += s;
+    }
+}
+
+constexpr int nPtrBatch = 224;
+struct NeqPtrBatch {
+    int base, count;
+    const float* ip[nPtrBatch];
+    float* A[nPtrBatch];
+};
+__global__ void neq_set_ptrs_kernel(NeqLayerDev* __restrict__ layers, const NeqPtrBatch b) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < b.count) {
+        layers[b.base + t].ip = b.ip[t];
+        layers[b.base + t].A = b.A[t];
+    }
+}
+
+static int g_neq_item_chunks = 112;
+
+struct NeqPlan {
+    std::vector<int64_t> key;
+    std::vector<NeqLayerDev> layers;
+    std::vector<NeqItemDev> items;
+    std::vector<NeqReduceDev> red;
+    size_t off_layers = 0, off_items = 0, off_red = 0, off_slabs = 0, total = 0, lds = 0;
+    double flops = 0, bytes = 0;
+    bool uploaded = false;
+};
+static NeqPlan g_nplan;
+static std::mutex g_nplan_mu;
+static size_t nalign(size_t v) { return (v + 255) / 256 * 256; }
+
+static int build_neq_plan(NeqPlan& P, const pleas_neq_layer* ly, int n) {
+    P.layers.assign(n, NeqLayerDev());
+    P.items.clear();
+    P.red.clear();
+    P.flops = P.bytes = 0;
+    P.lds = 0;
+    std::vector<size_t> slab_off(n, 0);
+    size_t slabs = 0;
+    struct Work { double w; NeqItemDev it; };
+    std::vector<Work> work;
+    for (int i = 0; i < n; ++i) {
+        const pleas_neq_layer& l = ly[i];
+        if (l.N <= 0 || l.Cin <= 0 || l.Hin <= 0 || l.Win <= 0 || l.KH <= 0 || l.KW <= 0 || l.stride <= 0 || l.pad < 0)
+            return bad_arg("normal_eq: layer geometry");
+        const int Hout = (l.Hin + 2 * l.pad - l.KH) / l.stride + 1, Wout = (l.Win + 2 * l.pad - l.KW) / l.stride + 1;
+        if (Hout <= 0 || Wout <= 0) return bad_arg("normal_eq: empty output");
+        const int64_t HWo = (int64_t)Hout * Wout, K = (int64_t)l.N * HWo;
+        if (K >= (1ll << 31)) return bad_arg("normal_eq: N*Hout*Wout must be < 2^31");
+        NeqLayerDev& d = P.layers[i];
+        d.Cin = l.Cin; d.Hin = l.Hin; d.Win = l.Win; d.Hout = Hout; d.Wout = Wout;
+        d.KH = l.KH; d.KW = l.KW; d.stride = l.stride; d.pad = l.pad;
+        d.HWo = (uint32_t)HWo;
+        d.Ktot = (uint32_t)K;
+        const int R = l.KH * l.KW;
+        d.K = R * l.Cin;
+        const int T = l.Cin > 64 ? 128 : 64;
+        const bool direct = R == 1 && l.stride == 1 && l.pad == 0;
+        const bool vec = direct && HWo % 4 == 0;
+        d.variant = (T == 64 ? 1 : 0) | (vec ? 0 : 2) | (direct ? 0 : 4);
+        const int nchunks = (int)ceil_div(K, nBK);
+        const int S = (int)ceil_div(nchunks, g_neq_item_chunks);
+        const int cps = (int)ceil_div(nchunks, S);
+        d.S = S;
+        P.lds = std::max(P.lds, (size_t)4 * T * nLds * sizeof(float));
+        const int tiles = (int)ceil_div(l.Cin, T);
+        int slot = 0;
+        slab_off[i] = slabs;
+        for (int rx = 0; rx < R; ++rx)
+            for (int tm = 0; tm < tiles; ++tm)
+                for (int ry = 0; ry < R; ++ry)
+                    for (int tn = 0; tn < tiles; ++tn) {
+                        if (ry * tiles + tn > rx * tiles + tm) continue;  // lower triangle of block tiles only
+                        for (int s = 0; s < S; ++s) {
+                            Work w;
+                            w.it = NeqItemDev{i, tm, tn, rx, ry, s, s * cps, std::min((s + 1) * cps, nchunks), slot, 0};
+                            w.w = (double)(w.it.c_end - w.it.c_begin) * T * T;
+                            work.push_back(w);
+                        }
+                        if (S > 1) P.red.push_back(NeqReduceDev{i, tm, tn, rx, ry, slot, T, 0});
+                        ++slot;
+                    }
+        if (S > 1) slabs += (size_t)slot * S * T * T;
+        P.flops += (double)d.K * d.K * (double)K;  // lower triangle: half of 2 K^2 P
+        P.bytes += (double)l.Cin * l.N * l.Hin * l.Win * sizeof(float);
+    }
+    std::stable_sort(work.begin(), work.end(), [](const Work& a, const Work& b) { return a.w > b.w; });
+    P.items.reserve(work.size());
+    for (auto& w : work) P.items.push_back(w.it);
+    size_t off = 0;
+    P.off_layers = off;
+    off = nalign(off + P.layers.size() * sizeof(NeqLayerDev));
+    P.off_items = off;
+    off = nalign(off + P.items.size() * sizeof(NeqItemDev));
+    P.off_red = off;
+    off = nalign(off + P.red.size() * sizeof(NeqReduceDev));
+    P.off_slabs = off;
+    P.total = off + slabs * sizeof(float);
+    for (int i = 0; i < n; ++i) P.layers[i].slab = reinterpret_cast<float*>(slab_off[i]);
+    P.uploaded = false;
+    return PLEAS_OK;
+}
+
+}  // namespace pleas
+
+using namespace pleas;
+
+extern "C" size_t pleas_normal_eq_ws_bytes(const pleas_neq_layer* layers, int n_layers) {
+    if (!layers || n_layers <= 0) return 0;
+    NeqPlan tmp;
+    if (build_neq_plan(tmp, layers, n_layers) != PLEAS_OK) return 0;
+    return tmp.total;
+}
+
+extern "C" int pleas_normal_eq_accum(const pleas_neq_layer* layers, int n_layers, void* ws, size_t ws_bytes, int ws_fresh,
+                                     void* stream_) {
+    if (!layers || n_layers <= 0) return bad_arg("normal_eq: empty layer list");
+    for (int i = 0; i < n_layers; ++i) {
+        if (!layers[i].ip || !layers[i].A) return bad_arg("normal_eq: null pointer");
+        if (((uintptr_t)layers[i].ip & 15) != 0) return bad_arg("normal_eq: 16-byte alignment");
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    std::lock_guard<std::mutex> lk(g_nplan_mu);
+    NeqPlan& P = g_nplan;
+    std::vector<int64_t> key;
+    key.push_back(n_layers);
+    key.push_back((int64_t)(uintptr_t)ws);
+    key.push_back(g_neq_item_chunks);
+    for (int i = 0; i < n_layers; ++i)
+        for (int v : {layers[i].N, layers[i].Cin, layers[i].Hin, layers[i].Win, layers[i].KH, layers[i].KW, layers[i].stride,
+                      layers[i].pad})
+            key.push_back(v);
+    if (key != P.key) {
+        const int rc = build_neq_plan(P, layers, n_layers);
+        if (rc != PLEAS_OK) return rc;
+        P.key.swap(key);
+    }
+    if (ws_fresh) P.uploaded = false;
+    if (!ws || ws_bytes < P.total) {
+        std::snprintf(g_last_error, sizeof(g_last_error), "normal_eq workspace too small: need %zu bytes", P.total);
+        P.key.clear();
+        return PLEAS_ENOMEM;
+    }
+    char* base = (char*)ws;
+    if (!P.uploaded) {
+        float* slab0 = reinterpret_cast<float*>(base + P.off_slabs);
+        std::vector<NeqLayerDev> abs_layers = P.layers;
+        for (auto& d : abs_layers) d.slab = slab0 + reinterpret_cast<size_t>(d.slab);
+        PLEAS_HIP_CHECK(hipMemcpyAsync(base + P.off_layers, abs_layers.data(), abs_layers.size() * sizeof(NeqLayerDev),
+                                       hipMemcpyHostToDevice, stream));
+        PLEAS_HIP_CHECK(hipMemcpyAsync(base + P.off_items, P.items.data(), P.items.size() * sizeof(NeqItemDev),
+                                       hipMemcpyHostToDevice, stream));
+        if (!P.red.empty())
+            PLEAS_HIP_CHECK(hipMemcpyAsync(base + P.off_red, P.red.data(), P.red.size() * sizeof(NeqReduceDev),
+                                           hipMemcpyHostToDevice, stream));
+        PLEAS_HIP_CHECK(hipStreamSynchronize(stream));
+        P.uploaded = true;
+    }
+    NeqLayerDev* dl = reinterpret_cast<NeqLayerDev*>(base + P.off_layers);
+    for (int b0 = 0; b0 < n_layers; b0 += nPtrBatch) {
+        NeqPtrBatch pb;
+        pb.base = b0;
+        pb.count = std::min(nPtrBatch, n_layers - b0);
+        for (int t = 0; t < pb.count; ++t) {
+            pb.ip[t] = layers[b0 + t].ip;
+            pb.A[t] = layers[b0 + t].A;
+        }
+        hipLaunchKernelGGL(neq_set_ptrs_kernel, dim3(1), dim3(256), 0, stream, dl, pb);
+        PLEAS_LAUNCH_CHECK("neq_set_ptrs_kernel");
+    }
+    ProfScope prof(kProfNormalEq, P.flops, P.bytes, stream);
+    hipLaunchKernelGGL(neq_batch_kernel, dim3((unsigned)P.items.size()), dim3(nThreads), P.lds, stream, dl,
+                       reinterpret_cast<const NeqItemDev*>(base + P.off_items));
+    PLEAS_LAUNCH_CHECK("neq_batch_kernel");
+    if (!P.red.empty()) {
+        hipLaunchKernelGGL(neq_reduce_kernel, dim3((unsigned)P.red.size()), dim3(256), 0, stream, dl,
+                           reinterpret_cast<const NeqReduceDev*>(base + P.off_red));
+        PLEAS_LAUNCH_CHECK("neq_reduce_kernel");
+    }
+    return PLEAS_OK;
+}

@@ -293,14 +293,16 @@ class WgradBatch:
         self._arr = None
         self._ws = None
 
+    ACCUMULATE, KPOS_MAJOR = 1, 2
+
     def add(self, resid: torch.Tensor, ip: torch.Tensor, grad: torch.Tensor, kernel=(1, 1), stride: int = 1,
-            pad: int = 0) -> None:
+            pad: int = 0, flags: int = 0) -> None:
         if not (resid.is_contiguous() and ip.is_contiguous() and grad.is_contiguous()):
             raise PleasHipError("WgradBatch.add: contiguous tensors expected")
         N, Cout, Cin = resid.shape[0], resid.shape[1], ip.shape[1]
         Hin, Win = (ip.shape[2], ip.shape[3]) if ip.dim() == 4 else (1, 1)
         self._keep.append((resid, ip, grad))
-        self._geo.append((N, Cout, Cin, Hin, Win, kernel[0], kernel[1], stride, pad))
+        self._geo.append((N, Cout, Cin, Hin, Win, kernel[0], kernel[1], stride, pad, flags))
 
     def flush(self) -> None:
         n = len(self._keep)
@@ -311,7 +313,7 @@ class WgradBatch:
         for i, ((resid, ip, grad), geo) in enumerate(zip(self._keep, self._geo)):
             a = self._arr[i]
             a.resid, a.ip, a.grad = resid.data_ptr(), ip.data_ptr(), grad.data_ptr()
-            a.N, a.Cout, a.Cin, a.Hin, a.Win, a.KH, a.KW, a.stride, a.pad = geo
+            a.N, a.Cout, a.Cin, a.Hin, a.Win, a.KH, a.KW, a.stride, a.pad, a.flags = geo
         lib = _lib.lib()
         if self._ws is None:
             need = int(lib.pleas_wgrad_batch_ws_bytes(self._arr, n))
@@ -326,6 +328,56 @@ class WgradBatch:
             self.flush()
             return
         check(rc, "pleas_wgrad_batch")
+        self._keep.clear()
+        self._geo.clear()
+
+
+class NormalEqBatch:
+    """A_l += U_l^T U_l for all layers of one batch in ONE grouped launch (``pleas_normal_eq_accum``)."""
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self._keep: list = []
+        self._geo: list = []
+        self._arr = None
+        self._ws = None
+        self._fresh = 1
+
+    def add(self, ip: torch.Tensor, A: torch.Tensor, kernel=(1, 1), stride: int = 1, pad: int = 0) -> None:
+        if not (ip.is_contiguous() and A.is_contiguous()):
+            raise PleasHipError("NormalEqBatch.add: contiguous tensors expected")
+        N, Cin = ip.shape[0], ip.shape[1]
+        Hin, Win = (ip.shape[2], ip.shape[3]) if ip.dim() == 4 else (1, 1)
+        K = kernel[0] * kernel[1] * Cin
+        if tuple(A.shape) != (K, K):
+            raise PleasHipError("NormalEqBatch.add: A must be (%d, %d)" % (K, K))
+        self._keep.append((ip, A))
+        self._geo.append((N, Cin, Hin, Win, kernel[0], kernel[1], stride, pad))
+
+    def flush(self) -> None:
+        n = len(self._keep)
+        if n == 0:
+            return
+        if self._arr is None or len(self._arr) != n:
+            self._arr = (_lib.NeqLayer * n)()
+        for i, ((ip, A), geo) in enumerate(zip(self._keep, self._geo)):
+            a = self._arr[i]
+            a.ip, a.A = ip.data_ptr(), A.data_ptr()
+            a.N, a.Cin, a.Hin, a.Win, a.KH, a.KW, a.stride, a.pad = geo
+        lib = _lib.lib()
+        if self._ws is None:
+            need = int(lib.pleas_normal_eq_ws_bytes(self._arr, n))
+            if need == 0:
+                raise PleasHipError("pleas_normal_eq_ws_bytes rejected the layer list: %s" % lib.pleas_last_error().decode())
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._fresh = 1
+        rc = lib.pleas_normal_eq_accum(self._arr, n, self._ws.data_ptr(), self._ws.numel(), self._fresh, _stream())
+        self._fresh = 0
+        if rc == -12:
+            self._ws = None
+            self.flush()
+            return
+        check(rc, "pleas_normal_eq_accum")
         self._keep.clear()
         self._geo.clear()
 

@@ -1,0 +1,199 @@
+"""Closed-form PLeaS: per-layer normal equations accumulated on the GPU, then one solve per layer.
+
+``train(..., solver="normal_eq")``.  The reference fits every merged Conv2d/Linear layer L by Adam on
+``mean((L(ip) - op)^2)`` (pleas/methods/pleas_merging.py:281-291, :357-358); the minimiser of the
+same objective summed over the batches is ``W^T = A^-1 B`` with ``U = im2col(ip)``,
+``A = sum U^T U`` and ``B = sum U^T op``.  (With equal batch sizes the per-batch ``mean`` only
+rescales the objective.)  Frozen entries of the reference's gradient mask (:57-58) stay at their
+initial value and move to the right-hand side.
+
+MI355X design: per batch, ONE grouped fp32-MFMA launch accumulates ``U^T U`` of every layer
+(``pleas_normal_eq_accum``: lower-triangular block tiles, im2col never materialised) and ONE adds
+``op . U`` (``pleas_wgrad_batch`` with ACCUMULATE | KPOS_MAJOR).  All ``A`` (and all ``B``) live in one
+flat fp32 arena, so a multi-GPU run shards whole batches over ranks and all-reduces each arena ONCE
+before the solve.  The K x K solves (3.8e11 flop in total for ResNet-101, 0.1 % of the accumulation
+work) use the vendor Cholesky through torch.linalg in this round (own blocked Cholesky: DESIGN.md, next).
+"""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .pleas_merging import PleasFitter, _LayerPlan
+
+
+class NormalEqFitter(PleasFitter):
+    """Accumulates A and B^T for every merged layer; ``solve`` writes the closed-form weights."""
+
+    def __init__(self, *args, ridge: float = 1e-6, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.ridge = ridge
+        dev = self.device
+        self.K: List[int] = []
+        for plan in self.plans:
+            w = plan.w_shape
+            self.K.append(int(w[1] * (w[2] * w[3] if len(w) == 4 else 1)))
+        self.A_flat = torch.zeros(sum(k * k for k in self.K), dtype=torch.float32, device=dev)
+        self.B_flat = torch.zeros(sum(k * p.w_shape[0] for k, p in zip(self.K, self.plans)), dtype=torch.float32, device=dev)
+        self.A: List[torch.Tensor] = []
+        self.Bt: List[torch.Tensor] = []   # [Cout][K] with kernel-position-major columns
+        oa = ob = 0
+        for k, plan in zip(self.K, self.plans):
+            self.A.append(self.A_flat[oa:oa + k * k].view(k, k))
+            oa += k * k
+            co = plan.w_shape[0]
+            self.Bt.append(self.B_flat[ob:ob + co * k].view(co, k))
+            ob += co * k
+        # bias columns (Linear layers): column sums of U, of op, and the row count
+        self.bias_stats: Dict[int, List[torch.Tensor]] = {
+            i: [torch.zeros(self.K[i], device=dev), torch.zeros(p.w_shape[0], device=dev), torch.zeros(1, device=dev)]
+            for i, p in enumerate(self.plans) if p.b is not None}
+        self.neq = self.ops.NormalEqBatch(dev)
+        self.batches_seen = 0
+
+    def _hip_geometry_ok(self, plan: _LayerPlan, ip: torch.Tensor) -> bool:
+        mod = plan.mod
+        if not plan.is_conv:
+            return ip.dim() == 2
+        return (mod.groups == 1 and mod.dilation == (1, 1) and mod.stride[0] == mod.stride[1]
+                and mod.padding[0] == mod.padding[1] and ip.shape[1] >= 16)
+
+    @torch.no_grad()
+    def step(self, x: torch.Tensor) -> None:
+        """Accumulate one batch (no parameter update)."""
+        ops = self.ops
+        x = x.to(self.device, non_blocking=True)
+        self.model1(x)
+        self.model2(x)
+        KP = ops.WgradBatch.ACCUMULATE | ops.WgradBatch.KPOS_MAJOR
+        for idx, plan in enumerate(self.plans):
+            name = plan.name
+            if name not in self.tap1.inputs or name not in self.tap2.inputs:
+                print("Key error on %s" % name)
+                continue
+            ip = ops.merge_blocks(self.tap1.inputs[name], self.tap2.inputs[name], 1, *plan.in_maps)
+            op = ops.merge_blocks(self.tap1.outputs[name], self.tap2.outputs[name], 1, *plan.out_maps)
+            mod = plan.mod
+            if self._hip_geometry_ok(plan, ip):
+                if plan.is_conv:
+                    geo = (tuple(mod.kernel_size), mod.stride[0], mod.padding[0])
+                    self.neq.add(ip, self.A[idx], *geo)
+                    self.wgrad.add(op, ip, self.Bt[idx], *geo, flags=KP)
+                else:
+                    self.neq.add(ip, self.A[idx])
+                    self.wgrad.add(op, ip, self.Bt[idx], flags=KP)
+            else:  # stem (3 input channels) / exotic geometry: tiny K, vendor GEMM on an explicit im2col
+                U = F.unfold(ip, mod.kernel_size, mod.dilation, mod.padding, mod.stride)      # B, (ci,kh,kw), L
+                cin, r = ip.shape[1], mod.kernel_size[0] * mod.kernel_size[1]
+                U = U.view(U.shape[0], cin, r, -1).permute(0, 3, 2, 1).reshape(-1, r * cin)    # rows x (r, ci)
+                Y = op.reshape(op.shape[0], op.shape[1], -1).permute(0, 2, 1).reshape(-1, op.shape[1])
+                self.A[idx].addmm_(U.t(), U)
+                self.Bt[idx].addmm_(Y.t(), U)
+            if plan.b is not None:
+                s = self.bias_stats[idx]
+                rows_u = ip.reshape(-1, ip.shape[-1]) if not plan.is_conv else None
+                if rows_u is None:
+                    raise NotImplementedError("normal_eq: conv layers with bias")
+                s[0].add_(rows_u.sum(0))
+                s[1].add_(op.reshape(-1, op.shape[-1]).sum(0))
+                s[2].add_(float(rows_u.shape[0]))
+        self.neq.flush()
+        self.wgrad.flush()
+        self.batches_seen += 1
+        self.tap1.clear()
+        self.tap2.clear()
+
+    @torch.no_grad()
+    def solve(self) -> Dict[str, float]:
+        """Closed-form weights for every layer -> the parameter arena.  Returns per-layer info."""
+        from .pleas_merging import dp_sum_
+
+        dp_sum_(self.A_flat, self.world)
+        dp_sum_(self.B_flat, self.world)
+        for s in self.bias_stats.values():
+            for t in s:
+                dp_sum_(t, self.world)
+        info: Dict[str, float] = {}
+        off = 0
+        for idx, plan in enumerate(self.plans):
+            K, co = self.K[idx], plan.w_shape[0]
+            A = self.A[idx]
+            A = torch.tril(A) + torch.tril(A, -1).t()          # kernels fill the lower triangle only
+            Bt = self.Bt[idx]
+            if len(plan.w_shape) == 4:
+                cin, r = plan.w_shape[1], plan.w_shape[2] * plan.w_shape[3]
+                to_kpos = lambda t: t.reshape(co, cin, r).permute(0, 2, 1).reshape(co, K)
+                from_kpos = lambda t: t.reshape(co, r, cin).permute(0, 2, 1).reshape(plan.w_shape)
+            else:
+                to_kpos = lambda t: t.reshape(co, K)
+                from_kpos = lambda t: t.reshape(plan.w_shape)
+            n_w = plan.w.numel()
+            mask = to_kpos(self.mask[off:off + n_w])
+            w0 = to_kpos(plan.w)
+            if plan.b is not None:                             # augmented system for the bias column
+                su, sy, m = self.bias_stats[idx]
+                A = torch.cat([torch.cat([A, su[:, None]], 1), torch.cat([su[None, :], m.view(1, 1)], 1)], 0)
+                Bt = torch.cat([Bt, sy[:, None]], 1)
+                mask = torch.cat([mask, torch.ones(co, 1, device=mask.device)], 1)
+                w0 = torch.cat([w0, plan.b[:, None]], 1)
+            W = w0.clone()
+            patterns, inverse = torch.unique(mask > 0.5, dim=0, return_inverse=True)
+            for p in range(patterns.shape[0]):
+                rows = (inverse == p).nonzero().flatten()
+                free = patterns[p].nonzero().flatten()
+                if free.numel() == 0:
+                    continue
+                frozen = (~patterns[p]).nonzero().flatten()
+                Aff = A.index_select(0, free).index_select(1, free)
+                rhs = Bt.index_select(0, rows).index_select(1, free)
+                if frozen.numel():
+                    Afz = A.index_select(0, free).index_select(1, frozen)
+                    rhs = rhs - w0.index_select(0, rows).index_select(1, frozen) @ Afz.t()
+                sol = _spd_solve(Aff, rhs.t(), self.ridge)     # (F, rows)
+                W[rows[:, None], free[None, :]] = sol.t()
+            if plan.b is not None:
+                plan.b.copy_(W[:, -1])
+                W = W[:, :-1]
+            plan.w.copy_(from_kpos(W.contiguous()))
+            info[plan.name] = float(K)
+            off += n_w + (plan.b.numel() if plan.b is not None else 0)
+        return info
+
+
+def _spd_solve(A: torch.Tensor, rhs: torch.Tensor, ridge: float) -> torch.Tensor:
+    """Solve (A + ridge * mean(diag A) * I) X = rhs by Cholesky; falls back to fp64 if fp32 breaks down."""
+    lam = ridge * float(A.diagonal().mean())
+    A = A + lam * torch.eye(A.shape[0], device=A.device, dtype=A.dtype)
+    L, bad = torch.linalg.cholesky_ex(A)
+    if int(bad) != 0:
+        A64 = A.double()
+        L64, bad64 = torch.linalg.cholesky_ex(A64)
+        if int(bad64) != 0:
+            return torch.linalg.lstsq(A64, rhs.double()).solution.float()
+        return torch.cholesky_solve(rhs.double(), L64).float()
+    return torch.cholesky_solve(rhs, L)
+
+
+def train_normal_eq(dataloader, model1, model2, model3, spec, perm, costs, budget_ratios, MAX_STEPS, separate_classifier,
+                    num_classes, model_type, verbose, ridge: float = 1e-6):
+    """Same data consumption as the Adam loop (``MAX_STEPS + 1`` batches of one pass, reference :368-373);
+    with ``torch.distributed`` initialised, rank r accumulates batches ``b % world == r``."""
+    from .activation_matching import _dist_info
+
+    fit = NormalEqFitter(model1, model2, model3, spec, perm, costs, budget_ratios, MAX_STEPS, 5e-4, separate_classifier,
+                         num_classes, model_type, ridge=ridge)
+    fit.rank, fit.world = _dist_info()
+    for idx, batch in enumerate(dataloader):
+        if idx > MAX_STEPS:
+            break
+        if idx % fit.world != fit.rank:
+            continue
+        x, _ = batch
+        fit.step(x)
+        if verbose:
+            print("normal_eq: accumulated batch %d" % idx)
+    fit.solve()
+    return fit.finish()

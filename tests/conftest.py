@@ -12,8 +12,26 @@ if REPO not in sys.path:
 GOLDEN = os.path.join(REPO, "tests", "golden")
 
 
+def _usable_cores():
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the GPU box reports every socket core but grants a small CPU share: without this the CPU oracle
+    # runs hundreds of threads on a few cores and crawls
+    torch.set_num_threads(max(1, min(8, _usable_cores())))
 
 
 def pytest_collection_modifyitems(config, items):

@@ -314,3 +314,57 @@ def test_target_residual_and_loss(ops):
     ops.loss_final(parts, torch.tensor([0, cnt], dtype=torch.int32, device="cuda"),
                    torch.tensor([1.0, 1.0 / n], device="cuda"), loss)
     assert float(loss[0]) == 0.0 and abs(float(loss[1]) - float(((out - target) ** 2).mean())) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------ normal equations
+NEQ_CASES = [
+    # N, Cin, H, W, k, stride, pad
+    (4, 64, 14, 14, 1, 1, 0),      # direct loader, one 64-tile
+    (4, 200, 14, 14, 1, 1, 0),     # 2x2 block tiles, ragged
+    (3, 40, 7, 7, 1, 1, 0),        # HW = 49 scalar loads
+    (4, 48, 10, 10, 3, 1, 1),      # 3x3 shifted loader: 9x9 blocks of kernel positions
+    (2, 130, 12, 12, 3, 2, 1),     # stride 2, two tiles per position
+    (2, 64, 56, 56, 1, 1, 0),      # long pixel axis -> slabs + reduce
+    (16, 96, 1, 1, 1, 1, 0),       # linear-like
+]
+
+
+@pytest.mark.parametrize("N,Cin,H,W,k,stride,pad", NEQ_CASES)
+def test_normal_eq_accum_matches_unfold(ops, N, Cin, H, W, k, stride, pad):
+    import torch.nn.functional as F
+
+    g = torch.Generator().manual_seed(N + Cin + k)
+    K = k * k * Cin
+    A = torch.zeros(K, K, device="cuda")
+    batch = ops.NormalEqBatch(torch.device("cuda"))
+    want = torch.zeros(K, K, dtype=torch.float64)
+    for rep in range(2):  # accumulates over batches
+        ip = torch.randn(N, Cin, H, W, generator=g)
+        U = F.unfold(ip.double(), k, 1, pad, stride)                                   # N, (ci, r), L
+        U = U.view(N, Cin, k * k, -1).permute(0, 3, 2, 1).reshape(-1, K)               # rows x (r, ci)
+        want += U.t() @ U
+        batch.add(ip.cuda(), A, (k, k), stride, pad)
+        batch.flush()
+    got = A.cpu().double()
+    T = 128 if Cin > 64 else 64
+    tiles = -(-Cin // T)
+    blk = lambda idx: (idx // Cin) * tiles + (idx % Cin) // T                      # block-tile index of a row/col
+    rows = torch.arange(K)
+    lower = blk(rows)[:, None] >= blk(rows)[None, :]
+    assert _rel(got[lower], want[lower]) < 3e-6
+    assert (got[~lower] == 0).all()                                                    # strict upper tiles untouched
+
+
+def test_wgrad_accumulate_kpos_major(ops):
+    g = torch.Generator().manual_seed(9)
+    ip, resid = torch.randn(4, 40, 9, 9, generator=g), torch.randn(4, 24, 9, 9, generator=g)
+    w = torch.zeros(24, 40, 3, 3)
+    want = torch.ops.aten.convolution_backward(resid.double(), ip.double(), w.double(), None, [1, 1], [1, 1], [1, 1], False,
+                                               [0, 0], 1, [False, True, False])[1]
+    out = torch.ones(24, 9 * 40, device="cuda")
+    batch = ops.WgradBatch(torch.device("cuda"))
+    for _ in range(2):
+        batch.add(resid.cuda(), ip.cuda(), out, (3, 3), 1, 1, flags=ops.WgradBatch.ACCUMULATE | ops.WgradBatch.KPOS_MAJOR)
+        batch.flush()
+    ref = 1 + 2 * want.reshape(24, 40, 9).permute(0, 2, 1).reshape(24, 360)
+    assert _rel(out.cpu(), ref) < 3e-6

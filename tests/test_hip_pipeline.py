@@ -182,3 +182,77 @@ def test_grouped_equals_per_node_launches(tiny_bottleneck):
     pb, cb = activation_matching(t.spec, m1, m2, t.batches(), 3, output_costs=True, grouped=False)
     for k in t.spec:
         assert _rel(ca[k], cb[k]) < 1e-6 and (pa[k] == pb[k]).all()
+
+
+def _layer_objective(t, m3, ratio, perm, costs, batches):
+    """Reference objective sum_layers mean((L(ip) - op)^2) summed over batches, on the CPU oracle."""
+    blocks = orc.spread_blocks(t.spec, orc.get_blocks(t.spec, perm, costs, ratio))
+    a1, a2 = {}, {}
+    h = orc._hook_inputs(t.m1, a1) + orc._hook_inputs(t.m2, a2)
+    total = 0.0
+    with torch.no_grad():
+        for x, _ in batches:
+            t.m1(x)
+            t.m2(x)
+            for name, layer in m3.named_modules():
+                if isinstance(layer, (torch.nn.Conv2d, torch.nn.Linear)):
+                    ip, op = orc.layer_targets(orc.get_attr(t.m1, name.split(".")), orc.get_attr(t.m2, name.split(".")),
+                                               blocks, name, a1[name], a2[name], num_classes=10)
+                    total += float(((layer(ip) - op) ** 2).mean())
+    for hh in h:
+        hh.remove()
+    return total
+
+
+@pytest.mark.parametrize("ratio", [0.0, 0.5])
+def test_train_normal_eq_minimises_the_reference_objective(tiny_basic, ratio):
+    from pleas.methods.partial_matching import partial_merge
+    from pleas.methods.pleas_merging import train
+
+    t = tiny_basic
+    perm, costs_c = t.per_key("am_perm"), t.per_key("am_cost")
+    costs = {k: v.cuda() for k, v in costs_c.items()}
+    data = t.batches("xt")[:21]
+    m1, m2 = _cuda_pair(t)
+    m3 = partial_merge(t.spec, m1, m2, perm, costs, ratio)
+    init = {k: v.clone() for k, v in m3.state_dict().items()}
+    m_adam = train(data, m1, m2, copy.deepcopy(m3), t.spec, perm, costs, ratio, False, 20, None, num_classes=10)
+    m_neq = train(data, m1, m2, m3, t.spec, perm, costs, ratio, False, 20, None, num_classes=10, solver="normal_eq")
+    f_init = _layer_objective(t, orc.partial_merge(t.spec, t.m1, t.m2, perm, costs_c, ratio), ratio, perm, costs_c, data)
+    f_adam = _layer_objective(t, m_adam.cpu(), ratio, perm, costs_c, data)
+    f_neq = _layer_objective(t, m_neq.cpu(), ratio, perm, costs_c, data)
+    assert f_neq <= f_adam * (1 + 1e-4) and f_neq < f_init, (f_init, f_adam, f_neq)
+    if ratio == 0.0:
+        # closed form of one layer against the fp64 oracle (normal equations + lstsq) on the same batches
+        name = "layer2.0.conv2"
+        layer = orc.get_attr(m_neq, name.split("."))
+        blocks = orc.spread_blocks(t.spec, orc.get_blocks(t.spec, perm, costs_c, ratio))
+        a1, a2 = {}, {}
+        h = orc._hook_inputs(t.m1, a1) + orc._hook_inputs(t.m2, a2)
+        ips, ops_ = [], []
+        with torch.no_grad():
+            for x, _ in data:
+                t.m1(x)
+                t.m2(x)
+                ip, op = orc.layer_targets(orc.get_attr(t.m1, name.split(".")), orc.get_attr(t.m2, name.split(".")), blocks,
+                                           name, a1[name], a2[name], num_classes=10)
+                ips.append(ip)
+                ops_.append(op)
+        for hh in h:
+            hh.remove()
+        A, Bm = orc.normal_equations(ips, ops_, layer)
+        want = orc.solve_normal_equations(A, Bm, ridge=1e-6).t().reshape(layer.weight.shape)
+        assert _rel(layer.weight, want.float()) < 1e-3
+    else:
+        # frozen entries (reference gradient mask) keep their initial value
+        from pleas.methods.partial_matching import get_blocks, spread_blocks
+        from pleas.methods.pleas_merging import get_gradient_mask
+
+        layers = {n: m for n, m in m_neq.named_modules() if isinstance(m, (torch.nn.Conv2d, torch.nn.Linear))}
+        masks = get_gradient_mask(spread_blocks(t.spec, get_blocks(t.spec, perm, costs_c, ratio, False)), layers)
+        k = 0
+        for n, m in layers.items():
+            for pn, p in m.named_parameters():
+                frozen = masks[k] == 0
+                assert torch.equal(p.detach().cpu()[frozen], init["%s.%s" % (n, pn)][frozen])
+                k += 1
