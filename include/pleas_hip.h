@@ -197,6 +197,17 @@ size_t pleas_normal_eq_ws_bytes(const pleas_neq_layer* layers, int n_layers);
 int pleas_normal_eq_accum(const pleas_neq_layer* layers, int n_layers, void* ws, size_t ws_bytes, int ws_fresh,
                           void* stream);
 
+/* Batched SPD solve of the normal equations (blocked Cholesky + forward/back substitution, panel 64,
+ * trailing updates on fp32 MFMA tiles).  For every problem p:  X (A_p + lambda*mean(diag A_p) I) = Bt_p,
+ * i.e. each of the N_p rows of Bt_p (length K_p) is one right-hand side and is overwritten by its
+ * solution.  A_p: K_p x K_p row-major, LOWER triangle read; overwritten (L below the diagonal, L^T
+ * above).  A, Bt, K, N: HOST arrays (of DEVICE pointers / sizes); info: DEVICE int[nprob], 0 = ok,
+ * j > 0 = pivot j not positive in fp32 (the caller should redo that problem in higher precision).
+ * Problems of different sizes share the launches: cost = 5 * max(K)/64 launches per 96 problems.
+ */
+int pleas_cholesky_solve_batched(float* const* A, float* const* Bt, const int* K, const int* N, int nprob, float lambda,
+                                 int* info, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Opt-in live timing of the library's kernels with HIP events recorded on the launch stream
  * (used by bench.py for the roofline figure; off by default, no cost when off).

@@ -41,6 +41,8 @@ SIGNATURES = {
                                       c_int64, c_float, c_void_p, c_void_p, POINTER(c_int), c_void_p]),
     "pleas_target_residual_max_partials": (c_int, []),
     "pleas_loss_final": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "pleas_cholesky_solve_batched": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int), POINTER(c_int), c_int,
+                                             c_float, c_void_p, c_void_p]),
     "pleas_normal_eq_ws_bytes": (c_size_t, [c_void_p, c_int]),
     "pleas_normal_eq_accum": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "pleas_wgrad_batch_ws_bytes": (c_size_t, [c_void_p, c_int]),

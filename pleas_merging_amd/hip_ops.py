@@ -382,6 +382,26 @@ class NormalEqBatch:
         self._geo.clear()
 
 
+def cholesky_solve_batched(As: Sequence[torch.Tensor], Bts: Sequence[torch.Tensor], ridge: float = 0.0) -> torch.Tensor:
+    """In place: every row of ``Bts[p]`` (N_p x K_p) becomes the solution of ``x (A_p + ridge*mean(diag) I) = row``.
+    ``As[p]`` (K_p x K_p, lower triangle read) is overwritten by its Cholesky factor.  Returns the device info vector."""
+    k = len(As)
+    if k == 0:
+        return torch.zeros(0, dtype=torch.int32)
+    _need_gpu(*As, *Bts)
+    for a, b in zip(As, Bts):
+        if a.dim() != 2 or a.shape[0] != a.shape[1] or b.dim() != 2 or b.shape[1] != a.shape[0] or not a.is_contiguous() \
+                or not b.is_contiguous():
+            raise PleasHipError("cholesky_solve_batched: A must be (K, K), Bt (N, K), both contiguous")
+    info = torch.zeros(k, dtype=torch.int32, device=As[0].device)
+    rc = _lib.lib().pleas_cholesky_solve_batched(
+        (ctypes.c_void_p * k)(*[a.data_ptr() for a in As]), (ctypes.c_void_p * k)(*[b.data_ptr() for b in Bts]),
+        (ctypes.c_int * k)(*[a.shape[0] for a in As]), (ctypes.c_int * k)(*[b.shape[0] for b in Bts]), k, float(ridge),
+        info.data_ptr(), _stream())
+    check(rc, "pleas_cholesky_solve_batched")
+    return info
+
+
 # ---------------------------------------------------------------------------------------- live kernel timing
 def profile_enable(on: bool) -> None:
     _lib.lib().pleas_prof_enable(int(bool(on)))

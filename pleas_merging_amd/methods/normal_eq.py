@@ -11,8 +11,9 @@ MI355X design: per batch, ONE grouped fp32-MFMA launch accumulates ``U^T U`` of 
 (``pleas_normal_eq_accum``: lower-triangular block tiles, im2col never materialised) and ONE adds
 ``op . U`` (``pleas_wgrad_batch`` with ACCUMULATE | KPOS_MAJOR).  All ``A`` (and all ``B``) live in one
 flat fp32 arena, so a multi-GPU run shards whole batches over ranks and all-reduces each arena ONCE
-before the solve.  The K x K solves (3.8e11 flop in total for ResNet-101, 0.1 % of the accumulation
-work) use the vendor Cholesky through torch.linalg in this round (own blocked Cholesky: DESIGN.md, next).
+before the solve.  The K x K systems of all layers (and mask patterns) are solved by ONE batched call of
+the HIP blocked Cholesky (``pleas_cholesky_solve_batched``); a system whose fp32 factorisation hits a
+non-positive pivot is redone in fp64 on the vendor solver and counted in ``info["fp64_fallbacks"]``.
 """
 from __future__ import annotations
 
@@ -118,6 +119,7 @@ class NormalEqFitter(PleasFitter):
                 dp_sum_(t, self.world)
         info: Dict[str, float] = {}
         off = 0
+        jobs, finals = [], []   # (W, rows, free, A_FF, rhs, A_FF backup) per solve; (plan, W, layout) per layer
         for idx, plan in enumerate(self.plans):
             K, co = self.K[idx], plan.w_shape[0]
             A = self.A[idx]
@@ -125,11 +127,12 @@ class NormalEqFitter(PleasFitter):
             Bt = self.Bt[idx]
             if len(plan.w_shape) == 4:
                 cin, r = plan.w_shape[1], plan.w_shape[2] * plan.w_shape[3]
-                to_kpos = lambda t: t.reshape(co, cin, r).permute(0, 2, 1).reshape(co, K)
-                from_kpos = lambda t: t.reshape(co, r, cin).permute(0, 2, 1).reshape(plan.w_shape)
+                to_kpos = lambda t, co=co, cin=cin, r=r, K=K: t.reshape(co, cin, r).permute(0, 2, 1).reshape(co, K)
+                from_kpos = lambda t, co=co, cin=cin, r=r, shp=plan.w_shape: \
+                    t.reshape(co, r, cin).permute(0, 2, 1).reshape(shp)
             else:
-                to_kpos = lambda t: t.reshape(co, K)
-                from_kpos = lambda t: t.reshape(plan.w_shape)
+                to_kpos = lambda t, co=co, K=K: t.reshape(co, K)
+                from_kpos = lambda t, shp=plan.w_shape: t.reshape(shp)
             n_w = plan.w.numel()
             mask = to_kpos(self.mask[off:off + n_w])
             w0 = to_kpos(plan.w)
@@ -147,34 +150,41 @@ class NormalEqFitter(PleasFitter):
                 if free.numel() == 0:
                     continue
                 frozen = (~patterns[p]).nonzero().flatten()
-                Aff = A.index_select(0, free).index_select(1, free)
-                rhs = Bt.index_select(0, rows).index_select(1, free)
+                whole = frozen.numel() == 0
+                Aff = A.clone() if whole else A.index_select(0, free).index_select(1, free).contiguous()
+                rhs = Bt.index_select(0, rows) if whole else Bt.index_select(0, rows).index_select(1, free)
                 if frozen.numel():
                     Afz = A.index_select(0, free).index_select(1, frozen)
                     rhs = rhs - w0.index_select(0, rows).index_select(1, frozen) @ Afz.t()
-                sol = _spd_solve(Aff, rhs.t(), self.ridge)     # (F, rows)
-                W[rows[:, None], free[None, :]] = sol.t()
+                jobs.append((W, rows, free, Aff, rhs.contiguous(), Aff.clone()))  # last: untouched copy for a fallback
+            finals.append((plan, W, from_kpos))
+            info[plan.name] = float(K)
+            off += n_w + (plan.b.numel() if plan.b is not None else 0)
+        # ONE batched HIP launch sequence solves every (layer, mask pattern) system
+        rhs_orig = [j[4].clone() for j in jobs]
+        flags = self.ops.cholesky_solve_batched([j[3] for j in jobs], [j[4] for j in jobs], ridge=self.ridge).cpu()
+        for (W, rows, free, _, sol, A_orig), rhs0, bad in zip(jobs, rhs_orig, flags.tolist()):
+            if bad:  # fp32 Cholesky broke down (ill-conditioned A): redo this one system in fp64 on the vendor solver
+                info["fp64_fallbacks"] = info.get("fp64_fallbacks", 0.0) + 1.0
+                sol = _spd_solve_fp64(A_orig, rhs0, self.ridge)
+            W[rows[:, None], free[None, :]] = sol
+        for plan, W, from_kpos in finals:
             if plan.b is not None:
                 plan.b.copy_(W[:, -1])
                 W = W[:, :-1]
             plan.w.copy_(from_kpos(W.contiguous()))
-            info[plan.name] = float(K)
-            off += n_w + (plan.b.numel() if plan.b is not None else 0)
         return info
 
 
-def _spd_solve(A: torch.Tensor, rhs: torch.Tensor, ridge: float) -> torch.Tensor:
-    """Solve (A + ridge * mean(diag A) * I) X = rhs by Cholesky; falls back to fp64 if fp32 breaks down."""
-    lam = ridge * float(A.diagonal().mean())
-    A = A + lam * torch.eye(A.shape[0], device=A.device, dtype=A.dtype)
-    L, bad = torch.linalg.cholesky_ex(A)
+def _spd_solve_fp64(A: torch.Tensor, rhs_rows: torch.Tensor, ridge: float) -> torch.Tensor:
+    """Rows x of ``x (A + ridge*mean(diag A) I) = rhs_row`` in fp64 (fallback when the fp32 HIP Cholesky flags a
+    non-positive pivot)."""
+    A64 = A.double()
+    A64 = A64 + ridge * A64.diagonal().mean() * torch.eye(A64.shape[0], device=A.device, dtype=torch.float64)
+    L, bad = torch.linalg.cholesky_ex(A64)
     if int(bad) != 0:
-        A64 = A.double()
-        L64, bad64 = torch.linalg.cholesky_ex(A64)
-        if int(bad64) != 0:
-            return torch.linalg.lstsq(A64, rhs.double()).solution.float()
-        return torch.cholesky_solve(rhs.double(), L64).float()
-    return torch.cholesky_solve(rhs, L)
+        return torch.linalg.lstsq(A64, rhs_rows.double().t()).solution.t().float()
+    return torch.cholesky_solve(rhs_rows.double().t(), L).t().float()
 
 
 def train_normal_eq(dataloader, model1, model2, model3, spec, perm, costs, budget_ratios, MAX_STEPS, separate_classifier,

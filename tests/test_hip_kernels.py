@@ -368,3 +368,37 @@ def test_wgrad_accumulate_kpos_major(ops):
         batch.flush()
     ref = 1 + 2 * want.reshape(24, 40, 9).permute(0, 2, 1).reshape(24, 360)
     assert _rel(out.cpu(), ref) < 3e-6
+
+
+# ------------------------------------------------------------------------------------------ batched SPD solve
+def test_cholesky_solve_batched_mixed_sizes(ops):
+    g = torch.Generator().manual_seed(21)
+    sizes = [(1, 3), (5, 1), (64, 7), (65, 100), (130, 17), (200, 256), (513, 40), (1000, 129)]
+    As, Bts, refs = [], [], []
+    for K, N in sizes:
+        M = torch.randn(K, K + 8, generator=g, dtype=torch.float64)
+        A = M @ M.t() / (K + 8) + 0.5 * torch.eye(K, dtype=torch.float64)
+        Bt = torch.randn(N, K, generator=g, dtype=torch.float64)
+        refs.append(torch.linalg.solve(A, Bt.t()).t())
+        As.append(torch.tril(A).float().cuda().contiguous())       # only the lower triangle is read
+        Bts.append(Bt.float().cuda().contiguous())
+    info = ops.cholesky_solve_batched(As, Bts, ridge=0.0)
+    assert (info.cpu() == 0).all()
+    for (K, N), got, want in zip(sizes, Bts, refs):
+        assert _rel(got.cpu(), want) < 2e-5, (K, N, _rel(got.cpu(), want))
+
+
+def test_cholesky_solve_ridge_and_breakdown_flag(ops):
+    g = torch.Generator().manual_seed(22)
+    K = 96
+    M = torch.randn(K, 10, generator=g, dtype=torch.float64)
+    A = M @ M.t()                                                    # rank 10: singular
+    Bt = torch.randn(4, K, generator=g, dtype=torch.float64)
+    lam = 1e-3
+    want = torch.linalg.solve(A + lam * A.diagonal().mean() * torch.eye(K, dtype=torch.float64), Bt.t()).t()
+    a, b = A.float().cuda().contiguous(), Bt.float().cuda().contiguous()
+    info = ops.cholesky_solve_batched([a], [b], ridge=lam)
+    assert int(info[0]) == 0 and _rel(b.cpu(), want) < 5e-3
+    a2 = (-torch.eye(8)).cuda().contiguous()                         # not positive definite -> flagged, no NaN trap
+    info = ops.cholesky_solve_batched([a2], [torch.ones(2, 8).cuda()], ridge=0.0)
+    assert int(info[0]) == 1
