@@ -9,3 +9,4 @@ from .activation_matching import (
 from .weight_matching import weight_matching
 from .partial_matching import expand_ratios, get_blocks, partial_merge, build_partial_merge_model
 from .pleas_merging import train, get_gradient_mask
+from .extras import reset_bn_stats, zip_ratios, save_matching, load_matching, load_checkpoint

@@ -202,3 +202,58 @@ def test_product_never_imports_oracle():
                 if f.endswith((".py", ".hip", ".hpp", ".h")):
                     text = open(os.path.join(dirpath, f)).read()
                     assert "oracle" not in text.replace("oracle/", "").lower() or f == "build.py", os.path.join(dirpath, f)
+
+
+# ------------------------------------------------------------------ section 8(f) "next" rows (host logic)
+def test_zip_ratios_stage_rule():
+    from pleas.core.compiler import get_permutation_spec
+    from pleas.methods.extras import zip_ratios
+    from pleas_merging_amd import resnet as zoo
+
+    spec = get_permutation_spec(zoo.resnet50(), ((1, 3, 224, 224),))
+    for budget, last in ((1.0, 4), (1.2, 3), (1.55, 2), (1.8, 1), (2.0, 0)):
+        r = zip_ratios(spec, budget)
+        assert set(r) == set(spec)
+        for k, v in r.items():
+            stage = int(k.key.split(".")[0][5:]) if k.key.startswith("layer") else 0
+            assert v == (0.0 if stage <= last else 1.0), (budget, k)
+    with pytest.raises(KeyError):
+        zip_ratios(spec, 1.3)
+
+
+def test_matching_and_checkpoint_round_trip(tiny_basic, tmp_path):
+    from pleas.methods.extras import load_checkpoint, load_matching, save_matching
+    from pleas_merging_amd import resnet as zoo
+
+    t = tiny_basic
+    perm, costs = t.per_key("am_perm"), t.per_key("am_cost")
+    save_matching(str(tmp_path / "m.pt"), perm, costs)
+    p2, c2 = load_matching(str(tmp_path / "m.pt"))
+    assert list(p2) == list(perm) and all(torch.equal(p2[k], perm[k]) and torch.equal(c2[k], costs[k]) for k in perm)
+    for blob in (t.m1.state_dict(), {"model": t.m1.state_dict(), "epoch": 3}):
+        torch.save(blob, str(tmp_path / "ck.pt"))
+        m = load_checkpoint(zoo.tiny_resnet("basic", (1, 1, 1, 1), 10, 4), str(tmp_path / "ck.pt"))
+        assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), t.m1.state_dict().values()))
+
+
+def test_reset_bn_stats_matches_driver_procedure(tiny_basic):
+    import copy
+
+    from pleas.methods.extras import reset_bn_stats
+
+    t = tiny_basic
+    m3 = orc.partial_merge(t.spec, t.m1, t.m2, t.per_key("am_perm"), t.per_key("am_cost"), 0.5)
+    ref = copy.deepcopy(m3).train()   # the drivers' procedure, written out (run_domainnet.py:327-341)
+    for mod in ref.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.reset_running_stats()
+    data = t.batches("xt")
+    with torch.no_grad():
+        for i, b in enumerate(data):
+            ref(b[0].float())
+            if i + 1 > 100:
+                break
+    got = reset_bn_stats(m3, data, 101)
+    assert got.training
+    for (k, a), (_, b) in zip(got.state_dict().items(), ref.state_dict().items()):
+        assert torch.equal(a, b), k
