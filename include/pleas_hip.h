@@ -160,6 +160,29 @@ int pleas_sqerr(const float* a, const float* b, int64_t n, float scale, int accu
  *   layers: HOST array; resid/ip/grad DEVICE pointers (16-byte aligned); ws >= pleas_wgrad_batch_ws_bytes.
  *   Deterministic; the work list is cached per (geometry sequence, ws); ws_fresh as in pleas_gram_batch.
  */
+/* pleas_fwd_batch: forward of every merged layer of one update with the target, residual and loss fused:
+ *   out   = conv(ip, w) (+ bias)                      (never stored)
+ *   tgt   = coef(co) * ([row1[co]>=0] o1[n][row1[co]] + [row2[co]>=0] o2[n][row2[co]]),  coef = 0.5 for co < n_merged
+ *   resid = dscale * (out - tgt)      -> layers[i].resid  (the input of pleas_wgrad_batch)
+ *   loss[i] = loss_scale * sum (out - tgt)^2           (DEVICE float[n_layers], fixed summation order)
+ * A Linear layer is Hin = Win = KH = KW = 1.  w must be 16-byte aligned.  ws / ws_fresh as in pleas_gram_batch.
+ */
+typedef struct pleas_fwd_layer {
+    const float* ip;     /* [N][Cin][Hin][Win] merged input */
+    const float* w;      /* [Cout][Cin][KH][KW] */
+    const float* bias;   /* [Cout] or NULL */
+    const float* o1;     /* [N][Csrc][Hout*Wout] source-layer outputs */
+    const float* o2;
+    const int32_t* row1; /* [Cout] block maps (DEVICE) */
+    const int32_t* row2;
+    float* resid;        /* [N][Cout][Hout*Wout] */
+    int N, Cout, Cin, Hin, Win, KH, KW, stride, pad, Csrc, n_merged;
+    float dscale, loss_scale;
+} pleas_fwd_layer;
+size_t pleas_fwd_batch_ws_bytes(const pleas_fwd_layer* layers, int n_layers);
+int pleas_fwd_batch(const pleas_fwd_layer* layers, int n_layers, float* loss, void* ws, size_t ws_bytes, int ws_fresh,
+                    void* stream);
+
 typedef struct pleas_wgrad_layer {
     const float* resid; /* [N][Cout][Hout*Wout] */
     const float* ip;    /* [N][Cin][Hin][Win]   */

@@ -45,12 +45,22 @@ SIGNATURES = {
                                              c_float, c_void_p, c_void_p]),
     "pleas_normal_eq_ws_bytes": (c_size_t, [c_void_p, c_int]),
     "pleas_normal_eq_accum": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p]),
+    "pleas_fwd_batch_ws_bytes": (c_size_t, [c_void_p, c_int]),
+    "pleas_fwd_batch": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "pleas_wgrad_batch_ws_bytes": (c_size_t, [c_void_p, c_int]),
     "pleas_wgrad_batch": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "pleas_gram_batch_ws_bytes": (c_size_t, [c_void_p, c_int, POINTER(c_int), c_int]),
     "pleas_gram_batch": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_int), c_int, c_int, c_int, c_void_p,
                                  c_size_t, c_int, c_void_p]),
 }
+
+
+class FwdLayer(ctypes.Structure):
+    """struct pleas_fwd_layer"""
+    _fields_ = [("ip", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("o1", c_void_p), ("o2", c_void_p),
+                ("row1", c_void_p), ("row2", c_void_p), ("resid", c_void_p), ("N", c_int), ("Cout", c_int), ("Cin", c_int),
+                ("Hin", c_int), ("Win", c_int), ("KH", c_int), ("KW", c_int), ("stride", c_int), ("pad", c_int),
+                ("Csrc", c_int), ("n_merged", c_int), ("dscale", c_float), ("loss_scale", c_float)]
 
 
 class NeqLayer(ctypes.Structure):

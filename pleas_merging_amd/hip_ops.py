@@ -282,6 +282,62 @@ def loss_final(partials: torch.Tensor, n_partials: torch.Tensor, scale: torch.Te
     check(rc, "pleas_loss_final")
 
 
+class FwdBatch:
+    """Forward + target + residual + loss of all merged layers of one update in ONE grouped launch
+    (``pleas_fwd_batch``).  ``add`` per layer, ``flush(loss)`` once per update."""
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self._keep: list = []
+        self._geo: list = []
+        self._arr = None
+        self._ws = None
+        self._fresh = 1
+
+    def add(self, ip, w, bias, o1, o2, row1, row2, n_merged: int, resid, dscale: float, loss_scale: float,
+            kernel=(1, 1), stride: int = 1, pad: int = 0) -> None:
+        for t in (ip, w, o1, o2, resid):
+            if not t.is_contiguous():
+                raise PleasHipError("FwdBatch.add: contiguous tensors expected")
+        N, Cin = ip.shape[0], ip.shape[1]
+        Hin, Win = (ip.shape[2], ip.shape[3]) if ip.dim() == 4 else (1, 1)
+        self._keep.append((ip, w, bias, o1, o2, row1, row2, resid))
+        self._geo.append((N, w.shape[0], Cin, Hin, Win, kernel[0], kernel[1], stride, pad, o1.shape[1], int(n_merged),
+                          float(dscale), float(loss_scale)))
+
+    def flush(self, loss: torch.Tensor) -> None:
+        n = len(self._keep)
+        if n == 0:
+            return
+        if loss.numel() != n or not loss.is_contiguous():
+            raise PleasHipError("FwdBatch.flush: loss must hold one float per layer")
+        if self._arr is None or len(self._arr) != n:
+            self._arr = (_lib.FwdLayer * n)()
+        for i, (t, geo) in enumerate(zip(self._keep, self._geo)):
+            a = self._arr[i]
+            ip, w, bias, o1, o2, row1, row2, resid = t
+            a.ip, a.w, a.bias = ip.data_ptr(), w.data_ptr(), (bias.data_ptr() if bias is not None else None)
+            a.o1, a.o2, a.row1, a.row2, a.resid = o1.data_ptr(), o2.data_ptr(), row1.data_ptr(), row2.data_ptr(), resid.data_ptr()
+            (a.N, a.Cout, a.Cin, a.Hin, a.Win, a.KH, a.KW, a.stride, a.pad, a.Csrc, a.n_merged, a.dscale,
+             a.loss_scale) = geo
+        lib = _lib.lib()
+        if self._ws is None:
+            need = int(lib.pleas_fwd_batch_ws_bytes(self._arr, n))
+            if need == 0:
+                raise PleasHipError("pleas_fwd_batch_ws_bytes rejected the layer list: %s" % lib.pleas_last_error().decode())
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._fresh = 1
+        rc = lib.pleas_fwd_batch(self._arr, n, loss.data_ptr(), self._ws.data_ptr(), self._ws.numel(), self._fresh, _stream())
+        self._fresh = 0
+        if rc == -12:
+            self._ws = None
+            self.flush(loss)
+            return
+        check(rc, "pleas_fwd_batch")
+        self._keep.clear()
+        self._geo.clear()
+
+
 class WgradBatch:
     """Weight gradients of all merged layers of one update in ONE grouped launch (``pleas_wgrad_batch``).
     ``add`` per layer (operands must stay unmodified until ``flush``), ``flush`` once per update."""

@@ -118,7 +118,6 @@ class NormalEqFitter(PleasFitter):
             for t in s:
                 dp_sum_(t, self.world)
         info: Dict[str, float] = {}
-        off = 0
         jobs, finals = [], []   # (W, rows, free, A_FF, rhs, A_FF backup) per solve; (plan, W, layout) per layer
         for idx, plan in enumerate(self.plans):
             K, co = self.K[idx], plan.w_shape[0]
@@ -134,7 +133,7 @@ class NormalEqFitter(PleasFitter):
                 to_kpos = lambda t, co=co, K=K: t.reshape(co, K)
                 from_kpos = lambda t, shp=plan.w_shape: t.reshape(shp)
             n_w = plan.w.numel()
-            mask = to_kpos(self.mask[off:off + n_w])
+            mask = to_kpos(self.mask[plan.off_w:plan.off_w + n_w])
             w0 = to_kpos(plan.w)
             if plan.b is not None:                             # augmented system for the bias column
                 su, sy, m = self.bias_stats[idx]
@@ -159,7 +158,6 @@ class NormalEqFitter(PleasFitter):
                 jobs.append((W, rows, free, Aff, rhs.contiguous(), Aff.clone()))  # last: untouched copy for a fallback
             finals.append((plan, W, from_kpos))
             info[plan.name] = float(K)
-            off += n_w + (plan.b.numel() if plan.b is not None else 0)
         # ONE batched HIP launch sequence solves every (layer, mask pattern) system
         rhs_orig = [j[4].clone() for j in jobs]
         flags = self.ops.cholesky_solve_batched([j[3] for j in jobs], [j[4] for j in jobs], ridge=self.ridge).cpu()

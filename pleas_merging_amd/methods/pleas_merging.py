@@ -115,7 +115,7 @@ def cosine_lrs(base_lr: float, t_max: int, n: int) -> List[float]:
 
 # ------------------------------------------------------------------------------------------ per-layer plan
 class _LayerPlan:
-    __slots__ = ("name", "mod", "is_conv", "w", "b", "gw", "gb", "in_maps", "out_maps", "w_shape")
+    __slots__ = ("name", "mod", "is_conv", "w", "b", "gw", "gb", "in_maps", "out_maps", "w_shape", "off_w")
 
 
 def _identity_block(n: int):
@@ -156,7 +156,8 @@ class PleasFitter:
     uses it directly to time single steps."""
 
     def __init__(self, model1, model2, model3, spec, perm, costs, budget_ratios, max_steps: int, lr: float = 5e-4,
-                 separate_classifier=False, num_classes=1000, model_type="rn50", data_parallel: bool = False):
+                 separate_classifier=False, num_classes=1000, model_type="rn50", data_parallel: bool = False,
+                 forward: str = "hip"):
         from .. import hip_ops
         from .activation_matching import _dist_info
 
@@ -176,9 +177,10 @@ class PleasFitter:
 
         layers = {n: m for n, m in model3.named_modules() if isinstance(m, (nn.Conv2d, nn.Linear))}
         self.layer_modules = layers
-        total = sum(p.numel() for m in layers.values() for p in m.parameters())
+        pad4 = lambda n: (n + 3) // 4 * 4   # every tensor starts 16-byte aligned inside the arenas (vector loads)
+        total = sum(pad4(p.numel()) for m in layers.values() for p in m.parameters())
         dev = self.device
-        self.p = torch.empty(total, dtype=torch.float32, device=dev)
+        self.p = torch.zeros(total, dtype=torch.float32, device=dev)
         self.g = torch.zeros(total, dtype=torch.float32, device=dev)
         self.m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.v = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -196,10 +198,10 @@ class PleasFitter:
                 self.mask[off:off + n].copy_(masks[k].reshape(-1))
                 view, gview = self.p[off:off + n].view(prm.shape), self.g[off:off + n].view(prm.shape)
                 if pname == "weight":
-                    plan.w, plan.gw, plan.w_shape = view, gview, tuple(prm.shape)
+                    plan.w, plan.gw, plan.w_shape, plan.off_w = view, gview, tuple(prm.shape), off
                 else:
                     plan.b, plan.gb = view, gview
-                off += n
+                off += pad4(n)
                 k += 1
             src = get_attr(model1, name.split("."))
             cin = src.in_channels if plan.is_conv else src.in_features
@@ -219,8 +221,14 @@ class PleasFitter:
         self.loss_scale = torch.zeros(len(self.plans), dtype=torch.float32, device=dev)
         self.loss_meta_host = [None] * len(self.plans)
         self.wgrad = hip_ops.WgradBatch(dev)
+        if forward not in ("hip", "vendor"):
+            raise ValueError("forward must be 'hip' (fused MFMA kernel) or 'vendor' (MIOpen + pleas_target_residual)")
+        self.forward = forward
+        self.fwd = hip_ops.FwdBatch(dev)
+        self._fwd_loss = None
+        self._fwd_index = None
 
-    # -- one layer: merged input, merged-layer forward, fused target/residual, queue the weight gradient
+    # -- one layer: merged input; queue forward(+target+residual+loss) and weight gradient for the grouped launches
     def _fit_layer(self, idx: int, plan: _LayerPlan) -> None:
         ops = self.ops
         name = plan.name
@@ -228,36 +236,50 @@ class PleasFitter:
         o1, o2 = self.tap1.outputs[name], self.tap2.outputs[name]
         ip = ops.merge_blocks(ip1, ip2, 1, *plan.in_maps)
         mod = plan.mod
-        if plan.is_conv:
-            out = F.conv2d(ip, plan.w, plan.b, mod.stride, mod.padding, mod.dilation, mod.groups)
-        else:
-            out = F.linear(ip, plan.w, plan.b)
         r1, r2, nm = plan.out_maps
-        if out.shape[1] != r1.numel() or out.shape[2:] != o1.shape[2:]:
-            raise RuntimeError("layer %s: merged output %s vs target blocks %d x %s" %
-                               (name, tuple(out.shape), r1.numel(), tuple(o1.shape[2:])))
-        n = out.numel() * self.world  # the mean runs over the full (global) batch
-        # out <- 2 (out - target) / n in place; per-workgroup sums of squares -> this layer's partial row
-        nparts = ops.target_residual(out, o1.contiguous(), o2.contiguous(), r1, r2, nm, 2.0 / n, self.loss_parts[idx])
-        if self.loss_meta_host[idx] != (nparts, n):
-            self.loss_meta_host[idx] = (nparts, n)
-            self.loss_nparts[idx] = nparts
-            self.loss_scale[idx] = 1.0 / n
-        resid = out
-        hip_ok = plan.is_conv and mod.groups == 1 and mod.dilation == (1, 1) and mod.stride[0] == mod.stride[1] \
-            and mod.padding[0] == mod.padding[1] and ip.shape[1] >= 16
-        if hip_ok:
-            self.wgrad.add(resid, ip, plan.gw, tuple(mod.kernel_size), mod.stride[0], mod.padding[0])
-        elif not plan.is_conv and ip.dim() == 2:
-            self.wgrad.add(resid, ip, plan.gw)
-        elif plan.is_conv:  # stem (3 input channels) and exotic geometries: vendor kernel
-            gw = torch.ops.aten.convolution_backward(resid, ip, plan.w, None, mod.stride, mod.padding, mod.dilation,
-                                                     False, [0, 0], mod.groups, [False, True, False])[1]
-            plan.gw.copy_(gw)
+        cout = plan.w_shape[0]
+        if cout != r1.numel():
+            raise RuntimeError("layer %s: %d merged outputs vs %d target blocks" % (name, cout, r1.numel()))
+        square = plan.is_conv and mod.groups == 1 and mod.dilation == (1, 1) and mod.stride[0] == mod.stride[1] \
+            and mod.padding[0] == mod.padding[1] and mod.kernel_size[0] == mod.kernel_size[1]
+        linear = (not plan.is_conv) and ip.dim() == 2
+        geo = (tuple(mod.kernel_size), mod.stride[0], mod.padding[0]) if plan.is_conv else ((1, 1), 1, 0)
+        if self.forward == "hip" and (square or linear):
+            resid = torch.empty((ip.shape[0], cout) + tuple(o1.shape[2:]), dtype=torch.float32, device=ip.device)
+            n = resid.numel() * self.world           # the mean runs over the full (global) batch
+            self.fwd.add(ip, plan.w, plan.b, o1, o2, r1, r2, nm, resid, 2.0 / n, 1.0 / n, *geo)
+            self._fwd_rows.append(idx)
+        else:                                        # vendor forward + fused target/residual (one launch per layer)
+            out = F.conv2d(ip, plan.w, plan.b, mod.stride, mod.padding, mod.dilation, mod.groups) if plan.is_conv \
+                else F.linear(ip, plan.w, plan.b)
+            if out.shape[2:] != o1.shape[2:]:
+                raise RuntimeError("layer %s: merged output %s vs source output %s" % (name, tuple(out.shape), tuple(o1.shape)))
+            n = out.numel() * self.world
+            nparts = ops.target_residual(out, o1, o2, r1, r2, nm, 2.0 / n, self.loss_parts[idx])
+            if self.loss_meta_host[idx] != (nparts, n):
+                self.loss_meta_host[idx] = (nparts, n)
+                self.loss_nparts[idx] = nparts
+                self.loss_scale[idx] = 1.0 / n
+            resid = out
+        if (square and ip.shape[1] >= 16) or linear:
+            self.wgrad.add(resid, ip, plan.gw, *geo)
+        elif plan.is_conv:  # stem (3 input channels) and exotic geometries: vendor weight gradient
+            self._vendor_wgrad.append((resid, ip, plan))
         else:
-            r2d, i2d = resid.reshape(-1, resid.shape[-1]), ip.reshape(-1, ip.shape[-1])
-            torch.mm(r2d.t(), i2d, out=plan.gw)
+            self._vendor_wgrad.append((resid, ip, plan))
         if plan.gb is not None:
+            self._bias_grads.append((resid, plan))
+
+    def _finish_vendor_parts(self) -> None:
+        for resid, ip, plan in self._vendor_wgrad:
+            mod = plan.mod
+            if plan.is_conv:
+                gw = torch.ops.aten.convolution_backward(resid, ip, plan.w, None, mod.stride, mod.padding, mod.dilation,
+                                                         False, [0, 0], mod.groups, [False, True, False])[1]
+                plan.gw.copy_(gw)
+            else:
+                torch.mm(resid.reshape(-1, resid.shape[-1]).t(), ip.reshape(-1, ip.shape[-1]), out=plan.gw)
+        for resid, plan in self._bias_grads:
             plan.gb.copy_(resid.sum((0, 2, 3)) if plan.is_conv else resid.reshape(-1, resid.shape[-1]).sum(0))
 
     @torch.no_grad()
@@ -267,13 +289,24 @@ class PleasFitter:
         x = dp_slice(x, self.rank, self.world)
         self.model1(x)
         self.model2(x)
+        self._fwd_rows, self._vendor_wgrad, self._bias_grads = [], [], []
         for idx, plan in enumerate(self.plans):
             if plan.name not in self.tap1.inputs or plan.name not in self.tap2.inputs:
                 print("Key error on %s" % plan.name)
                 continue
             self._fit_layer(idx, plan)
+        if self._fwd_rows:   # ONE grouped MFMA launch: forward + target + residual + loss of every merged layer
+            if self._fwd_loss is None or self._fwd_loss.numel() != len(self._fwd_rows):
+                self._fwd_loss = torch.zeros(len(self._fwd_rows), dtype=torch.float32, device=self.device)
+                self._fwd_index = torch.tensor(self._fwd_rows, dtype=torch.long, device=self.device)
+            self.fwd.flush(self._fwd_loss)
+        vendor_rows = len(self._fwd_rows) < len(self.plans)
+        if vendor_rows:
+            self.ops.loss_final(self.loss_parts, self.loss_nparts, self.loss_scale, self.loss_now)
+        if self._fwd_rows:
+            self.loss_now.index_copy_(0, self._fwd_index, self._fwd_loss)
+        self._finish_vendor_parts()
         self.wgrad.flush()  # ONE grouped MFMA launch: weight gradients of every merged layer
-        self.ops.loss_final(self.loss_parts, self.loss_nparts, self.loss_scale, self.loss_now)
         dp_sum_(self.g, self.world)
         dp_sum_(self.loss_now, self.world)
         self.loss_sum.add_(self.loss_now)

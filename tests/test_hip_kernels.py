@@ -402,3 +402,51 @@ def test_cholesky_solve_ridge_and_breakdown_flag(ops):
     a2 = (-torch.eye(8)).cuda().contiguous()                         # not positive definite -> flagged, no NaN trap
     info = ops.cholesky_solve_batched([a2], [torch.ones(2, 8).cuda()], ridge=0.0)
     assert int(info[0]) == 1
+
+
+# ------------------------------------------------------------------------------------------ fused forward + target + residual + loss
+FWD_CASES = [
+    # N, Cout, Cin, H, W, k, stride, pad, bias
+    (4, 256, 64, 14, 14, 1, 1, 0, False),
+    (4, 64, 256, 14, 14, 1, 1, 0, False),     # TM = 64
+    (3, 96, 80, 7, 7, 1, 1, 0, False),        # ragged pixels / channels
+    (4, 128, 128, 14, 14, 3, 1, 1, False),    # 3x3 with padding
+    (2, 40, 24, 9, 11, 3, 1, 1, False),       # non-square image
+    (4, 128, 64, 28, 28, 3, 2, 1, False),     # stride 2
+    (2, 64, 3, 32, 32, 7, 2, 3, False),       # stem geometry: Kd = 147 (scalar weight loads)
+    (16, 70, 300, 1, 1, 1, 1, 0, True),       # linear layer with bias
+]
+
+
+@pytest.mark.parametrize("N,Cout,Cin,H,W,k,stride,pad,bias", FWD_CASES)
+def test_fwd_batch_matches_conv_and_target(ops, N, Cout, Cin, H, W, k, stride, pad, bias):
+    import torch.nn.functional as F
+    from pleas_merging_amd.methods.partial_matching import block_maps
+
+    g = torch.Generator().manual_seed(Cout * 7 + Cin + k)
+    ip = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g) if bias else None
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    nm, ns = Cout - 2 * (Cout // 5), Cout // 5          # merged / separate output units: Csrc = nm + ns
+    Csrc = nm + ns
+    pm = torch.randperm(Csrc, generator=g)
+    blk = (torch.arange(nm), pm[:nm], torch.arange(nm, Csrc), pm[nm:])
+    o1, o2 = torch.randn(N, Csrc, Ho, Wo, generator=g), torch.randn(N, Csrc, Ho, Wo, generator=g)
+    target = torch.cat([(o1[:, blk[0]] + o2[:, blk[1]]) / 2, o1[:, blk[2]], o2[:, blk[3]]], 1)
+    out = F.conv2d(ip.double(), w.double(), b.double() if bias else None, stride, pad)
+    numel = out.numel()
+    want = 2 * (out - target.double()) / numel
+    want_loss = float(((out - target.double()) ** 2).mean())
+    r1, r2, nmerged = block_maps(blk, "cuda")
+    batch = ops.FwdBatch(torch.device("cuda"))
+    resid = [torch.full((N, Cout, Ho, Wo), float("nan"), device="cuda") for _ in range(2)]
+    loss = torch.zeros(2, device="cuda")
+    wd = w.cuda().contiguous()
+    for i in range(2):   # two layers in one launch
+        batch.add(ip.cuda(), wd, b.cuda() if bias else None, o1.cuda(), o2.cuda(), r1, r2, nmerged, resid[i], 2.0 / numel,
+                  1.0 / numel, (k, k), stride, pad)
+    batch.flush(loss)
+    for i in range(2):
+        assert _rel(resid[i].cpu(), want) < 5e-6
+        assert abs(float(loss[i]) - want_loss) < 1e-5 * max(1.0, want_loss)

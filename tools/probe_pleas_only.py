@@ -19,3 +19,10 @@ for _ in range(3): fit.step(x)
 torch.cuda.synchronize(); t0 = time.time()
 for _ in range(ns): fit.step(x)
 torch.cuda.synchronize(); print("PLeaS: %.2f ms/step" % ((time.time() - t0) / ns * 1e3))
+# --- is the step CPU-bound?  enqueue time (no sync) vs wall time per step
+import time as _t
+torch.cuda.synchronize(); t0 = _t.time(); enq = 0.0
+for _ in range(ns):
+    a = _t.time(); fit.step(x); enq += _t.time() - a
+t1 = _t.time(); torch.cuda.synchronize(); t2 = _t.time()
+print("enqueue %.2f ms/step, wall %.2f ms/step, GPU drain after last enqueue %.1f ms" % (enq / ns * 1e3, (t2 - t0) / ns * 1e3, (t2 - t1) * 1e3))
