@@ -298,6 +298,7 @@ def main():
         labels = {
             "gram_partial": "gram_batch_kernel (grouped fp32 MFMA 32x32x2 contraction, one launch per matching batch)",
             "conv_wgrad": "wgrad_batch_kernel (grouped fp32 MFMA 32x32x2 weight gradients, one launch per PLeaS update)",
+            "conv_fwd": "fwd_batch_kernel (grouped fp32 MFMA 32x32x2 forward + target + residual + loss, one launch per PLeaS update)",
         }
 
         def roof(name):
