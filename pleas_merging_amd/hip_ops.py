@@ -125,7 +125,9 @@ class GramBatch:
         self._keep.append((x, y))
         self._meta.append(_as_bchw(x, axis) + (group,))
 
-    def flush(self, accumulate: bool = True) -> None:
+    def flush(self, accumulate: bool = True, keep: bool = False) -> None:
+        """Contract everything added since the last flush.  ``keep=True`` leaves the node list in place: used when
+        the forward pass is a replayed hipGraph, whose activations are the same device tensors every batch."""
         n = len(self._keep)
         if n == 0:
             return
@@ -147,9 +149,14 @@ class GramBatch:
         self._fresh = 0
         if rc == -12:  # node list changed shape: size the workspace again
             self._ws = None
-            self.flush(accumulate)
+            self.flush(accumulate, keep)
             return
         check(rc, "pleas_gram_batch")
+        if not keep:
+            self._keep.clear()
+            self._meta.clear()
+
+    def drop(self) -> None:
         self._keep.clear()
         self._meta.clear()
 

@@ -67,8 +67,7 @@ class NormalEqFitter(PleasFitter):
         """Accumulate one batch (no parameter update)."""
         ops = self.ops
         x = x.to(self.device, non_blocking=True)
-        self.model1(x)
-        self.model2(x)
+        self._run_sources(x)
         KP = ops.WgradBatch.ACCUMULATE | ops.WgradBatch.KPOS_MAJOR
         for idx, plan in enumerate(self.plans):
             name = plan.name
@@ -104,8 +103,9 @@ class NormalEqFitter(PleasFitter):
         self.neq.flush()
         self.wgrad.flush()
         self.batches_seen += 1
-        self.tap1.clear()
-        self.tap2.clear()
+        if self._src_graph is None:
+            self.tap1.clear()
+            self.tap2.clear()
 
     @torch.no_grad()
     def solve(self) -> Dict[str, float]:

@@ -307,3 +307,34 @@ def test_full_size_planted_permutation_resnet50():
     inv = invert_perm(planted)
     for k in spec:
         assert (perm[k] == inv[k]).all(), k
+
+
+def test_graph_captured_forwards_give_identical_results(tiny_bottleneck):
+    """Opt-in hipGraph capture of the source / twin forwards must not change any number."""
+    from pleas_merging_amd.methods.activation_matching import accumulate_costs_fused
+    from pleas.methods.partial_matching import partial_merge
+    from pleas.methods.pleas_merging import PleasFitter
+    from pleas_merging_amd import hip_ops
+
+    t = tiny_bottleneck
+    m1, m2 = _cuda_pair(t)
+    data = t.batches() + t.batches()
+    a = accumulate_costs_fused(t.spec, m1, m2, data, 8, hip_ops.EPI_NEG_CDIST, graph_forward=False)
+    b = accumulate_costs_fused(t.spec, m1, m2, data, 8, hip_ops.EPI_NEG_CDIST, graph_forward=True)
+    for k in t.spec:
+        assert torch.equal(a[k], b[k]), k
+    perm = t.per_key("am_perm")
+    costs = {k: v.cuda() for k, v in t.per_key("am_cost").items()}
+    outs = []
+    for graph in (False, True):
+        m3 = partial_merge(t.spec, m1, m2, perm, costs, 0.5)
+        fit = PleasFitter(m1, m2, m3, t.spec, perm, costs, 0.5, 7, num_classes=10, graph_sources=graph)
+        for x, _ in data:
+            fit.step(x)
+        assert (fit._src_graph is not None) == graph
+        outs.append({k: v.clone() for k, v in fit.finish().state_dict().items()})
+    for k in outs[0]:
+        if k == DEGENERATE:   # stem: rounding-noise-driven and its 3-channel wgrad is the vendor's (atomics) kernel
+            assert torch.allclose(outs[0][k], outs[1][k], atol=2 * 5e-4 * 8)
+        else:
+            assert torch.equal(outs[0][k], outs[1][k]), k
