@@ -36,6 +36,16 @@ inline int bad_arg(const char* what) {
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Pointers that reach a kernel through a device-side table are "generic" to hipcc, which then emits
+// flat_load / flat_store: those count on lgkmcnt as well as vmcnt, so every LDS wait in the MFMA loop
+// also waits for the global prefetch.  Casting to the global address space gives global_load / global_store.
+typedef __attribute__((address_space(1))) float gfloat;
+typedef __attribute__((address_space(1))) const float cgfloat;
+typedef __attribute__((address_space(1))) const int gcint;
+#define PLEAS_GLOBAL(p) ((::pleas::cgfloat*)(p))
+#define PLEAS_GLOBAL_W(p) ((::pleas::gfloat*)(p))
+#define PLEAS_GLOBAL_I(p) ((::pleas::gcint*)(p))
+
 // ---- opt-in per-kernel timing with HIP events on the launch stream (pleas_prof_* in the C-ABI)
 enum ProfKernel { kProfGramPartial = 0, kProfGramFinalize, kProfLsap, kProfMergeBlocks, kProfMaskedAdam, kProfSqerr,
                   kProfConvFwd, kProfConvWgrad, kProfNormalEq, kProfSolve, kProfCount };

@@ -100,11 +100,11 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradIt
 #pragma unroll
             for (int q = 0; q < PASS_X; ++q) {
                 if constexpr (VECX == 4) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(L.resid + base + offx[q]);
+                    const f32x4 v = *(const __attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL(L.resid) + base + offx[q]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) rx[q][e] = v[e];
                 } else {
-                    rx[q][0] = L.resid[base + offx[q]];
+                    rx[q][0] = PLEAS_GLOBAL(L.resid)[base + offx[q]];
                 }
             }
         }
@@ -126,11 +126,11 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradIt
 #pragma unroll
             for (int q = 0; q < PASS_Y; ++q) {
                 if constexpr (VECY == 4) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(L.ip + base + offy[q]);
+                    const f32x4 v = *(const __attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL(L.ip) + base + offy[q]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ry[q][e] = v[e];
                 } else {
-                    ry[q][0] = L.ip[base + offy[q]];
+                    ry[q][0] = PLEAS_GLOBAL(L.ip)[base + offy[q]];
                 }
             }
         }
@@ -210,9 +210,10 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradIt
                         const size_t o = (L.flags & PLEAS_WGRAD_KPOS_MAJOR)
                                              ? (size_t)co * ((size_t)R * L.Cin) + (size_t)it.r * L.Cin + ci
                                              : ((size_t)co * L.Cin + ci) * R + it.r;
-                        L.out[o] = (L.flags & PLEAS_WGRAD_ACCUMULATE) ? L.out[o] + acc[sm][sn][r] : acc[sm][sn][r];
+                        gfloat* outp = PLEAS_GLOBAL_W(L.out);
+                        outp[o] = (L.flags & PLEAS_WGRAD_ACCUMULATE) ? outp[o] + acc[sm][sn][r] : acc[sm][sn][r];
                     } else
-                        L.slab[((size_t)it.split * L.Cout + co) * ((size_t)R * L.Cin) + (size_t)it.r * L.Cin + ci] =
+                        PLEAS_GLOBAL_W(L.slab)[((size_t)it.split * L.Cout + co) * ((size_t)R * L.Cin) + (size_t)it.r * L.Cin + ci] =
                             acc[sm][sn][r];
                 }
             }

@@ -85,7 +85,8 @@ __device__ __forceinline__ void fwd_tile(const FwdLayerDev& L, const FwdItemDev&
         offa[q] = (uint32_t)min(gi, L.Cout - 1) * L.Kd;
     }
     // ---- B (input) staging: this thread's pixel and half of the chunk's k rows
-    const int bpix = tid & 127, bhalf = tid >> 7;
+    const int bpix = tid & 127;
+    const int bhalf = __builtin_amdgcn_readfirstlane(tid >> 7);  // wave-uniform: the k walk below stays on the scalar unit
     const uint32_t P = p0 + bpix;
     const bool pin = P < L.Ptot;
     const uint32_t pn = pin ? P / L.HWo : 0u, pp = pin ? P - pn * L.HWo : 0u;
@@ -95,6 +96,14 @@ __device__ __forceinline__ void fwd_tile(const FwdLayerDev& L, const FwdItemDev&
     float rb[16];
     unsigned okb = 0;
     bool kina = false;
+    // per-pixel tap table for kernels larger than 1x1 (KH*KW <= 64, checked on the host)
+    unsigned long long tapmask = 0;
+    const long long pixoff = (long long)ih0 * L.Win + iw0;
+    for (int r = 0; r < R; ++r) {
+        const int kh = r / L.KW, kw = r - kh * L.KW;
+        const bool ok = pin && ih0 + kh >= 0 && ih0 + kh < L.Hin && iw0 + kw >= 0 && iw0 + kw < L.Win;
+        tapmask |= (unsigned long long)ok << r;
+    }
 
     f32x16 acc[MTM][2];
 #pragma unroll
@@ -112,43 +121,52 @@ __device__ __forceinline__ void fwd_tile(const FwdLayerDev& L, const FwdItemDev&
 #pragma unroll
             for (int q = 0; q < PASS; ++q) {
                 if constexpr (VECA == 4) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(L.w + offa[q] + kc);
+                    const f32x4 v = *(const __attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL(L.w) + offa[q] + kc);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ra[q][e] = v[e];
                 } else {
-                    ra[q][0] = L.w[offa[q] + kc];
+                    ra[q][0] = PLEAS_GLOBAL(L.w)[offa[q] + kc];
                 }
             }
         }
         {
+            // Every lane of a wave walks the SAME k values (wave-uniform ci, kh, kw); only the pixel differs.
+            // Loads are unconditional: an out-of-range tap reads element 0 (offset masked to zero, no branch) and is
+            // zeroed when the tile is written to LDS.
             const uint32_t k = (uint32_t)c * fBK + bhalf * 16;
             okb = 0;
             if (R == 1) {   // 1x1 (also Linear): k is the input channel, the tap is the pixel itself
                 const bool inside = pin && ih0 >= 0 && ih0 < L.Hin && iw0 >= 0 && iw0 < L.Win;
-                const size_t tap = pbase + (inside ? (size_t)ih0 * L.Win + iw0 : 0);
+                const size_t tap = pbase + (size_t)(inside ? ih0 * L.Win + iw0 : 0);
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const bool ok = inside && (k + q) < L.Kd;
-                    if (ok) okb |= 1u << q;
-                    rb[q] = L.ip[ok ? tap + (size_t)(k + q) * HWi : 0];
+                    okb |= (ok ? 1u : 0u) << q;
+                    const size_t off = (tap + (size_t)(k + q) * HWi) & (size_t)(-(long long)ok);
+                    rb[q] = PLEAS_GLOBAL(L.ip)[off];
                 }
             } else {
+                // general kernel: the tap validity of this thread's pixel is a precomputed bit mask and its pixel
+                // offset a constant; (ci, r, kh, kw) are wave-uniform and walk on the scalar unit
                 int ci = (int)(k / (uint32_t)R);
                 int r = (int)(k - (uint32_t)ci * R);
                 int kh = r / L.KW, kw = r - kh * L.KW;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
-                    const int ih = ih0 + kh, iw = iw0 + kw;
-                    const bool ok = pin && (k + q) < L.Kd && ih >= 0 && ih < L.Hin && iw >= 0 && iw < L.Win;
-                    if (ok) okb |= 1u << q;
-                    rb[q] = L.ip[ok ? pbase + (size_t)ci * HWi + (size_t)ih * L.Win + iw : 0];
-                    if (++kw == L.KW) {
-                        kw = 0;
-                        if (++kh == L.KH) {
-                            kh = 0;
-                            ++ci;
-                        }
-                    }
+                    const bool ok = ((tapmask >> r) & 1ull) && (k + q) < L.Kd;
+                    okb |= (ok ? 1u : 0u) << q;
+                    const long long lin = (long long)ci * HWi + kh * L.Win + kw;   // scalar
+                    const size_t off = (size_t)((long long)pbase + pixoff + lin) & (size_t)(-(long long)ok);
+                    rb[q] = PLEAS_GLOBAL(L.ip)[off];
+                    ++r;
+                    ++kw;
+                    const int cw = kw == L.KW;
+                    kw = cw ? 0 : kw;
+                    kh += cw;
+                    const int cr = r == R;
+                    r = cr ? 0 : r;
+                    kh = cr ? 0 : kh;
+                    ci += cr;
                 }
             }
         }
@@ -227,37 +245,67 @@ __device__ __forceinline__ void fwd_tile(const FwdLayerDev& L, const FwdItemDev&
     const uint32_t Pg = p0 + pg;
     const bool gin = Pg < L.Ptot;
     const uint32_t gn = gin ? Pg / L.HWo : 0u, gp = gin ? Pg - gn * L.HWo : 0u;
-    for (int lco = tid >> 5; lco < TM; lco += 8) {
-        const int co = i0 + lco;
-        if (co >= L.Cout || !gin) continue;
-        const int r1 = L.row1[co], r2 = L.row2[co];
-        const float coef = co < L.n_merged ? 0.5f : 1.0f;
-        const float bv = L.bias ? L.bias[co] : 0.f;
-        const f32x4 o = *reinterpret_cast<const f32x4*>(Ct + lco * EL + pg);
-        if (vec_ok) {
-            f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-            if (r1 >= 0) a = *reinterpret_cast<const f32x4*>(L.o1 + ((size_t)gn * L.Csrc + r1) * L.HWo + gp);
-            if (r2 >= 0) b = *reinterpret_cast<const f32x4*>(L.o2 + ((size_t)gn * L.Csrc + r2) * L.HWo + gp);
-            f32x4 d;
+    // Each thread owns TM/8 output channels (lco = tid/32 + 8 j) x 4 pixels.  All map / bias loads are issued first,
+    // then the target gathers in batches of 4 channels, branch-free (absent or out-of-range rows read element 0 and are
+    // masked), so the loads of a batch are in flight together instead of one dependent chain per channel.
+    constexpr int ROWS = TM / 8;
+    int m1[ROWS], m2[ROWS];
+    float bias_v[ROWS];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float dd = (o[e] + bv) - (a[e] + b[e]) * coef;
-                sq = fmaf(dd, dd, sq);
-                d[e] = L.dscale * dd;
+    for (int j = 0; j < ROWS; ++j) {
+        const int co = min(i0 + (tid >> 5) + 8 * j, L.Cout - 1);
+        m1[j] = PLEAS_GLOBAL_I(L.row1)[co];
+        m2[j] = PLEAS_GLOBAL_I(L.row2)[co];
+        bias_v[j] = L.bias ? PLEAS_GLOBAL(L.bias)[co] : 0.f;
+    }
+    if (vec_ok) {
+#pragma unroll
+        for (int jb = 0; jb < ROWS; jb += 4) {
+            f32x4 ta[4], tb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = jb + u;
+                const size_t oa = (((size_t)gn * L.Csrc + max(m1[j], 0)) * L.HWo + gp) & (size_t)(-(long long)(gin && m1[j] >= 0));
+                const size_t ob = (((size_t)gn * L.Csrc + max(m2[j], 0)) * L.HWo + gp) & (size_t)(-(long long)(gin && m2[j] >= 0));
+                ta[u] = *(const __attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL(L.o1) + oa);
+                tb[u] = *(const __attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL(L.o2) + ob);
             }
-            *reinterpret_cast<f32x4*>(L.resid + ((size_t)gn * L.Cout + co) * L.HWo + gp) = d;
-        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = jb + u;
+                const int lco = (tid >> 5) + 8 * j, co = i0 + lco;
+                const bool live = gin && co < L.Cout;
+                const float coef = co < L.n_merged ? 0.5f : 1.0f;
+                const float fa = m1[j] >= 0 ? 1.f : 0.f, fb = m2[j] >= 0 ? 1.f : 0.f;
+                const f32x4 o = *reinterpret_cast<const f32x4*>(Ct + lco * EL + pg);
+                f32x4 d;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float dd = (o[e] + bias_v[j]) - (ta[u][e] * fa + tb[u][e] * fb) * coef;
+                    sq = live ? fmaf(dd, dd, sq) : sq;
+                    d[e] = L.dscale * dd;
+                }
+                if (live) *(__attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL_W(L.resid) + ((size_t)gn * L.Cout + co) * L.HWo + gp) = d;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            const int lco = (tid >> 5) + 8 * j, co = i0 + lco;
+            if (co >= L.Cout || !gin) continue;
+            const float coef = co < L.n_merged ? 0.5f : 1.0f;
+            const f32x4 o = *reinterpret_cast<const f32x4*>(Ct + lco * EL + pg);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const uint32_t Pe = Pg + e;
                 if (Pe >= L.Ptot) break;
                 const uint32_t n = Pe / L.HWo, p = Pe - n * L.HWo;
                 float a = 0.f, b = 0.f;
-                if (r1 >= 0) a = L.o1[((size_t)n * L.Csrc + r1) * L.HWo + p];
-                if (r2 >= 0) b = L.o2[((size_t)n * L.Csrc + r2) * L.HWo + p];
-                const float dd = (o[e] + bv) - (a + b) * coef;
+                if (m1[j] >= 0) a = PLEAS_GLOBAL(L.o1)[((size_t)n * L.Csrc + m1[j]) * L.HWo + p];
+                if (m2[j] >= 0) b = PLEAS_GLOBAL(L.o2)[((size_t)n * L.Csrc + m2[j]) * L.HWo + p];
+                const float dd = (o[e] + bias_v[j]) - (a + b) * coef;
                 sq = fmaf(dd, dd, sq);
-                L.resid[((size_t)n * L.Cout + co) * L.HWo + p] = L.dscale * dd;
+                PLEAS_GLOBAL_W(L.resid)[((size_t)n * L.Cout + co) * L.HWo + p] = L.dscale * dd;
             }
         }
     }
@@ -356,6 +404,7 @@ static int build_fwd_plan(FwdPlan& P, const pleas_fwd_layer* ly, int n) {
             return bad_arg("conv_fwd: layer geometry");
         const int Hout = (l.Hin + 2 * l.pad - l.KH) / l.stride + 1, Wout = (l.Win + 2 * l.pad - l.KW) / l.stride + 1;
         if (Hout <= 0 || Wout <= 0) return bad_arg("conv_fwd: empty output");
+        if (l.KH * l.KW > 64) return bad_arg("conv_fwd: kernels larger than 64 taps are not supported");
         const int64_t HWo = (int64_t)Hout * Wout, Ptot = (int64_t)l.N * HWo, Kd = (int64_t)l.Cin * l.KH * l.KW;
         if (Ptot >= (1ll << 31) || (int64_t)l.Cout * Kd >= (1ll << 32)) return bad_arg("conv_fwd: tensor too large");
         FwdLayerDev& d = P.layers[i];

@@ -107,16 +107,16 @@ __device__ __forceinline__ void gram_tile(const GramGeom& g, float* smem, const 
 #pragma unroll
         for (int q = 0; q < PASSES; ++q) {
             if constexpr (VEC == 4) {
-                const f32x4 va = *reinterpret_cast<const f32x4*>(g.x + base + row_off_a[q]);
-                const f32x4 vb = *reinterpret_cast<const f32x4*>(g.y + base + row_off_b[q]);
+                const f32x4 va = *(const __attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL(g.x) + base + row_off_a[q]);
+                const f32x4 vb = *(const __attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL(g.y) + base + row_off_b[q]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     ra.v[q][e] = va[e];
                     rb.v[q][e] = vb[e];
                 }
             } else {
-                ra.v[q][0] = g.x[base + row_off_a[q]];
-                rb.v[q][0] = g.y[base + row_off_b[q]];
+                ra.v[q][0] = PLEAS_GLOBAL(g.x)[base + row_off_a[q]];
+                rb.v[q][0] = PLEAS_GLOBAL(g.y)[base + row_off_b[q]];
             }
         }
     };
@@ -193,7 +193,7 @@ __device__ __forceinline__ void gram_tile(const GramGeom& g, float* smem, const 
     }
 
     // ---- partial tile -> workspace slab `split`
-    float* gp = g.gpart + (size_t)split * g.C * g.C;
+    gfloat* gp = PLEAS_GLOBAL_W(g.gpart) + (size_t)split * g.C * g.C;
 #pragma unroll
     for (int sm = 0; sm < MT; ++sm)
 #pragma unroll
@@ -216,8 +216,8 @@ __device__ __forceinline__ void gram_tile(const GramGeom& g, float* smem, const 
         }
         if ((tid % LANES_PER_ROW) == 0) {
             const int row = srow + q * ROWS_PER_PASS;
-            if (tn == 0 && i0 + row < g.C) g.npart[((size_t)split * 2 + 0) * g.C + i0 + row] = sa;
-            if (tm == 0 && j0 + row < g.C) g.npart[((size_t)split * 2 + 1) * g.C + j0 + row] = sb;
+            if (tn == 0 && i0 + row < g.C) PLEAS_GLOBAL_W(g.npart)[((size_t)split * 2 + 0) * g.C + i0 + row] = sa;
+            if (tm == 0 && j0 + row < g.C) PLEAS_GLOBAL_W(g.npart)[((size_t)split * 2 + 1) * g.C + j0 + row] = sb;
         }
     }
 }

@@ -96,16 +96,16 @@ __device__ __forceinline__ void neq_tile(const NeqLayerDev& L, const NeqItemDev&
 #pragma unroll
         for (int q = 0; q < PASS; ++q) {
             if constexpr (VEC == 4) {
-                const f32x4 va = *reinterpret_cast<const f32x4*>(L.ip + basea + offa[q]);
-                const f32x4 vb = *reinterpret_cast<const f32x4*>(L.ip + baseb + offb[q]);
+                const f32x4 va = *(const __attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL(L.ip) + basea + offa[q]);
+                const f32x4 vb = *(const __attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL(L.ip) + baseb + offb[q]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     ra[q][e] = va[e];
                     rb[q][e] = vb[e];
                 }
             } else {
-                ra[q][0] = L.ip[basea + offa[q]];
-                rb[q][0] = L.ip[baseb + offb[q]];
+                ra[q][0] = PLEAS_GLOBAL(L.ip)[basea + offa[q]];
+                rb[q][0] = PLEAS_GLOBAL(L.ip)[baseb + offb[q]];
             }
         }
     };
@@ -161,7 +161,7 @@ __device__ __forceinline__ void neq_tile(const NeqLayerDev& L, const NeqItemDev&
         __syncthreads();
     }
     // epilogue: S == 1 -> A += tile ; else tile -> this (slot, split) slab
-    float* slab = L.S > 1 ? L.slab + ((size_t)it.slot * L.S + it.split) * (T * T) : nullptr;
+    gfloat* slab = L.S > 1 ? PLEAS_GLOBAL_W(L.slab) + ((size_t)it.slot * L.S + it.split) * (T * T) : nullptr;
 #pragma unroll
     for (int sm = 0; sm < MT; ++sm)
 #pragma unroll
@@ -173,7 +173,7 @@ __device__ __forceinline__ void neq_tile(const NeqLayerDev& L, const NeqItemDev&
                 if (slab) {
                     slab[li * T + lj] = acc[sm][sn][r];
                 } else if (i0 + li < L.Cin && j0 + lj < L.Cin) {
-                    float* o = L.A + ((size_t)it.rx * L.Cin + i0 + li) * L.K + (size_t)it.ry * L.Cin + j0 + lj;
+                    gfloat* o = PLEAS_GLOBAL_W(L.A) + ((size_t)it.rx * L.Cin + i0 + li) * L.K + (size_t)it.ry * L.Cin + j0 + lj;
                     *o += acc[sm][sn][r];
                 }
             }
