@@ -310,9 +310,11 @@ def main():
                     "algorithmic_flop_per_launch": round(rec[2] / max(rec[0], 1)), "total_ms": round(rec[1], 2)}
 
         roofs = {k: roof(k) for k in labels}
-        tpath = os.path.join(ROOT, "profiles", "gram_traffic.json")
-        if os.path.exists(tpath):
-            roofs["gram_partial"]["traffic"] = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        # HBM-side bytes per launch from rocprofv3 PMC passes on standalone replays of the same grids (profiles/)
+        for key, fname in (("gram_partial", "gram_traffic.json"), ("conv_fwd", "fwd_traffic.json")):
+            tpath = os.path.join(ROOT, "profiles", fname)
+            if os.path.exists(tpath) and args.arch == "resnet101" and args.batch == 16:
+                roofs[key]["traffic"] = json.load(open(tpath)).get("hbm_bytes_per_launch")
         dominant = max(roofs, key=lambda k: roofs[k]["total_ms"])   # own kernel with the most time in the timed region
         roofline = roofs[dominant]
         other = {k: v for k, v in roofs.items() if k != dominant}
