@@ -338,3 +338,39 @@ def test_graph_captured_forwards_give_identical_results(tiny_bottleneck):
             assert torch.allclose(outs[0][k], outs[1][k], atol=2 * 5e-4 * 8)
         elif outs[0][k].dtype.is_floating_point:   # vendor convs may pick another algorithm under capture: rounding only
             assert _rel(outs[0][k], outs[1][k].cpu()) < 1e-5, k
+
+
+def test_config4_zip_budget_partial_merge_and_train_vs_oracle():
+    """configs[4]-style partial merge at ResNet-18 scale: zip ratios (budget 1.55: stages 3-4 stay separate, which makes
+    ODD merged widths 2n-1 = 511 / 1023), gradient masks with frozen blocks, two PLeaS updates.  HIP path vs CPU oracle."""
+    from pleas.core.compiler import get_permutation_spec
+    from pleas.methods.activation_matching import activation_matching
+    from pleas.methods.extras import zip_ratios
+    from pleas.methods.partial_matching import partial_merge
+    from pleas.methods.pleas_merging import train
+    from pleas_merging_amd import resnet as zoo
+
+    m1, m2 = _rn("resnet18", 0, 50).eval(), _rn("resnet18", 1, 50).eval()
+    g = torch.Generator().manual_seed(77)
+    data = [(torch.randn(4, 3, 64, 64, generator=g), torch.zeros(4)) for _ in range(4)]
+    zoo.calibrate_bn(m1, [d[0] for d in data])
+    zoo.calibrate_bn(m2, [d[0] for d in data])
+    spec = get_permutation_spec(m1, ((1, 3, 64, 64),))
+    ratios = zip_ratios(spec, 1.55, (1.0, 1.24, 1.55, 1.71, 2.0))
+    assert set(ratios.values()) == {0.0, 1.0}
+    g1, g2 = copy.deepcopy(m1).cuda(), copy.deepcopy(m2).cuda()
+    perm, costs = activation_matching(spec, g1, g2, data, 2, output_costs=True)
+    want_p, want_c = orc.activation_matching(spec, m1, m2, data, 2, accumulate=True)
+    for k in spec:
+        assert (perm[k] == want_p[k]).all(), k
+    m3 = partial_merge(spec, g1, g2, perm, costs, ratios)
+    o3 = orc.partial_merge(spec, m1, m2, want_p, want_c, ratios)
+    widths = {v.shape[0] for k, v in m3.state_dict().items() if k.endswith("conv1.weight")}
+    assert 511 in widths or 1023 in widths          # the odd widths really occur
+    for (k, a), (_, b) in zip(m3.state_dict().items(), o3.state_dict().items()):
+        assert a.shape == b.shape and torch.allclose(a, b, rtol=1e-6, atol=1e-7), k
+    m3 = train(data, g1, g2, m3, spec, perm, costs, ratios, False, 1, None, num_classes=50)
+    o3, _ = orc.train(data, m1, m2, o3, spec, want_p, want_c, ratios, 1, num_classes=50)
+    for (k, a), (_, b) in zip(m3.state_dict().items(), o3.state_dict().items()):
+        if k != DEGENERATE and a.dtype.is_floating_point:
+            assert _rel(a, b) < 1e-4, (k, _rel(a, b))
