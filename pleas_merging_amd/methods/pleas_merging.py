@@ -296,11 +296,12 @@ class PleasFitter:
         x = dp_slice(x, self.rank, self.world)
         self._run_sources(x)
         self._fwd_rows, self._vendor_wgrad, self._bias_grads = [], [], []
-        for idx, plan in enumerate(self.plans):
-            if plan.name not in self.tap1.inputs or plan.name not in self.tap2.inputs:
-                print("Key error on %s" % plan.name)
-                continue
-            self._fit_layer(idx, plan)
+        with self.ops.pin_stream():
+            for idx, plan in enumerate(self.plans):
+                if plan.name not in self.tap1.inputs or plan.name not in self.tap2.inputs:
+                    print("Key error on %s" % plan.name)
+                    continue
+                self._fit_layer(idx, plan)
         if self._fwd_rows:   # ONE grouped MFMA launch: forward + target + residual + loss of every merged layer
             if self._fwd_loss is None or self._fwd_loss.numel() != len(self._fwd_rows):
                 self._fwd_loss = torch.zeros(len(self._fwd_rows), dtype=torch.float32, device=self.device)
