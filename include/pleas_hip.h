@@ -120,6 +120,21 @@ int pleas_merge_blocks(const float* w1, const float* w2, float* out, int64_t out
                        const int32_t* col1, const int32_t* col2, int n_merged_rows, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Frozen-source forward: inference BatchNorm (+ residual add) (+ ReLU) in one pass.
+ *
+ * Replaces: the BatchNorm2d -> (out += identity) -> ReLU module chain inside `model1(x); model2(x)`
+ *   (pleas/methods/pleas_merging.py:267-268, models put in eval() at :352-353): three vendor
+ *   kernels and seven tensor passes per chain become one kernel, one read (two with a residual)
+ *   and one write.
+ *
+ * x, res (nullable), y: [n][channels][inner] contiguous fp32;  scale[c] = weight[c] / sqrt(var[c] + eps),
+ * shift[c] = bias[c] - mean[c] * scale[c]  (DEVICE, prepared once by the caller).
+ *   y = x * scale[c] + shift[c] (+ res);   relu != 0 applies max(., 0).   y must not alias x.
+ */
+int pleas_bn_act(const float* x, const float* scale, const float* shift, const float* res, float* y, int64_t n,
+                 int channels, int64_t inner, int relu, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Fused masked Adam step over a flat parameter arena.
  *
  * Replaces: pleas/methods/pleas_merging.py:288-291 (`param.grad *= mask` for every
@@ -235,11 +250,12 @@ int pleas_cholesky_solve_batched(float* const* A, float* const* Bt, const int* K
  * Opt-in live timing of the library's kernels with HIP events recorded on the launch stream
  * (used by bench.py for the roofline figure; off by default, no cost when off).
  * kernel ids: 0 gram_partial, 1 gram_finalize, 2 lsap, 3 merge_blocks, 4 masked_adam, 5 sqerr,
- *             6 conv_fwd, 7 conv_wgrad, 8 normal_eq, 9 solve.
+ *             6 conv_fwd, 7 conv_wgrad, 8 normal_eq, 9 solve, 10 bn_act.
  * pleas_prof_collect waits for the recorded events of that kernel and returns the number of
  * launches, their summed duration, and the summed ALGORITHMIC flops / bytes of those launches.
  */
 void pleas_prof_enable(int on);
+void pleas_prof_select(unsigned kernel_mask); /* bit k: record kernel id k (default all); many-launch kernels can be left out */
 void pleas_prof_reset(void);
 int pleas_prof_collect(int kernel, int64_t* launches, double* total_ms, double* flops, double* bytes);
 

@@ -25,12 +25,14 @@ SIGNATURES = {
     "pleas_lsap_batched": (c_int, [POINTER(c_void_p), POINTER(c_int), c_int, c_int, POINTER(c_void_p), c_void_p]),
     "pleas_merge_blocks": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int, c_int, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "pleas_bn_act": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_void_p]),
     "pleas_masked_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
                                   c_float, c_int, c_void_p]),
     "pleas_sqerr_ws_bytes": (c_size_t, [c_int64]),
     "pleas_sqerr": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_int, c_void_p, c_float, c_void_p, c_void_p, c_size_t,
                             c_void_p]),
     "pleas_prof_enable": (None, [c_int]),
+    "pleas_prof_select": (None, [ctypes.c_uint]),
     "pleas_prof_reset": (None, []),
     "pleas_prof_collect": (c_int, [c_int, POINTER(c_int64), POINTER(ctypes.c_double), POINTER(ctypes.c_double),
                                    POINTER(ctypes.c_double)]),
@@ -81,7 +83,7 @@ class GramNode(ctypes.Structure):
     _fields_ = [("x", c_void_p), ("y", c_void_p), ("B", c_int), ("C", c_int), ("HW", c_int64), ("group", c_int)]
 
 PROF_KERNELS = ["gram_partial", "gram_finalize", "lsap", "merge_blocks", "masked_adam", "sqerr", "conv_fwd",
-                "conv_wgrad", "normal_eq", "solve"]
+                "conv_wgrad", "normal_eq", "solve", "bn_act"]
 
 
 class PleasHipError(RuntimeError):

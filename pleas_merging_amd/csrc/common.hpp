@@ -48,15 +48,16 @@ typedef __attribute__((address_space(1))) const int gcint;
 
 // ---- opt-in per-kernel timing with HIP events on the launch stream (pleas_prof_* in the C-ABI)
 enum ProfKernel { kProfGramPartial = 0, kProfGramFinalize, kProfLsap, kProfMergeBlocks, kProfMaskedAdam, kProfSqerr,
-                  kProfConvFwd, kProfConvWgrad, kProfNormalEq, kProfSolve, kProfCount };
+                  kProfConvFwd, kProfConvWgrad, kProfNormalEq, kProfSolve, kProfBnAct, kProfCount };
 extern bool g_prof_on;
+extern unsigned g_prof_mask;   // bit k set: kernel id k is recorded while profiling is on
 void prof_begin(int kernel, double flops, double bytes, hipStream_t stream);
 void prof_end(hipStream_t stream);
 
 struct ProfScope {
     hipStream_t s;
     bool on;
-    ProfScope(int kernel, double flops, double bytes, hipStream_t stream) : s(stream), on(g_prof_on) {
+    ProfScope(int kernel, double flops, double bytes, hipStream_t stream) : s(stream), on(g_prof_on && ((g_prof_mask >> kernel) & 1u)) {
         if (on) prof_begin(kernel, flops, bytes, s);
     }
     ~ProfScope() {

@@ -14,6 +14,7 @@ thread_local char g_last_error[256] = "";
 
 // ---- profiling records: one (start, stop) event pair per profiled launch, resolved at collect time
 bool g_prof_on = false;
+unsigned g_prof_mask = ~0u;
 struct ProfRec {
     hipEvent_t a, b;
     int kernel;
@@ -116,6 +117,41 @@ __global__ __launch_bounds__(kEwThreads) void merge_blocks_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// Inference BatchNorm folded to one affine map per channel, optional residual add, optional ReLU:
+//   y[n][c][i] = act(x[n][c][i] * scale[c] + shift[c] (+ res[n][c][i]))
+// One pass over x (and res), one write: replaces the vendor BN + in-place add + in-place ReLU chain
+// (3 kernels, 7 tensor passes) of a frozen source model.  `inner_v` = HW / VEC.
+template <int VEC>
+__global__ __launch_bounds__(kEwThreads) void bn_act_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift,
+                                                            const float* __restrict__ res, float* __restrict__ y,
+                                                            int64_t total_v, unsigned inner_v, unsigned channels,
+                                                            int relu) {
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total_v;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned row = (unsigned)(idx / inner_v);   // n * channels + c  (< 2^31, checked by the host)
+        const unsigned c = row % channels;
+        const float a = scale[c], b = shift[c];
+        if constexpr (VEC == 4) {
+            const f32x4 q = reinterpret_cast<const f32x4*>(x)[idx];
+            f32x4 r = {0.f, 0.f, 0.f, 0.f};
+            if (res) r = reinterpret_cast<const f32x4*>(res)[idx];
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = fmaf(q[e], a, b) + r[e];
+                o[e] = relu ? fmaxf(t, 0.f) : t;
+            }
+            reinterpret_cast<f32x4*>(y)[idx] = o;
+        } else {
+            const float t = fmaf(x[idx], a, b) + (res ? res[idx] : 0.f);
+            y[idx] = relu ? fmaxf(t, 0.f) : t;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kEwThreads) void masked_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                                  const float* __restrict__ mask, float* __restrict__ m,
                                                                  float* __restrict__ v, int64_t n, float one_minus_b1,
@@ -183,6 +219,8 @@ extern "C" const char* pleas_last_error(void) { return g_last_error; }
 
 extern "C" void pleas_prof_enable(int on) { g_prof_on = on != 0; }
 
+extern "C" void pleas_prof_select(unsigned kernel_mask) { g_prof_mask = kernel_mask; }
+
 extern "C" void pleas_prof_reset(void) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto& r : g_prof_recs) {
@@ -231,6 +269,26 @@ extern "C" int pleas_merge_blocks(const float* w1, const float* w2, float* out, 
         hipLaunchKernelGGL((merge_blocks_kernel<1>), dim3(ew_grid(total)), dim3(kEwThreads), 0, stream, w1, w2, out,
                            outer, rows_out, cols_out, inner, rows_src, cols_src, row1, row2, col1, col2, n_merged_rows);
     PLEAS_LAUNCH_CHECK("merge_blocks_kernel");
+    return PLEAS_OK;
+}
+
+extern "C" int pleas_bn_act(const float* x, const float* scale, const float* shift, const float* res, float* y,
+                            int64_t n, int channels, int64_t inner, int relu, void* stream_) {
+    if (!x || !scale || !shift || !y) return bad_arg("null pointer");
+    if (n < 0 || channels <= 0 || inner <= 0) return bad_arg("negative size");
+    const int64_t total = n * channels * inner;
+    if (total == 0) return PLEAS_OK;
+    if (n * channels >= ((int64_t)1 << 31) || inner >= ((int64_t)1 << 31)) return bad_arg("tensor too large");
+    hipStream_t stream = (hipStream_t)stream_;
+    const bool vec = inner % 4 == 0 && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) & 15) == 0);
+    ProfScope prof(kProfBnAct, 0.0, (res ? 3.0 : 2.0) * total * sizeof(float), stream);
+    if (vec)
+        hipLaunchKernelGGL((bn_act_kernel<4>), dim3(ew_grid(total / 4)), dim3(kEwThreads), 0, stream, x, scale, shift, res,
+                           y, total / 4, (unsigned)(inner / 4), (unsigned)channels, relu);
+    else
+        hipLaunchKernelGGL((bn_act_kernel<1>), dim3(ew_grid(total)), dim3(kEwThreads), 0, stream, x, scale, shift, res, y,
+                           total, (unsigned)inner, (unsigned)channels, relu);
+    PLEAS_LAUNCH_CHECK("bn_act_kernel");
     return PLEAS_OK;
 }
 

@@ -24,7 +24,10 @@
 
 namespace pleas {
 
-constexpr int kLsapThreads = 256;
+#ifndef PLEAS_LSAP_THREADS
+#define PLEAS_LSAP_THREADS 256
+#endif
+constexpr int kLsapThreads = PLEAS_LSAP_THREADS;
 constexpr int kLsapWaves = kLsapThreads / 64;
 constexpr int kMaxBatch = 128;
 

@@ -211,6 +211,29 @@ def hip_solve_lsa(A: torch.Tensor, maximize: bool = True) -> torch.Tensor:
     return solve_lsa_batched([A], maximize)[0].cpu()
 
 
+# ---------------------------------------------------------------------------------------- bn + add + relu
+def bn_act(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, res: Optional[torch.Tensor] = None,
+           relu: bool = True) -> torch.Tensor:
+    """``act(x * scale[c] + shift[c] (+ res))`` over dim 1 of a contiguous fp32 tensor: inference BatchNorm,
+    residual add and ReLU of a frozen source model in one pass (``pleas_bn_act``)."""
+    _need_gpu(x, scale, shift)
+    if x.dim() < 2 or x.dtype != torch.float32:
+        raise PleasHipError("bn_act needs an fp32 [N, C, ...] tensor")
+    x = x.contiguous()
+    if res is not None:
+        if res.shape != x.shape or res.dtype != torch.float32:
+            raise PleasHipError("bn_act: residual shape/dtype differs from x")
+        res = res.contiguous()
+    C = x.shape[1]
+    if scale.numel() != C or shift.numel() != C or not scale.is_contiguous() or not shift.is_contiguous():
+        raise PleasHipError("bn_act: scale/shift must be contiguous with one entry per channel")
+    y = torch.empty_like(x)
+    rc = _lib.lib().pleas_bn_act(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), res.data_ptr() if res is not None else None,
+                                 y.data_ptr(), x.shape[0], C, math.prod(x.shape[2:]), int(relu), _stream())
+    _lib.check(rc, "pleas_bn_act")
+    return y
+
+
 # ---------------------------------------------------------------------------------------- merge blocks
 def merge_blocks(w1: torch.Tensor, w2: torch.Tensor, row_axis: int, row1: torch.Tensor, row2: torch.Tensor,
                  n_merged_rows: int, col1: Optional[torch.Tensor] = None, col2: Optional[torch.Tensor] = None,
@@ -488,7 +511,13 @@ def cholesky_solve_batched(As: Sequence[torch.Tensor], Bts: Sequence[torch.Tenso
 
 
 # ---------------------------------------------------------------------------------------- live kernel timing
-def profile_enable(on: bool) -> None:
+def profile_enable(on: bool, skip: Sequence[str] = ()) -> None:
+    """``skip``: kernel names left unrecorded (the two events per launch are not free for kernels that run
+    hundreds of times per step, e.g. ``bn_act`` / ``merge_blocks``)."""
+    mask = 0xFFFFFFFF
+    for name in skip:
+        mask &= ~(1 << _lib.PROF_KERNELS.index(name))
+    _lib.lib().pleas_prof_select(mask)
     _lib.lib().pleas_prof_enable(int(bool(on)))
 
 

@@ -157,7 +157,7 @@ class PleasFitter:
 
     def __init__(self, model1, model2, model3, spec, perm, costs, budget_ratios, max_steps: int, lr: float = 5e-4,
                  separate_classifier=False, num_classes=1000, model_type="rn50", data_parallel: bool = False,
-                 forward: str = "hip", graph_sources: bool = False):
+                 forward: str = "hip", graph_sources: bool = False, fuse_sources: bool = True):
         from .. import hip_ops
         from .activation_matching import _dist_info
 
@@ -174,6 +174,14 @@ class PleasFitter:
         self.tap1, self.tap2 = ActivationTap(model1), ActivationTap(model2)
         model1.eval()
         model2.eval()
+        # the frozen sources run with BatchNorm (+ residual add) + ReLU folded into one HIP pass; the hooked
+        # Conv2d / Linear modules are shared, so the taps see the same tensors (source_forward.py)
+        self.src1, self.src2 = model1, model2
+        if fuse_sources:
+            from .source_forward import fuse_bn_act
+
+            self.src1 = fuse_bn_act(model1) or model1
+            self.src2 = fuse_bn_act(model2) or model2
 
         layers = {n: m for n, m in model3.named_modules() if isinstance(m, (nn.Conv2d, nn.Linear))}
         self.layer_modules = layers
@@ -327,8 +335,8 @@ class PleasFitter:
     def _run_sources(self, x: torch.Tensor) -> None:
         """Both source forwards; hooks fill the taps.  Graph path: capture on the 3rd call with this input shape."""
         if not self.graph_sources:
-            self.model1(x)
-            self.model2(x)
+            self.src1(x)
+            self.src2(x)
             return
         if self._src_graph is not None and self._x_static.shape == x.shape:
             self._x_static.copy_(x)
@@ -336,8 +344,8 @@ class PleasFitter:
             return
         self._eager_calls = getattr(self, "_eager_calls", 0) + 1
         if self._eager_calls < 3 or self._src_graph is not None:   # warm up (vendor algorithm search, allocator)
-            self.model1(x)
-            self.model2(x)
+            self.src1(x)
+            self.src2(x)
             return
         try:
             self.tap1.clear()
@@ -346,16 +354,16 @@ class PleasFitter:
             graph = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
             with torch.cuda.graph(graph):
-                self.model1(self._x_static)
-                self.model2(self._x_static)
+                self.src1(self._x_static)
+                self.src2(self._x_static)
             graph.replay()
             self._src_graph = graph
         except Exception as exc:  # noqa: BLE001 -- capture is an optimisation; eager is always valid
             print("pleas: source-forward graph capture unavailable (%s); running eagerly" % (exc,))
             self.graph_sources = False
             self._src_graph = None
-            self.model1(x)
-            self.model2(x)
+            self.src1(x)
+            self.src2(x)
 
     def finish(self) -> nn.Module:
         """Write the fitted weights back into ``model3`` and drop the hooks (reference :392-403)."""

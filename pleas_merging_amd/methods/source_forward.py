@@ -1,0 +1,113 @@
+"""Frozen source forwards with BatchNorm / residual add / ReLU folded into one HIP pass.
+
+The PLeaS loop runs ``model1(x); model2(x)`` under forward hooks on every Conv2d / Linear
+(reference pleas/methods/pleas_merging.py:267-268; both models in ``eval()``, :352-353).  Only the
+hooked layers' inputs and outputs are consumed, so everything between two hooked layers is free to
+be fused.  ``fuse_bn_act`` rewrites an fx trace of the model:
+
+    bn(x) -> relu                      =>  bn_act(x, scale, shift, None, relu=True)
+    bn(x) -> (+ identity) -> relu      =>  bn_act(x, scale, shift, identity, relu=True)
+    bn(x)                              =>  bn_act(x, scale, shift, None, relu=False)
+
+``scale = weight / sqrt(running_var + eps)`` and ``shift = bias - running_mean * scale`` are computed
+once in fp64.  The hooked modules are the SAME objects in the rewritten GraphModule, so hooks
+registered on the original model keep firing; conv outputs are never written in place.
+Values differ from the vendor BN kernel by fp32 rounding only (one fma instead of sub-mul-mul-add).
+"""
+from __future__ import annotations
+
+import operator
+from typing import Callable, Optional
+
+import torch
+import torch.fx
+import torch.nn.functional as F
+from torch import nn
+
+from .. import hip_ops
+
+
+def _bn_act(x, scale, shift, res, relu):
+    return hip_ops.bn_act(x, scale, shift, res, relu)
+
+
+def _is_relu(node: torch.fx.Node, mods) -> bool:
+    if node.op == "call_module":
+        return isinstance(mods[node.target], nn.ReLU)
+    if node.op == "call_function":
+        return node.target in (F.relu, torch.relu, torch.relu_)
+    if node.op == "call_method":
+        return node.target in ("relu", "relu_")
+    return False
+
+
+def _is_add(node: torch.fx.Node) -> bool:
+    if node.kwargs:
+        return False
+    if node.op == "call_function" and node.target in (operator.add, operator.iadd, torch.add):
+        return len(node.args) == 2 and all(isinstance(a, torch.fx.Node) for a in node.args)
+    if node.op == "call_method" and node.target in ("add", "add_"):
+        return len(node.args) == 2 and all(isinstance(a, torch.fx.Node) for a in node.args)
+    return False
+
+
+def _foldable(bn: nn.Module) -> bool:
+    return (isinstance(bn, nn.BatchNorm2d) and not bn.training and bn.running_mean is not None
+            and bn.running_var is not None and bn.running_mean.dtype == torch.float32)
+
+
+def fuse_bn_act(model: nn.Module, op: Callable = _bn_act) -> Optional[torch.fx.GraphModule]:
+    """fx copy of ``model`` (sharing its submodules) with every eval-mode BatchNorm2d chain replaced by
+    ``op(x, scale, shift, residual_or_None, relu)`` -- the HIP kernel ``hip_ops.bn_act`` unless a test
+    passes its own.  Returns None when the model cannot be traced or holds nothing to fold; the caller
+    then runs the model as it is (vendor kernels)."""
+    try:
+        gm = torch.fx.symbolic_trace(model)
+    except Exception:  # noqa: BLE001 -- untraceable control flow: nothing to rewrite
+        return None
+    mods = dict(gm.named_modules())
+    graph = gm.graph
+    folded = 0
+    for node in list(graph.nodes):
+        if node.op != "call_module" or not _foldable(mods.get(node.target)):
+            continue
+        if len(node.args) != 1 or node.kwargs:
+            continue
+        bn = mods[node.target]
+        with torch.no_grad():
+            var = bn.running_var.double()
+            w = bn.weight.double() if bn.weight is not None else torch.ones_like(var)
+            b = bn.bias.double() if bn.bias is not None else torch.zeros_like(var)
+            scale64 = w / torch.sqrt(var + bn.eps)
+            shift64 = b - bn.running_mean.double() * scale64
+        tag = node.name
+        gm.register_buffer("_pleas_scale_%s" % tag, scale64.float().contiguous(), persistent=False)
+        gm.register_buffer("_pleas_shift_%s" % tag, shift64.float().contiguous(), persistent=False)
+
+        chain, res, relu = [node], None, False
+        users = list(node.users)
+        if len(users) == 1 and _is_relu(users[0], mods):
+            chain.append(users[0])
+            relu = True
+        elif len(users) == 1 and _is_add(users[0]) and users[0].args[0] is not users[0].args[1]:
+            add = users[0]
+            add_users = list(add.users)
+            if len(add_users) == 1 and _is_relu(add_users[0], mods):
+                res = add.args[1] if add.args[0] is node else add.args[0]
+                chain += [add, add_users[0]]
+                relu = True
+        last = chain[-1]
+        with graph.inserting_before(last):
+            s = graph.get_attr("_pleas_scale_%s" % tag)
+            t = graph.get_attr("_pleas_shift_%s" % tag)
+            fused = graph.call_function(op, (node.args[0], s, t, res, relu))
+        last.replace_all_uses_with(fused)
+        for dead in reversed(chain):
+            graph.erase_node(dead)
+        folded += 1
+    if folded == 0:
+        return None
+    graph.lint()
+    gm.recompile()
+    gm.train(model.training)
+    return gm

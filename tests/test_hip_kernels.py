@@ -184,6 +184,41 @@ def test_merge_blocks_one_axis_activation(ops):
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("shape", [(3, 16, 8, 8), (2, 7, 7, 7), (4, 64, 14, 14), (1, 5, 3, 1)])
+@pytest.mark.parametrize("with_res,relu", [(False, True), (True, True), (False, False)])
+def test_bn_act_matches_eval_batchnorm(ops, shape, with_res, relu):
+    """Folded inference BN (+ residual) (+ ReLU) vs the torch fp32 module chain (tolerance: fp32 rounding of the fold)."""
+    g = torch.Generator().manual_seed(31)
+    C = shape[1]
+    bn = torch.nn.BatchNorm2d(C).eval()
+    bn.running_mean.copy_(torch.randn(C, generator=g))
+    bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+    bn.weight.data.copy_(torch.rand(C, generator=g) + 0.5)
+    bn.bias.data.copy_(torch.randn(C, generator=g))
+    x, res = torch.randn(shape, generator=g), torch.randn(shape, generator=g)
+    with torch.no_grad():
+        want = bn(x) + (res if with_res else 0)
+        want = torch.relu(want) if relu else want
+    scale = (bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps))
+    shift = (bn.bias.double() - bn.running_mean.double() * scale).float().cuda()
+    got = ops.bn_act(x.cuda(), scale.float().cuda(), shift, res.cuda() if with_res else None, relu).cpu()
+    assert got.shape == want.shape
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-5)
+    if relu:
+        assert (got >= 0).all()
+
+
+def test_bn_act_rejects_bad_operands(ops):
+    x = torch.randn(2, 4, 3, 3).cuda()
+    s = torch.ones(4).cuda()
+    with pytest.raises(ops.PleasHipError):
+        ops.bn_act(x, s[:3], s)
+    with pytest.raises(ops.PleasHipError):
+        ops.bn_act(x, s, s, torch.randn(2, 4, 3, 2).cuda())
+    with pytest.raises(ops.PleasHipError):
+        ops.bn_act(x.cpu(), s, s)
+
+
 def test_masked_adam_matches_torch(ops):
     g = torch.Generator().manual_seed(5)
     p0 = torch.randn(1000, generator=g)

@@ -340,6 +340,40 @@ def test_graph_captured_forwards_give_identical_results(tiny_bottleneck):
             assert _rel(outs[0][k], outs[1][k].cpu()) < 1e-5, k
 
 
+def test_fused_source_forwards_match_module_forwards(tiny_bottleneck):
+    """BN + add + ReLU folded into one HIP pass (default) vs the sources run module by module: same taps up to the
+    fp32 rounding of the fold, same fitted weights within the training tolerance."""
+    from pleas.methods.partial_matching import partial_merge
+    from pleas.methods.pleas_merging import PleasFitter
+
+    t = tiny_bottleneck
+    m1, m2 = _cuda_pair(t)
+    data = t.batches()
+    perm = t.per_key("am_perm")
+    costs = {k: v.cuda() for k, v in t.per_key("am_cost").items()}
+    outs, taps = [], []
+    for fuse in (False, True):
+        m3 = partial_merge(t.spec, m1, m2, perm, costs, 0.5)
+        fit = PleasFitter(m1, m2, m3, t.spec, perm, costs, 0.5, 3, num_classes=10, fuse_sources=fuse)
+        assert (fit.src1 is not m1) == fuse and (fit.src2 is not m2) == fuse
+        fit._run_sources(data[0][0].cuda())
+        taps.append(({k: v.clone() for k, v in fit.tap1.inputs.items()}, {k: v.clone() for k, v in fit.tap2.outputs.items()}))
+        fit.tap1.clear()
+        fit.tap2.clear()
+        for x, _ in data:
+            fit.step(x)
+        outs.append({k: v.clone() for k, v in fit.finish().state_dict().items()})
+    assert set(taps[0][0]) == set(taps[1][0]) and len(taps[0][0]) > 5
+    for k in taps[0][0]:
+        assert _rel(taps[0][0][k].cpu(), taps[1][0][k].cpu()) < 1e-5, k
+        assert _rel(taps[0][1][k].cpu(), taps[1][1][k].cpu()) < 1e-5, k
+    for k in outs[0]:
+        if k == DEGENERATE:
+            assert torch.allclose(outs[0][k], outs[1][k], atol=2 * 5e-4 * 4)
+        elif outs[0][k].dtype.is_floating_point:
+            assert _rel(outs[0][k], outs[1][k].cpu()) < 1e-4, k
+
+
 def test_config4_zip_budget_partial_merge_and_train_vs_oracle():
     """configs[4]-style partial merge at ResNet-18 scale: zip ratios (budget 1.55: stages 3-4 stay separate, which makes
     ODD merged widths 2n-1 = 511 / 1023), gradient masks with frozen blocks, two PLeaS updates.  HIP path vs CPU oracle."""

@@ -257,3 +257,40 @@ def test_reset_bn_stats_matches_driver_procedure(tiny_basic):
     assert got.training
     for (k, a), (_, b) in zip(got.state_dict().items(), ref.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_source_forward_rewrite_keeps_values_and_hooks(tiny_bottleneck):
+    """fx rewrite of the frozen sources (BN -> [+identity] -> ReLU => one op): checked on CPU with a torch stand-in
+    for the HIP op -- same logits, same hooked conv inputs/outputs, no BatchNorm/ReLU module call left."""
+    from pleas_merging_amd.methods.source_forward import fuse_bn_act
+
+    def op(x, s, t, res, relu):
+        y = x * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)
+        y = y if res is None else y + res
+        return torch.relu(y) if relu else y
+
+    import copy
+
+    model = copy.deepcopy(tiny_bottleneck.m1).eval()
+    gm = fuse_bn_act(model, op)
+    assert gm is not None
+    mods = dict(gm.named_modules())
+    calls = [n for n in gm.graph.nodes if n.op == "call_function" and n.target is op]
+    assert any(n.args[3] is not None for n in calls) and any(not n.args[4] for n in calls)
+    assert not [n for n in gm.graph.nodes
+                if n.op == "call_module" and isinstance(mods[n.target], (torch.nn.BatchNorm2d, torch.nn.ReLU))]
+    seen = {}
+    handles = [m.register_forward_hook(lambda m, i, o, n=n: seen.setdefault(n, []).append((i[0].clone(), o.clone())))
+               for n, m in model.named_modules() if isinstance(m, (torch.nn.Conv2d, torch.nn.Linear))]
+    x = tiny_bottleneck.batches()[0][0]
+    with torch.no_grad():
+        a, b = model(x), gm(x)
+    for h in handles:
+        h.remove()
+    assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
+    for name, (first, second) in seen.items():
+        assert torch.allclose(first[0], second[0], rtol=1e-4, atol=1e-5), name
+        assert torch.allclose(first[1], second[1], rtol=1e-4, atol=1e-5), name
+    model.train()
+    assert fuse_bn_act(model, op) is None   # training-mode BN updates running stats: never folded
+    model.eval()

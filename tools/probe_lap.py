@@ -2,6 +2,9 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 from scipy.optimize import linear_sum_assignment
+from pleas_merging_amd import _lib
+if os.environ.get('PLEAS_LIB'):
+    _lib.LIB_PATH = os.environ['PLEAS_LIB']; print('lib', _lib.LIB_PATH)
 from pleas_merging_amd import hip_ops
 rng = np.random.default_rng(0)
 def cd(n):

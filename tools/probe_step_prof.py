@@ -14,14 +14,15 @@ perm = make_identity_perm(spec); costs = {k: torch.eye(g.size, device=dev) for k
 x = torch.randn(B, 3, 224, 224, device=dev)
 for fwd in sys.argv[1:] or ["hip", "vendor"]:
     m3 = partial_merge(spec, m1, m2, perm, costs, 0.0)
-    fit = PleasFitter(m1, m2, m3, spec, perm, costs, 0.0, 400, forward=fwd)
+    fuse = not fwd.endswith(":nofuse"); fwd = fwd.split(":")[0]
+    fit = PleasFitter(m1, m2, m3, spec, perm, costs, 0.0, 400, forward=fwd, fuse_sources=fuse)
     for _ in range(3): fit.step(x)
     torch.cuda.synchronize(); hip_ops.profile_reset(); hip_ops.profile_enable(True)
     t0 = time.time()
     for _ in range(20): fit.step(x)
     torch.cuda.synchronize(); dt = (time.time() - t0) / 20
     hip_ops.profile_enable(False); p = hip_ops.profile_collect()
-    print("forward=%s: step %.2f ms" % (fwd, dt * 1e3))
+    print("forward=%s fuse_sources=%s: step %.2f ms" % (fwd, fuse, dt * 1e3))
     for k, v in p.items():
         print("   %-14s %6d launches %7.3f ms/step %s" % (k, v[0], v[1] / 20, ("%.1f TF/s" % (v[2] / (v[1] * 1e-3) / 1e12)) if v[2] else ""))
     fit.finish()
