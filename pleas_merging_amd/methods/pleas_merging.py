@@ -157,7 +157,8 @@ class PleasFitter:
 
     def __init__(self, model1, model2, model3, spec, perm, costs, budget_ratios, max_steps: int, lr: float = 5e-4,
                  separate_classifier=False, num_classes=1000, model_type="rn50", data_parallel: bool = False,
-                 forward: str = "hip", graph_sources: bool = False, fuse_sources: bool = True):
+                 forward: str = "hip", graph_sources: bool = False, fuse_sources: bool = True,
+                 overlap_sources: bool = True):
         from .. import hip_ops
         from .activation_matching import _dist_info
 
@@ -182,6 +183,10 @@ class PleasFitter:
 
             self.src1 = fuse_bn_act(model1) or model1
             self.src2 = fuse_bn_act(model2) or model2
+
+        # the two source forwards are independent chains of small kernels (one conv of a batch-16 ResNet fills a
+        # fraction of 256 CUs): model2 runs on a second HIP stream next to model1, joined before the taps are read
+        self._side_stream = torch.cuda.Stream(self.device) if overlap_sources else None
 
         layers = {n: m for n, m in model3.named_modules() if isinstance(m, (nn.Conv2d, nn.Linear))}
         self.layer_modules = layers
@@ -335,8 +340,7 @@ class PleasFitter:
     def _run_sources(self, x: torch.Tensor) -> None:
         """Both source forwards; hooks fill the taps.  Graph path: capture on the 3rd call with this input shape."""
         if not self.graph_sources:
-            self.src1(x)
-            self.src2(x)
+            self._run_sources_eager(x)
             return
         if self._src_graph is not None and self._x_static.shape == x.shape:
             self._x_static.copy_(x)
@@ -364,6 +368,24 @@ class PleasFitter:
             self._src_graph = None
             self.src1(x)
             self.src2(x)
+
+    def _run_sources_eager(self, x: torch.Tensor) -> None:
+        side = self._side_stream
+        if side is None:
+            with self.ops.pin_stream():
+                self.src1(x)
+                self.src2(x)
+            return
+        main = torch.cuda.current_stream(self.device)
+        # model2's tensors live in the side stream's allocator pool.  They are consumed on `main` (this update) and
+        # released by the host at the end of the update; the side stream re-uses them only after this wait, i.e.
+        # after every consumer enqueued on `main` so far -- no record_stream bookkeeping needed.
+        side.wait_stream(main)
+        with torch.cuda.stream(side), self.ops.pin_stream():
+            self.src2(x)
+        with self.ops.pin_stream():
+            self.src1(x)
+        main.wait_stream(side)
 
     def finish(self) -> nn.Module:
         """Write the fitted weights back into ``model3`` and drop the hooks (reference :392-403)."""
