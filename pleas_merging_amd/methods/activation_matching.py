@@ -40,12 +40,71 @@ _register_fused()
 
 
 # ------------------------------------------------------------------------------------------ twin graph
+def _out_of_place(twin: torch.fx.Graph, node: torch.fx.Node, lookup: Callable, submods) -> Optional[torch.fx.Node]:
+    """Out-of-place twin of an in-place op (same values, new tensor), or None when ``node`` is not one.
+    Deferred sinks read tracked activations after the forward, so nothing may overwrite them."""
+    import operator
+
+    import torch.nn.functional as F
+
+    if node.op == "call_module" and isinstance(submods[node.target], nn.ReLU) and submods[node.target].inplace:
+        return twin.call_function(torch.relu, (lookup(node.args[0]),))
+    if node.op == "call_function":
+        if node.target is operator.iadd:
+            return twin.call_function(operator.add, tuple(torch.fx.node.map_arg(node.args, lookup)))
+        if node.target is torch.relu_ or (node.target is F.relu and (node.kwargs.get("inplace") or
+                                                                    (len(node.args) > 1 and node.args[1]))):
+            return twin.call_function(torch.relu, (lookup(node.args[0]),))
+    if node.op == "call_method" and node.target in ("relu_", "add_") and not node.kwargs:
+        return twin.call_method(node.target[:-1], tuple(torch.fx.node.map_arg(node.args, lookup)))
+    return None
+
+
+class _SideStream:
+    """Stream fork/join calls placed in a split twin graph: model2's chain is enqueued on a second HIP
+    stream, model1's on the caller's stream, and the caller's stream waits for both before the sinks run.
+    Side-stream tensors are consumed on the caller's stream and re-used by the side stream only after the
+    next ``fork`` (which waits for everything enqueued on the caller's stream) -- no record_stream needed."""
+
+    def __init__(self, device: torch.device):
+        self.side = torch.cuda.Stream(device)
+        self.main = None
+
+        def fork(x):
+            self.main = torch.cuda.current_stream(x.device)
+            self.side.wait_stream(self.main)
+            torch.cuda.set_stream(self.side)
+            return x
+
+        def back():
+            torch.cuda.set_stream(self.main)
+
+        def join():
+            self.main.wait_stream(self.side)
+
+        fork.__name__ = fork.__qualname__ = "pleas_stream_fork"
+        back.__name__ = back.__qualname__ = "pleas_stream_back"
+        join.__name__ = join.__qualname__ = "pleas_stream_join"
+        self.fork, self.back, self.join = fork, back, join
+
+    def restore(self):
+        """After an exception inside the graph: make the caller's stream current again."""
+        if self.main is not None:
+            torch.cuda.set_stream(self.main)
+
+
 def _build_twin(model1: nn.Module, model2: nn.Module, axes: Iterable[Axis], emit: Callable,
-                keep_inputs: bool = False):
+                keep_inputs: bool = False, side_stream: Optional[_SideStream] = None):
     """Twin graph of ``model1``/``model2``; ``emit(graph, name, axis, node1, node2)`` adds the call
     made right after tracked node ``name`` and returns the fx node that holds its value.
     ``keep_inputs`` runs in-place activations out of place (same values, new tensor), so that tracked
-    activations stay intact until the end of the forward pass."""
+    activations stay intact until the end of the forward pass.
+    ``side_stream`` (needs ``keep_inputs``): instead of interleaving the two models node by node, emit model2's
+    whole chain on the side stream, then model1's chain, then join and only then the ``emit`` calls."""
+    if side_stream is not None:
+        if not keep_inputs:
+            raise ValueError("a split twin graph defers its sinks: it needs keep_inputs=True")
+        return _build_split_twin(model1, model2, axes, emit, side_stream)
     traced = torch.fx.symbolic_trace(model1)
     submods = dict(traced.named_modules())
     want: Dict[str, List[int]] = {}
@@ -67,11 +126,9 @@ def _build_twin(model1: nn.Module, model2: nn.Module, axes: Iterable[Axis], emit
             result = ([env[0][ret], env[1][ret]], cross)
             continue
         made = []
-        inplace_act = (keep_inputs and node.op == "call_module" and isinstance(submods[node.target], nn.ReLU)
-                       and submods[node.target].inplace)
         for side in (0, 1):
-            if inplace_act:
-                new = twin.call_function(torch.relu, (env[side][node.args[0]],))
+            new = _out_of_place(twin, node, lambda n, side=side: env[side][n], submods) if keep_inputs else None
+            if new is not None:
                 env[side][node] = new
                 made.append(new)
                 continue
@@ -83,6 +140,53 @@ def _build_twin(model1: nn.Module, model2: nn.Module, axes: Iterable[Axis], emit
         for a in want.get(node.name, ()):
             cross[node.name, a] = emit(twin, node.name, a, made[0], made[1])
     twin.output(result)
+    gm = torch.fx.GraphModule(nn.ModuleList([model1, model2]), twin)
+    gm.graph.lint()
+    return gm
+
+
+def _build_split_twin(model1: nn.Module, model2: nn.Module, axes: Iterable[Axis], emit: Callable, streams: _SideStream):
+    traced = torch.fx.symbolic_trace(model1)
+    submods = dict(traced.named_modules())
+    want: Dict[str, List[int]] = {}
+    for ax in axes:
+        if ax.axis not in want.setdefault(ax.key, []):
+            want[ax.key].append(ax.axis)
+    twin = torch.fx.Graph()
+    env = ({}, {})
+    shared = {}
+    for node in traced.graph.nodes:
+        if node.op == "placeholder":
+            shared[node] = twin.placeholder(node.target)
+    ret = None
+    for side in (1, 0):           # model2 first: its kernels are already queued on the side stream while model1 is enqueued
+        first = True
+        for node in traced.graph.nodes:
+            if node.op == "placeholder":
+                env[side][node] = shared[node]
+                if side == 1 and first:   # fork on the first input: the side stream waits for it, then becomes current
+                    env[side][node] = twin.call_function(streams.fork, (shared[node],))
+                    first = False
+                continue
+            if node.op == "output":
+                (ret,) = node.args
+                continue
+            new = _out_of_place(twin, node, lambda n, side=side: env[side][n], submods)
+            if new is not None:
+                env[side][node] = new
+                continue
+            new = twin.node_copy(node, lambda n, side=side: env[side][n])
+            if node.op in ("call_module", "get_attr"):
+                new.target = "%d.%s" % (side, node.target)
+            env[side][node] = new
+        if side == 1:
+            twin.call_function(streams.back, ())
+    twin.call_function(streams.join, ())
+    cross: Dict[Tuple[str, int], torch.fx.Node] = {}
+    for node in traced.graph.nodes:
+        for a in want.get(node.name, ()) if node.op not in ("placeholder", "output") else ():
+            cross[node.name, a] = emit(twin, node.name, a, env[0][node], env[1][node])
+    twin.output(([env[0][ret], env[1][ret]], cross))
     gm = torch.fx.GraphModule(nn.ModuleList([model1, model2]), twin)
     gm.graph.lint()
     return gm
@@ -146,12 +250,15 @@ class _FusedSink:
 
 
 def build_fused_module(spec: PermutationSpec, model1: nn.Module, model2: nn.Module, arena: GroupArena, epilogue: int,
-                       grouped: bool = True):
-    """Twin graph whose sinks feed the group arena (the HIP fast path).  Returns (module, sinks)."""
+                       grouped: bool = True, overlap: bool = False):
+    """Twin graph whose sinks feed the group arena (the HIP fast path).  Returns (module, sinks).
+    ``overlap`` (grouped only): model2's forward runs on a second HIP stream next to model1's."""
     node_group = {nax: key for key, group in spec.items() for nax in group.node}
     sinks = _FusedSink(arena, node_group, epilogue, grouped)
+    sinks.streams = _SideStream(arena.flat.device) if (overlap and grouped) else None
     gm = _build_twin(model1, model2, list(node_group.keys()),
-                     lambda g, name, a, n1, n2: g.call_function(sinks.bind(name), (n1, n2, a)), keep_inputs=grouped)
+                     lambda g, name, a, n1, n2: g.call_function(sinks.bind(name), (n1, n2, a)), keep_inputs=grouped,
+                     side_stream=sinks.streams)
     return gm, sinks
 
 
@@ -224,7 +331,8 @@ def compute_matching_costs(spec: PermutationSpec, gm_cross: nn.Module, dataloade
 
 def accumulate_costs_fused(spec: PermutationSpec, model1: nn.Module, model2: nn.Module, dataloader, num_batches: int,
                            epilogue: int, accumulate=True, shard: bool = True,
-                           grouped: bool = True, graph_forward: bool = False) -> Dict[Axis, torch.Tensor]:
+                           grouped: bool = True, graph_forward: bool = False,
+                           overlap: bool = True) -> Dict[Axis, torch.Tensor]:
     """HIP fast path: every tracked node adds into its group matrix while the forwards run.
 
     Data parallel: with ``torch.distributed`` initialised (one process per GPU, RCCL), rank r
@@ -236,7 +344,8 @@ def accumulate_costs_fused(spec: PermutationSpec, model1: nn.Module, model2: nn.
     if device.type != "cuda":
         raise RuntimeError("activation_matching: models must be on the GPU for the HIP path (got %s)" % device)
     arena = GroupArena(spec, device)
-    gm, sinks = build_fused_module(spec, model1, model2, arena, epilogue, grouped)
+    gm, sinks = build_fused_module(spec, model1, model2, arena, epilogue, grouped,
+                                   overlap=overlap and grouped and not graph_forward)
     rank, world = _dist_info() if (shard and accumulate is True) else (0, 1)
     # graph_forward=True (opt-in): after two eager batches (vendor warm-up) the whole twin forward (~1400 launches)
     # is captured into ONE hipGraph and replayed per batch on a static input; the sinks' tensors are then fixed
@@ -269,7 +378,12 @@ def accumulate_costs_fused(spec: PermutationSpec, model1: nn.Module, model2: nn.
                     print("pleas: twin-forward graph capture unavailable (%s); running eagerly" % (exc,))
                     use_graph, graph = False, None
                     sinks.batch.drop()
-            gm(x)
+            try:
+                gm(x)
+            except BaseException:
+                if sinks.streams is not None:
+                    sinks.streams.restore()
+                raise
             eager_seen += 1
             if sinks.batch is not None:
                 sinks.batch.flush(accumulate=True)

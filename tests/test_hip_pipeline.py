@@ -184,6 +184,22 @@ def test_grouped_equals_per_node_launches(tiny_bottleneck):
         assert _rel(ca[k], cb[k]) < 1e-6 and (pa[k] == pb[k]).all()
 
 
+def test_two_stream_twin_forward_equals_interleaved(tiny_bottleneck):
+    """Matching with model2's chain on a second HIP stream (default) vs the node-by-node interleaved twin graph."""
+    from pleas_merging_amd import hip_ops
+    from pleas_merging_amd.methods.activation_matching import accumulate_costs_fused
+
+    t = tiny_bottleneck
+    m1, m2 = _cuda_pair(t)
+    data = t.batches() + t.batches()
+    main = torch.cuda.current_stream()
+    a = accumulate_costs_fused(t.spec, m1, m2, data, 8, hip_ops.EPI_NEG_CDIST, overlap=False)
+    b = accumulate_costs_fused(t.spec, m1, m2, data, 8, hip_ops.EPI_NEG_CDIST, overlap=True)
+    assert torch.cuda.current_stream() == main
+    for k in t.spec:
+        assert torch.equal(a[k], b[k]), k
+
+
 def _layer_objective(t, m3, ratio, perm, costs, batches):
     """Reference objective sum_layers mean((L(ip) - op)^2) summed over batches, on the CPU oracle."""
     blocks = orc.spread_blocks(t.spec, orc.get_blocks(t.spec, perm, costs, ratio))

@@ -294,3 +294,79 @@ def test_source_forward_rewrite_keeps_values_and_hooks(tiny_bottleneck):
     model.train()
     assert fuse_bn_act(model, op) is None   # training-mode BN updates running stats: never folded
     model.eval()
+
+
+def test_split_twin_graph_defers_sinks_and_keeps_inplace_targets(tiny_bottleneck):
+    """The two-stream twin graph (model2's chain, then model1's, then the sinks) sees the same activations as the
+    interleaved one -- also for a model that overwrites tracked tensors in place (``out += identity``, ``relu_``)."""
+    import importlib
+
+    am = importlib.import_module("pleas_merging_amd.methods.activation_matching")
+
+    class Streams:   # stand-in for _SideStream on a machine without a GPU
+        def __init__(self):
+            self.log = []
+
+            def fork(x):
+                self.log.append("fork")
+                return x
+
+            def back():
+                self.log.append("back")
+
+            def join():
+                self.log.append("join")
+
+            for f in (fork, back, join):
+                f.__qualname__ = f.__name__
+            self.fork, self.back, self.join = fork, back, join
+
+    def emitter(store):
+        def emit(g, name, a, n1, n2):
+            def sink(x, y, a, _n=name):
+                store[_n, a] = (x.clone(), y.clone())
+
+            sink.__name__ = sink.__qualname__ = "sink_" + name
+            return g.call_function(sink, (n1, n2, a))
+
+        return emit
+
+    class InPlace(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c1, self.c2 = torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.Conv2d(4, 4, 3, padding=1)
+            self.act = torch.nn.ReLU(inplace=True)
+
+        def forward(self, x):
+            a = self.act(self.c1(x))
+            b = self.c2(a)
+            b += a
+            return b.relu_()
+
+    t = tiny_bottleneck
+    cases = [(t.m1, t.m2, [nax for g in t.spec.values() for nax in g.node], t.batches()[0][0])]
+    torch.manual_seed(0)
+    cases.append((InPlace(), InPlace(), [Axis("c1", 1), Axis("c2", 1), Axis("act", 1)], torch.randn(2, 3, 6, 6)))
+    for m1, m2, axes, x in cases:
+        inter, split, streams = {}, {}, Streams()
+        with torch.no_grad():
+            am._build_twin(m1, m2, axes, emitter(inter), keep_inputs=True)(x)
+            out = am._build_twin(m1, m2, axes, emitter(split), keep_inputs=True, side_stream=streams)(x)
+            want = (m1(x.clone()), m2(x.clone()))
+        assert streams.log == ["fork", "back", "join"]
+        assert torch.equal(out[0][0], want[0]) and torch.equal(out[0][1], want[1])
+        assert set(inter) == set(split) and len(split) == len(set(axes))
+        for k in inter:
+            assert torch.equal(inter[k][0], split[k][0]) and torch.equal(inter[k][1], split[k][1]), k
+    # the in-place model: what the sinks saw is what a hook would have seen right after each node
+    seen = {}
+    m1, m2, axes, x = cases[1]
+    hooks = [m1.c1.register_forward_hook(lambda m, i, o: seen.__setitem__("c1", o.clone())),
+             m1.c2.register_forward_hook(lambda m, i, o: seen.__setitem__("c2", o.clone()))]
+    with torch.no_grad():
+        m1(x)
+    for h in hooks:
+        h.remove()
+    assert torch.equal(split["c1", 1][0], seen["c1"]) and torch.equal(split["c2", 1][0], seen["c2"])
+    with pytest.raises(ValueError):
+        am._build_twin(m1, m2, axes, emitter({}), keep_inputs=False, side_stream=Streams())
