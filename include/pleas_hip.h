@@ -184,7 +184,7 @@ int pleas_sqerr(const float* a, const float* b, int64_t n, float scale, int accu
  */
 typedef struct pleas_fwd_layer {
     const float* ip;     /* [N][Cin][Hin][Win] merged input */
-    const float* w;      /* [Cout][Cin][KH][KW] */
+    const float* w;      /* [Cout][Cin][KH][KW], or [Cout][KH][KW][Cin] with PLEAS_FWD_KPOS_MAJOR */
     const float* bias;   /* [Cout] or NULL */
     const float* o1;     /* [N][Csrc][Hout*Wout] source-layer outputs */
     const float* o2;
@@ -193,7 +193,12 @@ typedef struct pleas_fwd_layer {
     float* resid;        /* [N][Cout][Hout*Wout] */
     int N, Cout, Cin, Hin, Win, KH, KW, stride, pad, Csrc, n_merged;
     float dscale, loss_scale;
+    int flags;           /* PLEAS_FWD_* */
 } pleas_fwd_layer;
+/* Weights stored kernel-position-major (the layout pleas_wgrad_batch writes with PLEAS_WGRAD_KPOS_MAJOR); needs
+ * Cin % 32 == 0.  Every 32-deep K chunk then has ONE tap: per-thread addressing is as cheap as for a 1x1 layer and
+ * the taps of a channel block re-read the same input rows back to back. */
+#define PLEAS_FWD_KPOS_MAJOR 1
 size_t pleas_fwd_batch_ws_bytes(const pleas_fwd_layer* layers, int n_layers);
 int pleas_fwd_batch(const pleas_fwd_layer* layers, int n_layers, float* loss, void* ws, size_t ws_bytes, int ws_fresh,
                     void* stream);

@@ -62,7 +62,7 @@ class FwdLayer(ctypes.Structure):
     _fields_ = [("ip", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("o1", c_void_p), ("o2", c_void_p),
                 ("row1", c_void_p), ("row2", c_void_p), ("resid", c_void_p), ("N", c_int), ("Cout", c_int), ("Cin", c_int),
                 ("Hin", c_int), ("Win", c_int), ("KH", c_int), ("KW", c_int), ("stride", c_int), ("pad", c_int),
-                ("Csrc", c_int), ("n_merged", c_int), ("dscale", c_float), ("loss_scale", c_float)]
+                ("Csrc", c_int), ("n_merged", c_int), ("dscale", c_float), ("loss_scale", c_float), ("flags", c_int)]
 
 
 class NeqLayer(ctypes.Structure):

@@ -33,6 +33,9 @@ namespace pleas {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef PLEAS_FWD_ABLATE
+#define PLEAS_FWD_ABLATE 0   // experiments only (tools/hipbench/run_fwd_ablate.sh): 1 no target gathers, 2 no epilogue,
+#endif                       // 4 no input-operand loads, 8 no weight loads, 16 per-item cycle stamps (pleas_fwd_debug_read)
 constexpr int fBK = 32;
 constexpr int fLdsA = 36;    // W tile rows: [TM][36]   (k contiguous)
 constexpr int fLdsB = 36;    // U tile rows: [128 pixels][36] (k contiguous: a thread's 16 k values of its pixel are one run)
@@ -51,7 +54,7 @@ struct FwdLayerDev {
     int Cout, Cin, Hin, Win, Hout, Wout, KH, KW, stride, pad, Csrc, n_merged;
     uint32_t HWo, Ptot, Kd;
     float dscale;         // 2 / (numel * world)
-    int variant;          // bit0: TM == 64, bit1: scalar W loads
+    int variant;          // bit0: TM == 64, bit1: scalar W loads, bit2: W is kernel-position-major [Cout][KH*KW][Cin]
     int part_base;        // first loss-partial slot of this layer
     int pad0;
 };
@@ -59,18 +62,27 @@ struct FwdItemDev {
     int layer, tm, tp, slot;  // slot: loss-partial index
 };
 
+#if (PLEAS_FWD_ABLATE & 16)
+__device__ long long g_fwd_stamps[32768][4];   // per work item: prologue, K loop, epilogue cycles, chunks
+#define PLEAS_FWD_STAMP(var) const long long var = clock64()
+#else
+#define PLEAS_FWD_STAMP(var)
+#endif
+
 template <int TM, int VECA>
 __device__ __forceinline__ void fwd_tile(const FwdLayerDev& L, const FwdItemDev& it, float* smem, float* __restrict__ partials) {
     constexpr int MTM = TM / 64;
     constexpr int LPR = fBK / VECA, RPP = fThreads / LPR, PASS = TM / RPP;
     float* As = smem;                      // [2][TM][fLdsA]
     float* Bs = smem + 2 * TM * fLdsA;     // [2][fTN][fLdsB]
+    PLEAS_FWD_STAMP(st0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int i0 = it.tm * TM;
     const uint32_t p0 = (uint32_t)it.tp * fTN;
     const uint32_t HWi = (uint32_t)L.Hin * L.Win;
     const int R = L.KH * L.KW;
+    const bool kpos = (L.variant & 4) != 0;
     const int nchunks = (int)((L.Kd + fBK - 1) / fBK);
 
     // ---- A (weights) staging: rows co, k contiguous
@@ -115,12 +127,17 @@ __device__ __forceinline__ void fwd_tile(const FwdLayerDev& L, const FwdItemDev&
 
     auto load_chunk = [&](int c) {
         {
-            const uint32_t k = (uint32_t)c * fBK + acol;
+            // kernel-position-major weights: chunk c = (channel block c / R, tap c % R); its 32 k values sit at
+            // [tap][block * 32 ..] of the weight row
+            const uint32_t k = kpos ? (uint32_t)(c % R) * L.Cin + (uint32_t)(c / R) * fBK + acol : (uint32_t)c * fBK + acol;
             kina = k < L.Kd;
             const uint32_t kc = kina ? k : 0u;
 #pragma unroll
             for (int q = 0; q < PASS; ++q) {
-                if constexpr (VECA == 4) {
+                if constexpr ((PLEAS_FWD_ABLATE & 8) != 0) {
+#pragma unroll
+                    for (int e = 0; e < VECA; ++e) ra[q][e] = (float)(kc + e);
+                } else if constexpr (VECA == 4) {
                     const f32x4 v = *(const __attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL(L.w) + offa[q] + kc);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ra[q][e] = v[e];
@@ -135,15 +152,24 @@ __device__ __forceinline__ void fwd_tile(const FwdLayerDev& L, const FwdItemDev&
             // zeroed when the tile is written to LDS.
             const uint32_t k = (uint32_t)c * fBK + bhalf * 16;
             okb = 0;
-            if (R == 1) {   // 1x1 (also Linear): k is the input channel, the tap is the pixel itself
-                const bool inside = pin && ih0 >= 0 && ih0 < L.Hin && iw0 >= 0 && iw0 < L.Win;
-                const size_t tap = pbase + (size_t)(inside ? ih0 * L.Win + iw0 : 0);
+            if (R == 1 || kpos) {
+                // ONE tap per chunk (1x1 / Linear, or kernel-position-major weights: channel block c / R, tap c % R; the
+                // taps of a channel block run back to back, so their shifted re-reads of the same input rows hit L1/L2).
+                // Per thread: one masked base offset per chunk; per load: + a wave-uniform channel offset.
+                const int cb = kpos ? c / R : c;
+                const int r = kpos ? c - cb * R : 0;
+                const int kh = r / L.KW, kw = r - kh * L.KW;
+                const bool ok_tap = (tapmask >> r) & 1ull;
+                const uint32_t ch0 = (uint32_t)cb * fBK + bhalf * 16;
+                const long long voff = ok_tap ? (long long)pbase + pixoff + (kh * L.Win + kw) : 0ll;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
-                    const bool ok = inside && (k + q) < L.Kd;
+                    const uint32_t ch = ch0 + q;
+                    const bool ok = ok_tap && ch < (uint32_t)L.Cin;
                     okb |= (ok ? 1u : 0u) << q;
-                    const size_t off = (tap + (size_t)(k + q) * HWi) & (size_t)(-(long long)ok);
-                    rb[q] = PLEAS_GLOBAL(L.ip)[off];
+                    const long long lin = (long long)min(ch, (uint32_t)L.Cin - 1u) * HWi;   // scalar; masked lanes read ip[lin]
+                    if constexpr ((PLEAS_FWD_ABLATE & 4) != 0) rb[q] = (float)((voff + lin) & 7); else
+                    rb[q] = PLEAS_GLOBAL(L.ip)[voff + lin];
                 }
             } else {
                 // general kernel: the tap validity of this thread's pixel is a precomputed bit mask and its pixel
@@ -157,6 +183,7 @@ __device__ __forceinline__ void fwd_tile(const FwdLayerDev& L, const FwdItemDev&
                     okb |= (ok ? 1u : 0u) << q;
                     const long long lin = (long long)ci * HWi + kh * L.Win + kw;   // scalar
                     const size_t off = (size_t)((long long)pbase + pixoff + lin) & (size_t)(-(long long)ok);
+                    if constexpr ((PLEAS_FWD_ABLATE & 4) != 0) rb[q] = (float)(off & 7); else
                     rb[q] = PLEAS_GLOBAL(L.ip)[off];
                     ++r;
                     ++kw;
@@ -216,6 +243,7 @@ __device__ __forceinline__ void fwd_tile(const FwdLayerDev& L, const FwdItemDev&
     load_chunk(0);
     store_chunk(0);
     __syncthreads();
+    PLEAS_FWD_STAMP(st1);
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
         const bool more = c + 1 < nchunks;
@@ -224,31 +252,46 @@ __device__ __forceinline__ void fwd_tile(const FwdLayerDev& L, const FwdItemDev&
         if (more) store_chunk(buf ^ 1);
         __syncthreads();
     }
+    PLEAS_FWD_STAMP(st2);
 
     // ---- epilogue.  Accumulators hold one pixel per lane; go through LDS once ([co][pixel], stride 132) so that
     //      each thread then owns 4 consecutive pixels of one output channel: 16-B target gathers, 16-B residual stores.
+    if constexpr ((PLEAS_FWD_ABLATE & 2) != 0) {   // keep the accumulators alive with one store per wave
+        float s = 0.f;
+#pragma unroll
+        for (int sm = 0; sm < MTM; ++sm)
+#pragma unroll
+            for (int sn = 0; sn < 2; ++sn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc[sm][sn][r];
+        if (s == 12345.678f) partials[L.part_base + it.slot] = s;
+        return;
+    }
     constexpr int EL = 132;
     float* Ct = smem;  // [TM][EL] floats <= the staging buffers just released by the last barrier of the K loop
+    auto spill_acc = [&]() {
 #pragma unroll
-    for (int sm = 0; sm < MTM; ++sm)
+        for (int sm = 0; sm < MTM; ++sm)
 #pragma unroll
-        for (int sn = 0; sn < 2; ++sn)
+            for (int sn = 0; sn < 2; ++sn)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int lco = wm * (TM / 2) + sm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                Ct[lco * EL + wn * 64 + sn * 32 + (lane & 31)] = acc[sm][sn][r];
-            }
-    __syncthreads();
+                for (int r = 0; r < 16; ++r) {
+                    const int lco = wm * (TM / 2) + sm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    Ct[lco * EL + wn * 64 + sn * 32 + (lane & 31)] = acc[sm][sn][r];
+                }
+        __syncthreads();
+    };
     float sq = 0.f;
     const bool vec_ok = (L.HWo % 4 == 0);   // then a 4-pixel group never straddles samples and is 16-B aligned
     const int pg = (tid & 31) * 4;           // pixel group of this thread
     const uint32_t Pg = p0 + pg;
     const bool gin = Pg < L.Ptot;
     const uint32_t gn = gin ? Pg / L.HWo : 0u, gp = gin ? Pg - gn * L.HWo : 0u;
-    // Each thread owns TM/8 output channels (lco = tid/32 + 8 j) x 4 pixels.  All map / bias loads are issued first,
-    // then the target gathers in batches of 4 channels, branch-free (absent or out-of-range rows read element 0 and are
-    // masked), so the loads of a batch are in flight together instead of one dependent chain per channel.
-    constexpr int ROWS = TM / 8;
+    // Each thread owns TM/8 output channels (lco = tid/32 + 8 j) x 4 pixels.  Order, chosen so that global-memory latency
+    // is exposed once instead of once per step: block maps + bias -> first batch of target gathers (8 channels, branch
+    // free: absent / out-of-range rows read element 0 and are masked) -> accumulators through LDS (the gathers are in
+    // flight meanwhile) -> second batch issued -> first consumed -> second consumed.
+    constexpr int ROWS = TM / 8, GB = 8, NB = ROWS / GB;
     int m1[ROWS], m2[ROWS];
     float bias_v[ROWS];
 #pragma unroll
@@ -259,20 +302,26 @@ __device__ __forceinline__ void fwd_tile(const FwdLayerDev& L, const FwdItemDev&
         bias_v[j] = L.bias ? PLEAS_GLOBAL(L.bias)[co] : 0.f;
     }
     if (vec_ok) {
+        f32x4 ta[NB][GB], tb[NB][GB];
+        auto gather = [&](const int bt) {
 #pragma unroll
-        for (int jb = 0; jb < ROWS; jb += 4) {
-            f32x4 ta[4], tb[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = jb + u;
+            for (int u = 0; u < GB; ++u) {
+                const int j = bt * GB + u;
                 const size_t oa = (((size_t)gn * L.Csrc + max(m1[j], 0)) * L.HWo + gp) & (size_t)(-(long long)(gin && m1[j] >= 0));
                 const size_t ob = (((size_t)gn * L.Csrc + max(m2[j], 0)) * L.HWo + gp) & (size_t)(-(long long)(gin && m2[j] >= 0));
-                ta[u] = *(const __attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL(L.o1) + oa);
-                tb[u] = *(const __attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL(L.o2) + ob);
+                if constexpr ((PLEAS_FWD_ABLATE & 1) != 0) {
+                    ta[bt][u] = f32x4{(float)(oa & 3), 0.f, 0.f, 0.f};
+                    tb[bt][u] = f32x4{(float)(ob & 3), 0.f, 0.f, 0.f};
+                } else {
+                    ta[bt][u] = *(const __attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL(L.o1) + oa);
+                    tb[bt][u] = *(const __attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL(L.o2) + ob);
+                }
             }
+        };
+        auto consume = [&](const int bt) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = jb + u;
+            for (int u = 0; u < GB; ++u) {
+                const int j = bt * GB + u;
                 const int lco = (tid >> 5) + 8 * j, co = i0 + lco;
                 const bool live = gin && co < L.Cout;
                 const float coef = co < L.n_merged ? 0.5f : 1.0f;
@@ -281,14 +330,20 @@ __device__ __forceinline__ void fwd_tile(const FwdLayerDev& L, const FwdItemDev&
                 f32x4 d;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float dd = (o[e] + bias_v[j]) - (ta[u][e] * fa + tb[u][e] * fb) * coef;
+                    const float dd = (o[e] + bias_v[j]) - (ta[bt][u][e] * fa + tb[bt][u][e] * fb) * coef;
                     sq = live ? fmaf(dd, dd, sq) : sq;
                     d[e] = L.dscale * dd;
                 }
                 if (live) *(__attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL_W(L.resid) + ((size_t)gn * L.Cout + co) * L.HWo + gp) = d;
             }
-        }
+        };
+        gather(0);
+        spill_acc();
+        if constexpr (NB > 1) gather(1);
+        consume(0);
+        if constexpr (NB > 1) consume(1);
     } else {
+        spill_acc();
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) {
             const int lco = (tid >> 5) + 8 * j, co = i0 + lco;
@@ -315,6 +370,15 @@ __device__ __forceinline__ void fwd_tile(const FwdLayerDev& L, const FwdItemDev&
     if (lane == 0) smem[wave] = sq;
     __syncthreads();
     if (tid == 0) partials[L.part_base + it.slot] = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+#if (PLEAS_FWD_ABLATE & 16)
+    if (tid == 0 && blockIdx.x < 32768) {
+        const long long st3 = clock64();
+        g_fwd_stamps[blockIdx.x][0] = st1 - st0;
+        g_fwd_stamps[blockIdx.x][1] = st2 - st1;
+        g_fwd_stamps[blockIdx.x][2] = st3 - st2;
+        g_fwd_stamps[blockIdx.x][3] = nchunks * 1000 + TM;
+    }
+#endif
 }
 
 __global__ __launch_bounds__(fThreads) void fwd_batch_kernel(const FwdLayerDev* __restrict__ layers,
@@ -323,7 +387,7 @@ __global__ __launch_bounds__(fThreads) void fwd_batch_kernel(const FwdLayerDev* 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const FwdItemDev it = items[blockIdx.x];
     const FwdLayerDev L = layers[it.layer];
-    switch (L.variant) {
+    switch (L.variant & 3) {
         case 0: fwd_tile<128, 4>(L, it, smem, partials); break;
         case 1: fwd_tile<64, 4>(L, it, smem, partials); break;
         case 2: fwd_tile<128, 1>(L, it, smem, partials); break;
@@ -414,6 +478,10 @@ static int build_fwd_plan(FwdPlan& P, const pleas_fwd_layer* ly, int n) {
         d.dscale = l.dscale;
         const int TM = l.Cout > 64 ? 128 : 64;
         d.variant = (TM == 64 ? 1 : 0) | (Kd % 4 == 0 ? 0 : 2);
+        if (l.flags & PLEAS_FWD_KPOS_MAJOR) {
+            if (l.Cin % fBK != 0) return bad_arg("conv_fwd: kernel-position-major weights need Cin % 32 == 0");
+            d.variant |= 4;
+        }
         d.part_base = parts;
         const int tms = (int)ceil_div(l.Cout, TM), tps = (int)ceil_div(Ptot, fTN);
         int slot = 0;
@@ -451,6 +519,13 @@ static int build_fwd_plan(FwdPlan& P, const pleas_fwd_layer* ly, int n) {
 
 using namespace pleas;
 
+#if (PLEAS_FWD_ABLATE & 16)
+extern "C" int pleas_fwd_debug_read(long long* out, int n_items) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fwd_stamps), sizeof(long long) * 4 * (size_t)std::min(n_items, 32768)) == hipSuccess
+               ? 0 : 1;
+}
+#endif
+
 extern "C" size_t pleas_fwd_batch_ws_bytes(const pleas_fwd_layer* layers, int n_layers) {
     if (!layers || n_layers <= 0) return 0;
     FwdPlan tmp;
@@ -474,7 +549,8 @@ extern "C" int pleas_fwd_batch(const pleas_fwd_layer* layers, int n_layers, floa
     key.push_back((int64_t)(uintptr_t)ws);
     for (int i = 0; i < n_layers; ++i) {
         const pleas_fwd_layer& l = layers[i];
-        for (int v : {l.N, l.Cout, l.Cin, l.Hin, l.Win, l.KH, l.KW, l.stride, l.pad, l.Csrc, l.n_merged}) key.push_back(v);
+        for (int v : {l.N, l.Cout, l.Cin, l.Hin, l.Win, l.KH, l.KW, l.stride, l.pad, l.Csrc, l.n_merged, l.flags})
+            key.push_back(v);
         int32_t bits[2];
         std::memcpy(&bits[0], &l.dscale, 4);
         std::memcpy(&bits[1], &l.loss_scale, 4);

@@ -346,8 +346,10 @@ class FwdBatch:
         self._ws = None
         self._fresh = 1
 
+    KPOS_MAJOR = 1   # w is [Cout][KH][KW][Cin] (needs Cin % 32 == 0)
+
     def add(self, ip, w, bias, o1, o2, row1, row2, n_merged: int, resid, dscale: float, loss_scale: float,
-            kernel=(1, 1), stride: int = 1, pad: int = 0) -> None:
+            kernel=(1, 1), stride: int = 1, pad: int = 0, flags: int = 0) -> None:
         for t in (ip, w, o1, o2, resid):
             if not t.is_contiguous():
                 raise PleasHipError("FwdBatch.add: contiguous tensors expected")
@@ -355,7 +357,7 @@ class FwdBatch:
         Hin, Win = (ip.shape[2], ip.shape[3]) if ip.dim() == 4 else (1, 1)
         self._keep.append((ip, w, bias, o1, o2, row1, row2, resid))
         self._geo.append((N, w.shape[0], Cin, Hin, Win, kernel[0], kernel[1], stride, pad, o1.shape[1], int(n_merged),
-                          float(dscale), float(loss_scale)))
+                          float(dscale), float(loss_scale), int(flags)))
 
     def flush(self, loss: torch.Tensor) -> None:
         n = len(self._keep)
@@ -371,7 +373,7 @@ class FwdBatch:
             a.ip, a.w, a.bias = ip.data_ptr(), w.data_ptr(), (bias.data_ptr() if bias is not None else None)
             a.o1, a.o2, a.row1, a.row2, a.resid = o1.data_ptr(), o2.data_ptr(), row1.data_ptr(), row2.data_ptr(), resid.data_ptr()
             (a.N, a.Cout, a.Cin, a.Hin, a.Win, a.KH, a.KW, a.stride, a.pad, a.Csrc, a.n_merged, a.dscale,
-             a.loss_scale) = geo
+             a.loss_scale, a.flags) = geo
         lib = _lib.lib()
         if self._ws is None:
             need = int(lib.pleas_fwd_batch_ws_bytes(self._arr, n))

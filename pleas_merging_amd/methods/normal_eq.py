@@ -124,7 +124,10 @@ class NormalEqFitter(PleasFitter):
             A = self.A[idx]
             A = torch.tril(A) + torch.tril(A, -1).t()          # kernels fill the lower triangle only
             Bt = self.Bt[idx]
-            if len(plan.w_shape) == 4:
+            if plan.kpos:                                      # the arena already holds [Cout][KH][KW][Cin]
+                to_kpos = lambda t, co=co, K=K: t.reshape(co, K)
+                from_kpos = lambda t, shp=tuple(plan.w.shape): t.reshape(shp)
+            elif len(plan.w_shape) == 4:
                 cin, r = plan.w_shape[1], plan.w_shape[2] * plan.w_shape[3]
                 to_kpos = lambda t, co=co, cin=cin, r=r, K=K: t.reshape(co, cin, r).permute(0, 2, 1).reshape(co, K)
                 from_kpos = lambda t, co=co, cin=cin, r=r, shp=plan.w_shape: \

@@ -64,6 +64,12 @@ def get_gradient_mask(perm_blocks, model_weights: Dict[str, nn.Module]) -> List[
     return masks
 
 
+def _square_conv(mod: nn.Conv2d) -> bool:
+    """Geometry the grouped HIP kernels take: dense, undilated, square kernel / stride / padding."""
+    return (mod.groups == 1 and mod.dilation == (1, 1) and mod.stride[0] == mod.stride[1]
+            and mod.padding[0] == mod.padding[1] and mod.kernel_size[0] == mod.kernel_size[1])
+
+
 class ActivationTap:
     """Forward hooks on every Conv2d / Linear / LayerNorm of a model that keep the module's
     input and output of the latest forward (reference keeps inputs only, :197-231)."""
@@ -115,7 +121,7 @@ def cosine_lrs(base_lr: float, t_max: int, n: int) -> List[float]:
 
 # ------------------------------------------------------------------------------------------ per-layer plan
 class _LayerPlan:
-    __slots__ = ("name", "mod", "is_conv", "w", "b", "gw", "gb", "in_maps", "out_maps", "w_shape", "off_w")
+    __slots__ = ("name", "mod", "is_conv", "w", "b", "gw", "gb", "in_maps", "out_maps", "w_shape", "off_w", "kpos")
 
 
 def _identity_block(n: int):
@@ -205,11 +211,18 @@ class PleasFitter:
             plan = _LayerPlan()
             plan.name, plan.mod, plan.is_conv = name, mod, isinstance(mod, nn.Conv2d)
             plan.b = plan.gb = None
+            # k x k convolutions with Cin % 32 == 0 keep their weight (gradient, mask, Adam state) KERNEL-POSITION-MAJOR
+            # [Cout][KH][KW][Cin] in the arenas: the fused forward then has one tap per K chunk, the weight-gradient
+            # kernel writes that layout directly, and the elementwise optimiser does not care (finish() permutes back)
+            plan.kpos = bool(forward == "hip" and plan.is_conv and _square_conv(mod) and mod.kernel_size[0] > 1
+                             and mod.weight.shape[1] % 32 == 0)   # the tensor's width: module attributes may be stale
             for pname, prm in mod.named_parameters():
                 n = prm.numel()
-                self.p[off:off + n].copy_(prm.detach().reshape(-1))
-                self.mask[off:off + n].copy_(masks[k].reshape(-1))
-                view, gview = self.p[off:off + n].view(prm.shape), self.g[off:off + n].view(prm.shape)
+                kp = plan.kpos and pname == "weight"
+                shape = (prm.shape[0], prm.shape[2], prm.shape[3], prm.shape[1]) if kp else tuple(prm.shape)
+                self.p[off:off + n].copy_((prm.detach().permute(0, 2, 3, 1) if kp else prm.detach()).reshape(-1))
+                self.mask[off:off + n].copy_((masks[k].permute(0, 2, 3, 1) if kp else masks[k]).reshape(-1))
+                view, gview = self.p[off:off + n].view(shape), self.g[off:off + n].view(shape)
                 if pname == "weight":
                     plan.w, plan.gw, plan.w_shape, plan.off_w = view, gview, tuple(prm.shape), off
                 else:
@@ -260,14 +273,14 @@ class PleasFitter:
         cout = plan.w_shape[0]
         if cout != r1.numel():
             raise RuntimeError("layer %s: %d merged outputs vs %d target blocks" % (name, cout, r1.numel()))
-        square = plan.is_conv and mod.groups == 1 and mod.dilation == (1, 1) and mod.stride[0] == mod.stride[1] \
-            and mod.padding[0] == mod.padding[1] and mod.kernel_size[0] == mod.kernel_size[1]
+        square = plan.is_conv and _square_conv(mod)
         linear = (not plan.is_conv) and ip.dim() == 2
         geo = (tuple(mod.kernel_size), mod.stride[0], mod.padding[0]) if plan.is_conv else ((1, 1), 1, 0)
         if self.forward == "hip" and (square or linear):
             resid = torch.empty((ip.shape[0], cout) + tuple(o1.shape[2:]), dtype=torch.float32, device=ip.device)
             n = resid.numel() * self.world           # the mean runs over the full (global) batch
-            self.fwd.add(ip, plan.w, plan.b, o1, o2, r1, r2, nm, resid, 2.0 / n, 1.0 / n, *geo)
+            self.fwd.add(ip, plan.w, plan.b, o1, o2, r1, r2, nm, resid, 2.0 / n, 1.0 / n, *geo,
+                         flags=ops.FwdBatch.KPOS_MAJOR if plan.kpos else 0)
             self._fwd_rows.append(idx)
         else:                                        # vendor forward + fused target/residual (one launch per layer)
             out = F.conv2d(ip, plan.w, plan.b, mod.stride, mod.padding, mod.dilation, mod.groups) if plan.is_conv \
@@ -282,7 +295,7 @@ class PleasFitter:
                 self.loss_scale[idx] = 1.0 / n
             resid = out
         if (square and ip.shape[1] >= 16) or linear:
-            self.wgrad.add(resid, ip, plan.gw, *geo)
+            self.wgrad.add(resid, ip, plan.gw, *geo, flags=ops.WgradBatch.KPOS_MAJOR if plan.kpos else 0)
         elif plan.is_conv:  # stem (3 input channels) and exotic geometries: vendor weight gradient
             self._vendor_wgrad.append((resid, ip, plan))
         else:
@@ -391,7 +404,7 @@ class PleasFitter:
         """Write the fitted weights back into ``model3`` and drop the hooks (reference :392-403)."""
         sd = self.model3.state_dict()
         for plan in self.plans:
-            sd["%s.weight" % plan.name] = plan.w.detach().clone()
+            sd["%s.weight" % plan.name] = (plan.w.detach().permute(0, 3, 1, 2) if plan.kpos else plan.w.detach()).clone()
             if plan.b is not None:
                 sd["%s.bias" % plan.name] = plan.b.detach().clone()
         self.model3.load_state_dict(sd)

@@ -219,6 +219,17 @@ def test_bn_act_rejects_bad_operands(ops):
         ops.bn_act(x.cpu(), s, s)
 
 
+def test_fwd_batch_rejects_kpos_major_with_ragged_channels(ops):
+    x = torch.randn(1, 24, 4, 4).cuda()
+    w = torch.randn(8, 3, 3, 24).cuda()
+    o = torch.randn(1, 8, 4, 4).cuda()
+    r = torch.arange(8, dtype=torch.int32, device="cuda")
+    batch = ops.FwdBatch(torch.device("cuda"))
+    batch.add(x, w, None, o, o, r, r, 8, torch.empty_like(o), 1.0, 1.0, (3, 3), 1, 1, flags=ops.FwdBatch.KPOS_MAJOR)
+    with pytest.raises(ops.PleasHipError):
+        batch.flush(torch.zeros(1, device="cuda"))
+
+
 def test_masked_adam_matches_torch(ops):
     g = torch.Generator().manual_seed(5)
     p0 = torch.randn(1000, generator=g)
@@ -448,6 +459,8 @@ FWD_CASES = [
     (4, 128, 128, 14, 14, 3, 1, 1, False),    # 3x3 with padding
     (2, 40, 24, 9, 11, 3, 1, 1, False),       # non-square image
     (4, 128, 64, 28, 28, 3, 2, 1, False),     # stride 2
+    (3, 72, 96, 10, 7, 3, 1, 1, False),       # kernel-position-major with ragged rows / pixels, non-square image
+    (2, 64, 32, 12, 12, 5, 1, 2, False),      # 5x5 taps
     (2, 64, 3, 32, 32, 7, 2, 3, False),       # stem geometry: Kd = 147 (scalar weight loads)
     (16, 70, 300, 1, 1, 1, 1, 0, True),       # linear layer with bias
 ]
@@ -478,9 +491,12 @@ def test_fwd_batch_matches_conv_and_target(ops, N, Cout, Cin, H, W, k, stride, p
     resid = [torch.full((N, Cout, Ho, Wo), float("nan"), device="cuda") for _ in range(2)]
     loss = torch.zeros(2, device="cuda")
     wd = w.cuda().contiguous()
+    # second layer of the launch: the same weights kernel-position-major [Cout][KH][KW][Cin] where that layout applies
+    kpos = Cin % 32 == 0 and k > 1
+    wk = w.permute(0, 2, 3, 1).contiguous().cuda() if kpos else wd
     for i in range(2):   # two layers in one launch
-        batch.add(ip.cuda(), wd, b.cuda() if bias else None, o1.cuda(), o2.cuda(), r1, r2, nmerged, resid[i], 2.0 / numel,
-                  1.0 / numel, (k, k), stride, pad)
+        batch.add(ip.cuda(), wk if i else wd, b.cuda() if bias else None, o1.cuda(), o2.cuda(), r1, r2, nmerged, resid[i],
+                  2.0 / numel, 1.0 / numel, (k, k), stride, pad, flags=ops.FwdBatch.KPOS_MAJOR if (i and kpos) else 0)
     batch.flush(loss)
     for i in range(2):
         assert _rel(resid[i].cpu(), want) < 5e-6

@@ -10,12 +10,13 @@
 static float* dev_rand(size_t n) { std::vector<float> h(n); for (auto& v : h) v = (float)(rand() % 2001 - 1000) * 1e-3f; float* d; hipMalloc(&d, n * 4); hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice); return d; }
 int main(int argc, char** argv) {
     const char* path = argc > 1 ? argv[1] : "rn101_layers.txt"; int reps = argc > 2 ? atoi(argv[2]) : 5, N = 16;
+    const int kpos = argc > 3 ? atoi(argv[3]) : 1;   // 1: k x k layers with Cin % 32 == 0 use kernel-position-major weights
     FILE* f = fopen(path, "r"); if (!f) { printf("cannot open %s\n", path); return 1; }
     int n; fscanf(f, "%d", &n);
     std::vector<pleas_fwd_layer> L(n); double flops = 0, bytes = 0;
     for (auto& l : L) { int co, ci, h, w, k, s, p; fscanf(f, "%d %d %d %d %d %d %d", &co, &ci, &h, &w, &k, &s, &p);
         int ho = (h + 2 * p - k) / s + 1, wo = (w + 2 * p - k) / s + 1; size_t P = (size_t)N * ho * wo;
-        l.N = N; l.Cout = co; l.Cin = ci; l.Hin = h; l.Win = w; l.KH = l.KW = k; l.stride = s; l.pad = p; l.Csrc = co; l.n_merged = co;
+        l.N = N; l.Cout = co; l.Cin = ci; l.Hin = h; l.Win = w; l.KH = l.KW = k; l.stride = s; l.pad = p; l.Csrc = co; l.n_merged = co; l.flags = (kpos && k > 1 && ci % 32 == 0) ? PLEAS_FWD_KPOS_MAJOR : 0;
         l.dscale = 2.0f / (co * P); l.loss_scale = 1.0f / (co * P);
         l.ip = dev_rand((size_t)N * ci * h * w); l.w = dev_rand((size_t)co * ci * k * k); l.bias = nullptr;
         l.o1 = dev_rand(co * P); l.o2 = dev_rand(co * P); float* r; hipMalloc(&r, co * P * 4); l.resid = r;
