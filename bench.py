@@ -68,6 +68,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--ratio", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lookahead", type=int, default=0, help="1: the next batch's source forwards are enqueued before the "
+                    "current PLeaS update and share the GPU with it (PleasFitter.steps(lookahead=True): about -3 %% "
+                    "wall-clock, but per-kernel durations then include the contention); 0 (default): one batch at a time")
     ap.add_argument("--profile-all", action="store_true", help="also bracket the many-launch elementwise kernels "
                     "(bn_act, merge_blocks) with events: complete phases_ms, slightly slower timed region")
     ap.add_argument("--cpu-sample-batch", type=int, default=2)
@@ -117,7 +120,7 @@ def build_models(arch, device, batch):
     return models
 
 
-def run_job(spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, ratio, dp):
+def run_job(spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, ratio, dp, lookahead=True):
     """The timed hot path.  Returns (merged model, perm, costs)."""
     from pleas_merging_amd.methods.activation_matching import activation_matching
     from pleas_merging_amd.methods.partial_matching import partial_merge
@@ -126,8 +129,8 @@ def run_job(spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, ratio, dp):
     perm, costs = activation_matching(spec, m1, m2, match_loader, len(match_loader), output_costs=True)
     m3 = partial_merge(spec, m1, m2, perm, costs, ratio)
     fit = PleasFitter(m1, m2, m3, spec, perm, costs, ratio, n_pleas_sched, data_parallel=dp)
-    for x, _ in pleas_loader:
-        fit.step(x)
+    for _ in fit.steps((x for x, _ in pleas_loader), lookahead=lookahead):
+        pass
     return fit.finish(), perm, costs
 
 
@@ -149,8 +152,8 @@ def time_normal_eq(spec, m1, m2, perm, costs, loader, ratio):
     hip_ops.profile_enable(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for x, _ in loader:
-        fit.step(x)
+    for _ in fit.steps(x for x, _ in loader):
+        pass
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     fit.solve()
@@ -269,7 +272,7 @@ def main():
     # ---- warm-up: W matching batches + W updates on throw-away state (MIOpen find, allocator, graph build)
     if args.warmup > 0:
         run_job(spec, m1, m2, pool.loader(0, args.warmup * world), pool.loader(0, args.warmup), max(1, args.warmup - 1),
-                args.ratio, dp)
+                args.ratio, dp, bool(args.lookahead))
 
     log("warm-up done")
     # ---- timed region.  Events bracket the few-launches-per-step kernels only: the elementwise kernels launched
@@ -280,7 +283,8 @@ def main():
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    m3, perm, costs = run_job(spec, m1, m2, pool.loader(0, n_match), pool.loader(0, n_pleas), max(1, n_sched), args.ratio, dp)
+    m3, perm, costs = run_job(spec, m1, m2, pool.loader(0, n_match), pool.loader(0, n_pleas), max(1, n_sched), args.ratio, dp,
+                              bool(args.lookahead))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

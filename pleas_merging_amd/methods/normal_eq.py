@@ -54,6 +54,7 @@ class NormalEqFitter(PleasFitter):
             for i, p in enumerate(self.plans) if p.b is not None}
         self.neq = self.ops.NormalEqBatch(dev)
         self.batches_seen = 0
+        self._slice_batch = False   # data parallel here = whole batches per rank (train_normal_eq), never sample slices
 
     def _hip_geometry_ok(self, plan: _LayerPlan, ip: torch.Tensor) -> bool:
         mod = plan.mod
@@ -62,20 +63,18 @@ class NormalEqFitter(PleasFitter):
         return (mod.groups == 1 and mod.dilation == (1, 1) and mod.stride[0] == mod.stride[1]
                 and mod.padding[0] == mod.padding[1] and ip.shape[1] >= 16)
 
-    @torch.no_grad()
-    def step(self, x: torch.Tensor) -> None:
-        """Accumulate one batch (no parameter update)."""
+    def _step(self, x: torch.Tensor, next_x=None) -> None:
+        """Accumulate one batch (no parameter update); driven by :meth:`PleasFitter.step`."""
         ops = self.ops
-        x = x.to(self.device, non_blocking=True)
-        self._run_sources(x)
+        self._begin_update(x, next_x)
         KP = ops.WgradBatch.ACCUMULATE | ops.WgradBatch.KPOS_MAJOR
         for idx, plan in enumerate(self.plans):
             name = plan.name
-            if name not in self.tap1.inputs or name not in self.tap2.inputs:
+            if name not in self.t1_in or name not in self.t2_in:
                 print("Key error on %s" % name)
                 continue
-            ip = ops.merge_blocks(self.tap1.inputs[name], self.tap2.inputs[name], 1, *plan.in_maps)
-            op = ops.merge_blocks(self.tap1.outputs[name], self.tap2.outputs[name], 1, *plan.out_maps)
+            ip = ops.merge_blocks(self.t1_in[name], self.t2_in[name], 1, *plan.in_maps)
+            op = ops.merge_blocks(self.t1_out[name], self.t2_out[name], 1, *plan.out_maps)
             mod = plan.mod
             if self._hip_geometry_ok(plan, ip):
                 if plan.is_conv:
@@ -103,9 +102,7 @@ class NormalEqFitter(PleasFitter):
         self.neq.flush()
         self.wgrad.flush()
         self.batches_seen += 1
-        if self._src_graph is None:
-            self.tap1.clear()
-            self.tap2.clear()
+        self._end_update()
 
     @torch.no_grad()
     def solve(self) -> Dict[str, float]:
@@ -197,14 +194,15 @@ def train_normal_eq(dataloader, model1, model2, model3, spec, perm, costs, budge
     fit = NormalEqFitter(model1, model2, model3, spec, perm, costs, budget_ratios, MAX_STEPS, 5e-4, separate_classifier,
                          num_classes, model_type, ridge=ridge)
     fit.rank, fit.world = _dist_info()
-    for idx, batch in enumerate(dataloader):
-        if idx > MAX_STEPS:
-            break
-        if idx % fit.world != fit.rank:
-            continue
-        x, _ = batch
-        fit.step(x)
+    def inputs():
+        for idx, batch in enumerate(dataloader):
+            if idx > MAX_STEPS:
+                break
+            if idx % fit.world == fit.rank:
+                yield batch[0]
+
+    for n in fit.steps(inputs()):
         if verbose:
-            print("normal_eq: accumulated batch %d" % idx)
+            print("normal_eq: accumulated batch %d of this rank" % n)
     fit.solve()
     return fit.finish()

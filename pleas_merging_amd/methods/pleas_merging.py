@@ -28,6 +28,7 @@ MI355X design of one Adam step
 """
 from __future__ import annotations
 
+import contextlib
 import math
 from typing import Dict, List, Optional, Tuple
 
@@ -97,6 +98,13 @@ class ActivationTap:
     def clear(self):
         self.inputs.clear()
         self.outputs.clear()
+
+    def take(self):
+        """Hand over the tensors of the latest forward and start a new generation (the hooks look the dicts up on
+        every call, so the next forward fills the fresh ones)."""
+        got = (self.inputs, self.outputs)
+        self.inputs, self.outputs = {}, {}
+        return got
 
     def remove(self):
         for h in self.handles:
@@ -191,8 +199,20 @@ class PleasFitter:
             self.src2 = fuse_bn_act(model2) or model2
 
         # the two source forwards are independent chains of small kernels (one conv of a batch-16 ResNet fills a
-        # fraction of 256 CUs): model2 runs on a second HIP stream next to model1, joined before the taps are read
-        self._side_stream = torch.cuda.Stream(self.device) if overlap_sources else None
+        # fraction of 256 CUs): the two models run on two side streams, joined before the taps are read
+        # Each source gets its own stream: their dependency chains of small kernels then also run NEXT TO the big grouped
+        # kernels of the previous update (step(x, next_x=...) enqueues the sources of the next batch before this update's
+        # own launches).  Equal priorities: favouring either side was slower (chain first 8.7 s, update first 11.5 s).
+        self._side_streams = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)) if overlap_sources else None
+        # The update's own launches go to a dedicated stream as well, not to the caller's: measured on the 401-update job,
+        # work on torch's default (null) stream overlaps the side streams markedly worse than work on a created stream
+        # (8.24 s vs 7.73 s for the whole job).  step() orders that stream after the caller's and the caller's after it.
+        self._upd_stream = torch.cuda.Stream(self.device) if overlap_sources else None
+        self._src_events = None
+        self._slice_batch = True   # data parallel: every update splits its batch's samples over the ranks
+        self._pending = None     # (batch as passed, its device copy, taps of model1, taps of model2, events): prefetched
+        self._cur_x = None
+        self.t1_in = self.t1_out = self.t2_in = self.t2_out = None   # taps of the update being applied
 
         layers = {n: m for n, m in model3.named_modules() if isinstance(m, (nn.Conv2d, nn.Linear))}
         self.layer_modules = layers
@@ -253,20 +273,24 @@ class PleasFitter:
         self.fwd = hip_ops.FwdBatch(dev)
         self._fwd_loss = None
         self._fwd_index = None
-        # graph_sources=True: the two source forwards (vendor convs + BN/ReLU, ~700 launches) are captured ONCE into
-        # a hipGraph and replayed per update on a static input buffer (no Python / dispatcher work per op; the
-        # hooks' tensors become fixed addresses).  Measured on the 401-update job: -0.9 ms per update, but the
-        # capture itself costs ~0.35 s, so it only pays for longer runs -> opt-in.
+        # graph_sources=True: from the second batch of a shape on, the two source forwards (~420 launches, ~35 us of host
+        # time per vendor convolution) are replayed from hipGraphs instead of being dispatched op by op: TWO graphs with
+        # their own static input and taps take turns, so that the sources of the next batch can be replayed while the
+        # update of the current one still reads the other generation.  Inside a graph the two models sit on parallel
+        # branches (captured from the two side streams).  Capture costs ~0.05 s per graph; a capture problem falls back
+        # to eager dispatch for the rest of the run.
         self.graph_sources = graph_sources
-        self._src_graph = None
-        self._x_static = None
+        self._graphs = [None, None]     # per generation: dict(graph, x, taps1, taps2, shape)
+        self._graph_turn = 0
+        self._graph_seen: Dict[tuple, int] = {}
+        self._graph_stream = torch.cuda.Stream(self.device, priority=-1) if graph_sources else None
 
     # -- one layer: merged input; queue forward(+target+residual+loss) and weight gradient for the grouped launches
     def _fit_layer(self, idx: int, plan: _LayerPlan) -> None:
         ops = self.ops
         name = plan.name
-        ip1, ip2 = self.tap1.inputs[name], self.tap2.inputs[name]
-        o1, o2 = self.tap1.outputs[name], self.tap2.outputs[name]
+        ip1, ip2 = self.t1_in[name], self.t2_in[name]
+        o1, o2 = self.t1_out[name], self.t2_out[name]
         ip = ops.merge_blocks(ip1, ip2, 1, *plan.in_maps)
         mod = plan.mod
         r1, r2, nm = plan.out_maps
@@ -315,16 +339,139 @@ class PleasFitter:
         for resid, plan in self._bias_grads:
             plan.gb.copy_(resid.sum((0, 2, 3)) if plan.is_conv else resid.reshape(-1, resid.shape[-1]).sum(0))
 
-    @torch.no_grad()
-    def step(self, x: torch.Tensor) -> None:
-        """One update: reference ``step`` (:234-302) + ``lr_sched.step()`` (:375)."""
+    def _launch_sources(self, x: torch.Tensor):
+        """Enqueue both source forwards for ``x``; returns the generation (device batch, taps, events) the update will
+        consume."""
         x = x.to(self.device, non_blocking=True)
-        x = dp_slice(x, self.rank, self.world)
-        self._run_sources(x)
+        if self._slice_batch:
+            x = dp_slice(x, self.rank, self.world)
+        if self.graph_sources:
+            gen = self._launch_graph(x)
+            if gen is not None:
+                return gen
+        self._run_sources_eager(x)
+        events = self._src_events
+        self._src_events = None
+        return (x, self.tap1.take(), self.tap2.take(), events)
+
+    def _capture_sources(self, x: torch.Tensor) -> dict:
+        self.tap1.take()
+        self.tap2.take()
+        x_static = x.clone()
+        graph = torch.cuda.CUDAGraph()
+        torch.cuda.current_stream(self.device).synchronize()
+        with torch.cuda.graph(graph):
+            cap = torch.cuda.current_stream(self.device)
+            side = self._side_streams or (cap, cap)
+            for stream, model in zip(side, (self.src1, self.src2)):
+                if stream is not cap:
+                    stream.wait_stream(cap)
+                with torch.cuda.stream(stream), self.ops.pin_stream():
+                    model(x_static)
+            for stream in side:
+                if stream is not cap:
+                    cap.wait_stream(stream)
+        return {"graph": graph, "x": x_static, "taps1": self.tap1.take(), "taps2": self.tap2.take(),
+                "shape": tuple(x.shape)}
+
+    def _launch_graph(self, x: torch.Tensor):
+        """Replay (capturing first if needed) this generation's source graph on the graph stream; None = run eagerly."""
+        key = tuple(x.shape)
+        seen = self._graph_seen[key] = self._graph_seen.get(key, 0) + 1
+        if seen <= 1:                    # the first batch of a shape runs eagerly: vendor plans, allocator
+            return None
+        slot = self._graph_turn = (self._graph_turn + 1) % 2
+        main, gs = torch.cuda.current_stream(self.device), self._graph_stream
+        try:
+            # everything below is ordered after the work already enqueued on `main`: in particular after the update that
+            # last read this generation's static taps (two updates back with one batch of look-ahead)
+            gs.wait_stream(main)
+            with torch.cuda.stream(gs):
+                g = self._graphs[slot]
+                if g is None or g["shape"] != key:
+                    g = self._graphs[slot] = self._capture_sources(x)
+                g["x"].copy_(x, non_blocking=True)
+                g["graph"].replay()
+                ev = torch.cuda.Event()
+                ev.record(gs)
+            return (x, g["taps1"], g["taps2"], [ev])
+        except Exception as exc:  # noqa: BLE001 -- capture is an optimisation; eager dispatch is always valid
+            print("pleas: source-forward graph capture unavailable (%s); running eagerly" % (exc,))
+            self.graph_sources = False
+            self._graphs = [None, None]
+            self.tap1.take()
+            self.tap2.take()
+            return None
+
+    def _begin_update(self, x: torch.Tensor, next_x: Optional[torch.Tensor]) -> None:
+        """Taps of ``x`` become current (running its sources now unless they were prefetched); the sources of
+        ``next_x`` are enqueued BEFORE this update's own kernels, so that they overlap them on the side streams."""
+        if self._pending is not None and self._pending[0] is not x:
+            raise RuntimeError("PleasFitter.step: a different batch was prefetched with next_x than the one passed now")
+        cur = self._pending if self._pending is not None else (x,) + self._launch_sources(x)
+        self._pending = None
+        if next_x is not None and (self._side_streams is not None or self.graph_sources):
+            self._pending = (next_x,) + self._launch_sources(next_x)
+        _, self._cur_x, (self.t1_in, self.t1_out), (self.t2_in, self.t2_out), events = cur
+        if events is not None:
+            main = torch.cuda.current_stream(self.device)
+            for ev in events:
+                main.wait_event(ev)
+
+    def _end_update(self) -> None:
+        # the device copy of the batch was read on the side streams: it is released only now, after this update's
+        # kernels (which waited for those streams) are enqueued on the stream that owns its memory
+        self._cur_x = None
+        self.t1_in = self.t1_out = self.t2_in = self.t2_out = None
+
+    @contextlib.contextmanager
+    def _session(self):
+        """Make the fitter's own stream current; order it after the caller's stream on entry and the caller's after it
+        on exit (so results are visible to whatever the caller enqueues next)."""
+        upd = self._upd_stream
+        if upd is None or torch.cuda.current_stream(self.device) == upd:
+            yield
+            return
+        caller = torch.cuda.current_stream(self.device)
+        upd.wait_stream(caller)
+        try:
+            with torch.cuda.stream(upd):
+                yield
+        finally:
+            caller.wait_stream(upd)
+
+    def steps(self, batches, lookahead: bool = False):
+        """Run one update per tensor of ``batches``; yields the index of each finished update.  The whole loop stays on
+        the fitter's stream (also current for the consumer's code between two updates).
+
+        ``lookahead=True``: the next batch's source forwards are enqueued before the current update's kernels and run
+        beside them (two tap generations in flight).  Measured on the ResNet-101 job: -3 % wall-clock (7.96 s vs 8.19 s),
+        while every grouped kernel takes longer because it shares the CUs (fused forward 2.9 -> 4.3 ms per launch).
+        Off by default: the gain is within run-to-run noise and per-kernel timings stay interpretable."""
+        with self._session():
+            it = iter(batches)
+            nxt = next(it, None)
+            idx = 0
+            while nxt is not None:
+                cur, nxt = nxt, next(it, None)
+                self.step(cur, next_x=nxt if lookahead else None)
+                yield idx
+                idx += 1
+
+    @torch.no_grad()
+    def step(self, x: torch.Tensor, next_x: Optional[torch.Tensor] = None) -> None:
+        """One update: reference ``step`` (:234-302) + ``lr_sched.step()`` (:375).  ``next_x`` (optional): the batch
+        of the NEXT call; its source forwards are enqueued now and run beside this update.  On return the work is
+        ordered before anything enqueued later on the caller's stream."""
+        with self._session():
+            self._step(x, next_x)
+
+    def _step(self, x: torch.Tensor, next_x: Optional[torch.Tensor]) -> None:
+        self._begin_update(x, next_x)
         self._fwd_rows, self._vendor_wgrad, self._bias_grads = [], [], []
         with self.ops.pin_stream():
             for idx, plan in enumerate(self.plans):
-                if plan.name not in self.tap1.inputs or plan.name not in self.tap2.inputs:
+                if plan.name not in self.t1_in or plan.name not in self.t2_in:
                     print("Key error on %s" % plan.name)
                     continue
                 self._fit_layer(idx, plan)
@@ -346,59 +493,34 @@ class PleasFitter:
         lr = self.lrs[min(self.step_count, len(self.lrs) - 1)]
         self.step_count += 1
         self.ops.masked_adam(self.p, self.g, self.mask, self.m, self.v, lr, self.step_count)
-        if self._src_graph is None:   # under graph replay the taps are the graph's static tensors
-            self.tap1.clear()
-            self.tap2.clear()
+        self._end_update()
 
     def _run_sources(self, x: torch.Tensor) -> None:
-        """Both source forwards; hooks fill the taps.  Graph path: capture on the 3rd call with this input shape."""
-        if not self.graph_sources:
-            self._run_sources_eager(x)
-            return
-        if self._src_graph is not None and self._x_static.shape == x.shape:
-            self._x_static.copy_(x)
-            self._src_graph.replay()
-            return
-        self._eager_calls = getattr(self, "_eager_calls", 0) + 1
-        if self._eager_calls < 3 or self._src_graph is not None:   # warm up (vendor algorithm search, allocator)
-            self.src1(x)
-            self.src2(x)
-            return
-        try:
-            self.tap1.clear()
-            self.tap2.clear()
-            self._x_static = x.clone()
-            graph = torch.cuda.CUDAGraph()
-            torch.cuda.synchronize()
-            with torch.cuda.graph(graph):
-                self.src1(self._x_static)
-                self.src2(self._x_static)
-            graph.replay()
-            self._src_graph = graph
-        except Exception as exc:  # noqa: BLE001 -- capture is an optimisation; eager is always valid
-            print("pleas: source-forward graph capture unavailable (%s); running eagerly" % (exc,))
-            self.graph_sources = False
-            self._src_graph = None
-            self.src1(x)
-            self.src2(x)
+        """Both source forwards, dispatched op by op; the hooks fill ``tap1`` / ``tap2`` (callers that read them right
+        away must synchronise: the models run on side streams)."""
+        self._run_sources_eager(x)
 
     def _run_sources_eager(self, x: torch.Tensor) -> None:
-        side = self._side_stream
+        side = self._side_streams
         if side is None:
             with self.ops.pin_stream():
                 self.src1(x)
                 self.src2(x)
             return
         main = torch.cuda.current_stream(self.device)
-        # model2's tensors live in the side stream's allocator pool.  They are consumed on `main` (this update) and
-        # released by the host at the end of the update; the side stream re-uses them only after this wait, i.e.
-        # after every consumer enqueued on `main` so far -- no record_stream bookkeeping needed.
-        side.wait_stream(main)
-        with torch.cuda.stream(side), self.ops.pin_stream():
-            self.src2(x)
-        with self.ops.pin_stream():
-            self.src1(x)
-        main.wait_stream(side)
+        # The sources' tensors live in the side streams' allocator pools.  They are consumed on `main` (by the update
+        # that owns this generation) and released by the host once that update is enqueued; a side stream re-uses them
+        # only after a LATER wait_stream(main), i.e. after every consumer enqueued on `main` up to then -- with one
+        # batch of look-ahead that is the update two generations back.  No record_stream bookkeeping needed.
+        events = []
+        for stream, model in zip(side, (self.src1, self.src2)):
+            stream.wait_stream(main)
+            with torch.cuda.stream(stream), self.ops.pin_stream():
+                model(x)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            events.append(ev)
+        self._src_events = events
 
     def finish(self) -> nn.Module:
         """Write the fitted weights back into ``model3`` and drop the hooks (reference :392-403)."""
@@ -433,11 +555,14 @@ def train(dataloader, model1, model2, model3, spec, perm, costs, budget_ratios, 
     fit = PleasFitter(model1, model2, model3, spec, perm, costs, budget_ratios, MAX_STEPS, lr, separate_classifier,
                       num_classes, model_type)
     names = [p.name for p in fit.plans]
-    for idx, batch in enumerate(dataloader):
-        if idx > MAX_STEPS:
-            break
-        x, _ = batch
-        fit.step(x)
+
+    def inputs():
+        for idx, batch in enumerate(dataloader):
+            if idx > MAX_STEPS:
+                break
+            yield batch[0]
+
+    for idx in fit.steps(inputs()):
         if verbose:
             print(float(fit.loss_sum.sum()))
         if idx % 20 == 0 and idx:

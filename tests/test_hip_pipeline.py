@@ -347,7 +347,7 @@ def test_graph_captured_forwards_give_identical_results(tiny_bottleneck):
         fit = PleasFitter(m1, m2, m3, t.spec, perm, costs, 0.5, 7, num_classes=10, graph_sources=graph)
         for x, _ in data:
             fit.step(x)
-        assert (fit._src_graph is not None) == graph
+        assert (fit._graphs[0] is not None and fit._graphs[1] is not None) == graph
         outs.append({k: v.clone() for k, v in fit.finish().state_dict().items()})
     for k in outs[0]:
         if k == DEGENERATE:   # stem: rounding-noise-driven and its 3-channel wgrad is the vendor's (atomics) kernel
@@ -373,6 +373,7 @@ def test_fused_source_forwards_match_module_forwards(tiny_bottleneck):
         fit = PleasFitter(m1, m2, m3, t.spec, perm, costs, 0.5, 3, num_classes=10, fuse_sources=fuse)
         assert (fit.src1 is not m1) == fuse and (fit.src2 is not m2) == fuse
         fit._run_sources(data[0][0].cuda())
+        torch.cuda.synchronize()   # the sources run on side streams
         taps.append(({k: v.clone() for k, v in fit.tap1.inputs.items()}, {k: v.clone() for k, v in fit.tap2.outputs.items()}))
         fit.tap1.clear()
         fit.tap2.clear()
@@ -404,7 +405,7 @@ def test_two_stream_source_forwards_equal_single_stream(tiny_bottleneck):
     for overlap in (False, True):
         m3 = partial_merge(t.spec, m1, m2, perm, costs, 0.5)
         fit = PleasFitter(m1, m2, m3, t.spec, perm, costs, 0.5, 7, num_classes=10, overlap_sources=overlap)
-        assert (fit._side_stream is not None) == overlap
+        assert (fit._side_streams is not None) == overlap
         for x, _ in data:
             fit.step(x)
         outs.append({k: v.clone() for k, v in fit.finish().state_dict().items()})
@@ -415,6 +416,43 @@ def test_two_stream_source_forwards_equal_single_stream(tiny_bottleneck):
             # layers narrower than the HIP tile's 16 input channels (this 4-wide fixture) take the vendor's atomics
             # weight-gradient kernel, which is order-dependent run to run even on one stream: rounding only
             assert _rel(outs[0][k], outs[1][k]) < 1e-6, k
+
+
+def test_lookahead_steps_equal_sequential_steps(tiny_bottleneck):
+    """steps(): the next batch's source forwards are enqueued before the current update (two side streams, two tap
+    generations in flight).  Same updates in the same order as step(x) one by one."""
+    from pleas.methods.partial_matching import partial_merge
+    from pleas.methods.pleas_merging import PleasFitter
+
+    t = tiny_bottleneck
+    m1, m2 = _cuda_pair(t)
+    xs = [x for x, _ in t.batches() + t.batches() + t.batches()]
+    perm = t.per_key("am_perm")
+    costs = {k: v.cuda() for k, v in t.per_key("am_cost").items()}
+    outs = []
+    for lookahead in (False, True):
+        m3 = partial_merge(t.spec, m1, m2, perm, costs, 0.5)
+        fit = PleasFitter(m1, m2, m3, t.spec, perm, costs, 0.5, len(xs) - 1, num_classes=10)
+        if lookahead:
+            assert list(fit.steps(xs, lookahead=True)) == list(range(len(xs)))
+            assert fit._pending is None
+        else:
+            for x in xs:
+                fit.step(x)
+        assert fit.step_count == len(xs)
+        outs.append({k: v.clone() for k, v in fit.finish().state_dict().items()})
+    for k in outs[0]:
+        if k == DEGENERATE:
+            assert torch.allclose(outs[0][k], outs[1][k], atol=2 * 5e-4 * len(xs))
+        elif outs[0][k].dtype.is_floating_point:   # 4-wide layers use the vendor's atomics weight gradient: rounding only
+            assert _rel(outs[0][k], outs[1][k]) < 1e-6, k
+    # a prefetched batch must be the one the next call applies
+    m3 = partial_merge(t.spec, m1, m2, perm, costs, 0.5)
+    fit = PleasFitter(m1, m2, m3, t.spec, perm, costs, 0.5, 3, num_classes=10)
+    fit.step(xs[0], next_x=xs[1])
+    with pytest.raises(RuntimeError):
+        fit.step(xs[2])
+    fit.finish()
 
 
 def test_config4_zip_budget_partial_merge_and_train_vs_oracle():

@@ -20,6 +20,10 @@ for _ in range(3): fit.step(x)
 torch.cuda.synchronize(); t0 = time.time()
 for _ in range(ns): fit.step(x)
 torch.cuda.synchronize(); print("PLeaS: %.2f ms/step" % ((time.time() - t0) / ns * 1e3))
+xs = [x.clone() for _ in range(ns)]
+torch.cuda.synchronize(); t0 = time.time()
+for _ in fit.steps(xs, lookahead=True): pass
+torch.cuda.synchronize(); print("PLeaS with look-ahead (steps()): %.2f ms/step" % ((time.time() - t0) / ns * 1e3))
 # --- is the step CPU-bound?  enqueue time (no sync) vs wall time per step
 import time as _t
 torch.cuda.synchronize(); t0 = _t.time(); enq = 0.0
@@ -30,6 +34,6 @@ print("enqueue %.2f ms/step, wall %.2f ms/step, GPU drain after last enqueue %.1
 
 # source forwards alone
 torch.cuda.synchronize(); t0 = _t.time()
-for _ in range(ns): fit._run_sources(x)
+for _ in range(ns): fit._launch_sources(x)
 t1 = _t.time(); torch.cuda.synchronize(); t2 = _t.time()
 print("sources only: enqueue %.2f ms, wall %.2f ms" % ((t1 - t0) / ns * 1e3, (t2 - t0) / ns * 1e3))
