@@ -2,3 +2,9 @@ from pleas_merging_amd.core.utils import *  # noqa: F401,F403
 from pleas_merging_amd.core.utils import (Axis, PermutationGroup, PermutationSpec, Permutation, StateDict,  # noqa: F401
                                           apply_perm, make_identity_perm, make_random_perm, invert_perm, perm_eq,
                                           get_attr, set_attr, UnionFind)
+
+
+def count_linear_flops(spec, model, inputs_or_shapes):  # reference utils.py:558-617
+    from pleas_merging_amd.methods.budget import count_linear_flops as impl
+
+    return impl(spec, model, inputs_or_shapes)

@@ -12,6 +12,9 @@ Host-side logic only; the forwards run under PyTorch-ROCm like everything else o
                           without the forwards (no reference counterpart; resumability)
 * ``load_checkpoint``  -- input checkpoints as the drivers read them: a raw state dict or ``['model']``
                           (run_domainnet.py:190-193, run_torchvision.py:176-182)
+
+The other 8(f) rows live next door: ``budget.py`` (FLOP model, Gurobi-free ``qp_ratios``) and ``evaluation.py``
+(``get_fc_perm`` / ``permute_final_features`` / ``eval_perm_model``).
 """
 from __future__ import annotations
 
@@ -24,23 +27,71 @@ from ..core.utils import Axis, Permutation, PermutationSpec
 
 
 @torch.no_grad()
-def reset_bn_stats(model: nn.Module, dataloader: Iterable, num_batches: int = 101, device=None) -> nn.Module:
+def reset_bn_stats(model: nn.Module, dataloader: Iterable, num_batches: int = 101, device=None, shard: bool = True) -> nn.Module:
     """Recompute BatchNorm running statistics of a (merged) model on data.
 
     Same procedure as the reference drivers: ``model.train()``, ``reset_running_stats()`` on every
     ``BatchNorm2d``, ``num_batches`` forward passes without gradients (the drivers break after 101),
     default momentum.  Leaves the model in train mode like the reference does; callers ``eval()`` next.
+
+    Data parallel (``torch.distributed`` initialised, one process per GPU): rank r forwards batches ``b % world == r``.
+    A train-mode forward normalises with the batch's own statistics, so batches are independent, and the running
+    statistics after n sequential updates are the fixed linear combination
+    ``(1-m)^n r0 + sum_b m (1-m)^(n-1-b) stat_b``: every rank accumulates its share of the sum and ONE all-reduce of
+    a flat buffer per statistic gives every rank the sequential result.
     """
+    from .activation_matching import _dist_info
+
     if device is None:
         device = next(iter(model.parameters())).device
+    rank, world = _dist_info() if shard else (0, 1)
     model.train()
-    for m in model.modules():
-        if isinstance(m, nn.BatchNorm2d):
-            m.reset_running_stats()
-    for i, batch in enumerate(dataloader):
-        if i >= num_batches:
-            break
-        model(batch[0].to(device).float())
+    bns = [m for m in model.modules() if isinstance(m, nn.BatchNorm2d)]
+    for m in bns:
+        m.reset_running_stats()
+    if world == 1:
+        for i, batch in enumerate(dataloader):
+            if i >= num_batches:
+                break
+            model(batch[0].to(device).float())
+        return model
+
+    import torch.distributed as dist
+
+    tracked = [m for m in bns if m.track_running_stats and m.running_mean is not None]
+    if any(m.momentum is None for m in tracked):
+        raise NotImplementedError("sharded reset_bn_stats: cumulative-average BatchNorm (momentum=None)")
+    saved = [m.momentum for m in tracked]
+    sizes = [m.num_features for m in tracked]
+    acc = torch.zeros(2, sum(sizes), dtype=torch.float64, device=device)     # weighted sums of batch means / variances
+    n = 0
+    try:
+        for m in tracked:
+            m.momentum = 1.0            # after a forward, running_* hold exactly this batch's statistics
+        for i, batch in enumerate(dataloader):
+            if i >= num_batches:
+                break
+            n = i + 1
+            if i % world != rank:
+                continue
+            model(batch[0].to(device).float())
+            off = 0
+            for m, mom, c in zip(tracked, saved, sizes):
+                wgt = (1.0 - mom) ** (-i)                                    # common factor m (1-m)^(n-1) applied at the end
+                acc[0, off:off + c].add_(m.running_mean.double(), alpha=wgt)
+                acc[1, off:off + c].add_(m.running_var.double(), alpha=wgt)
+                off += c
+    finally:
+        for m, mom in zip(tracked, saved):
+            m.momentum = mom
+    dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+    off = 0
+    for m, mom, c in zip(tracked, saved, sizes):
+        scale, keep = mom * (1.0 - mom) ** (n - 1), (1.0 - mom) ** n
+        m.running_mean.copy_((acc[0, off:off + c] * scale).float())           # r0 = 0
+        m.running_var.copy_((acc[1, off:off + c] * scale + keep).float())     # r0 = 1
+        m.num_batches_tracked.fill_(n)
+        off += c
     return model
 
 

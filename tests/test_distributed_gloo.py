@@ -61,6 +61,28 @@ def _gradient_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _bn_reset_worker(rank, world, port, q):
+    _init(rank, world, port)
+    import copy
+
+    from conftest import Tiny
+    from pleas.methods.extras import reset_bn_stats
+
+    t = Tiny("tiny_bottleneck.npz")
+    data = t.batches() + t.batches("x")[:3]          # 7 batches -> ranks get 4 and 3
+    data = [(x + 0.1 * i, y) for i, (x, y) in enumerate(data)]
+    seq = reset_bn_stats(copy.deepcopy(t.m1), data, 6, shard=False)       # the drivers' sequential procedure
+    par = reset_bn_stats(copy.deepcopy(t.m1), data, 6, shard=True)        # batches b % 2 == rank, one all-reduce
+    ok = True
+    for (k, a), (_, b) in zip(seq.state_dict().items(), par.state_dict().items()):
+        if "running" in k:
+            ok &= bool(torch.allclose(a, b, rtol=1e-5, atol=1e-6))
+        elif "num_batches_tracked" in k:
+            ok &= int(a) == int(b) == 6
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
 def _run(worker, port):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -79,6 +101,10 @@ def test_sharded_cost_accumulation_gloo():
 
 def test_sharded_pleas_gradient_gloo():
     _run(_gradient_worker, 29612)
+
+
+def test_sharded_bn_reset_equals_sequential_gloo():
+    _run(_bn_reset_worker, 29613)
 
 
 def test_dp_slice_rejects_ragged_batches():

@@ -370,3 +370,97 @@ def test_split_twin_graph_defers_sinks_and_keeps_inplace_targets(tiny_bottleneck
     assert torch.equal(split["c1", 1][0], seen["c1"]) and torch.equal(split["c2", 1][0], seen["c2"])
     with pytest.raises(ValueError):
         am._build_twin(m1, m2, axes, emitter({}), keep_inputs=False, side_stream=Streams())
+
+
+
+@pytest.mark.parametrize("fname", ["tiny_basic.npz", "tiny_bottleneck.npz"])
+def test_flop_model_and_fc_helpers_match_reference_fixture(fname):
+    """SURVEY 8(f) rows 2 and 4 against vectors produced by the reference (tests/golden/make_golden_extras.py)."""
+    from conftest import Tiny
+    from pleas.core.utils import count_linear_flops
+    from pleas.methods.partial_matching import partial_merge_flops
+    from pleas.methods.pleas_merging import get_fc_perm, permute_final_features
+
+    t = Tiny(fname)
+    case = json.load(open(os.path.join(GOLDEN, "extras_tiny.json")))["cases"][fname]
+    flops, terms = count_linear_flops(t.spec, t.m1, ((2, 3, 32, 32),))
+    assert flops == case["flops"]
+    assert [[float(c)] + [str(a) for a in axes] for c, *axes in terms] == case["terms"]
+    for entry in case["merge_flops"]:
+        r = entry["ratios"]
+        r = {Axis.parse(k): v for k, v in r.items()} if isinstance(r, dict) else r
+        assert abs(partial_merge_flops(t.spec, terms, r) - entry["flops"]) <= 1e-9 * entry["flops"]
+    perm, costs = t.per_key("am_perm"), t.per_key("am_cost")
+    for entry in case["fc"]:
+        blocks = get_fc_perm(perm, t.spec, costs, entry["ratio"])
+        assert [b.tolist() for b in blocks] == entry["blocks"]
+        feats = torch.tensor(entry["features"])
+        for idx in (0, 1):
+            assert torch.equal(permute_final_features(feats, blocks, idx), torch.tensor(entry["permuted"][idx]))
+
+
+def test_qp_ratios_without_gurobi(tiny_basic):
+    """The reference returns random ratios without Gurobi; ours must be feasible, use the budget, be monotone in it
+    and hit the optimum of a small instance found by exhaustive search."""
+    from pleas.core.utils import count_linear_flops
+    from pleas.methods.partial_matching import partial_merge_flops, qp_ratios
+
+    t = tiny_basic
+    _, terms = count_linear_flops(t.spec, t.m1, ((2, 3, 32, 32),))
+    base = partial_merge_flops(t.spec, terms, 0.0)
+    full = partial_merge_flops(t.spec, terms, 1.0) / base
+    w = {k: 0.5 + 0.25 * i for i, k in enumerate(t.spec)}
+    assert all(v == 0.0 for v in qp_ratios(t.spec, terms, 1.0, w).values())
+    assert all(v == 1.0 for v in qp_ratios(t.spec, terms, full + 0.1, w).values())
+    last = -1.0
+    for budget in (1.1, 1.3, 1.6, 1.9):
+        r = qp_ratios(t.spec, terms, budget, w)
+        assert set(r) == set(t.spec) and all(0.0 <= v <= 1.0 for v in r.values())
+        used = partial_merge_flops(t.spec, terms, r) / base
+        assert used <= budget + 1e-9 and used >= min(budget, full) - 1e-3      # feasible and budget-tight
+        obj = sum(w[k] * r[k] for k in r)
+        assert obj >= last - 1e-9
+        last = obj
+        assert qp_ratios(t.spec, terms, budget, w) == r                          # deterministic
+    # exhaustive check on a two-group toy: F = 10 (1 + a) + 6 (1 + a + b - a b) + 4 (1 + b)
+    spec = {Axis("p", 0): PermutationGroup(1, {Axis("p", 0)}, set()), Axis("q", 0): PermutationGroup(1, {Axis("q", 0)}, set())}
+    toy = [(10, Axis("p", 0)), (6, Axis("p", 0), Axis("q", 0)), (4, Axis("q", 0))]
+    ww = {Axis("p", 0): 1.0, Axis("q", 0): 0.8}
+    grid = np.linspace(0, 1, 201)
+    for budget in (1.2, 1.45, 1.7):
+        r = qp_ratios(spec, toy, budget, ww)
+        best = max(ww[Axis("p", 0)] * a + ww[Axis("q", 0)] * b for a in grid for b in grid
+                   if partial_merge_flops(spec, toy, {Axis("p", 0): a, Axis("q", 0): b}) <= budget * 20)
+        assert sum(ww[k] * r[k] for k in r) >= best - 1e-2
+
+
+def test_eval_helpers_route_features_to_the_right_head(tiny_basic):
+    """A merged 'backbone' that emits [merged | separate-1 | separate-2] features: with the blocks of get_fc_perm,
+    eval_perm_model must reproduce each source head's own predictions (accuracy 1 against them)."""
+    from pleas.methods.pleas_merging import eval_perm_model, eval_whole_model, get_fc_perm
+
+    t = tiny_basic
+    perm, costs = t.per_key("am_perm"), t.per_key("am_cost")
+    b1, b2, b1c, b2c = get_fc_perm(perm, t.spec, costs, 0.5)
+    width = len(b1) + len(b1c)
+    g = torch.Generator().manual_seed(5)
+    f1, f2 = torch.randn(16, width, generator=g), torch.randn(16, width, generator=g)
+    f2[:, b2] = f1[:, b1]                                 # merged units carry one shared value
+    merged_feats = torch.cat([f1[:, b1], f1[:, b1c], f2[:, b2c]], 1)
+
+    class Backbone(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.dummy = torch.nn.Parameter(torch.zeros(1))
+
+        def forward(self, idx):
+            return merged_feats[idx.long().flatten()]
+
+    heads = [torch.nn.Linear(width, 10), torch.nn.Linear(width, 10)]
+    for idx, (head, feats) in enumerate(zip(heads, (f1, f2))):
+        labels = head(feats).argmax(1)
+        loader = [(torch.arange(0, 8).view(8, 1), labels[:8]), (torch.arange(8, 16).view(8, 1), labels[8:])]
+        assert float(eval_perm_model(Backbone(), head, loader, 10, (b1, b2, b1c, b2c), idx)) == 1.0
+    whole = torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(4, 3))
+    x = torch.randn(6, 4, generator=g)
+    assert float(eval_whole_model(whole, [(x, whole(x).argmax(1))], 3)) == 1.0
