@@ -318,7 +318,8 @@ def main():
 
         roofs = {k: roof(k) for k in labels}
         # HBM-side bytes per launch from rocprofv3 PMC passes on standalone replays of the same grids (profiles/)
-        for key, fname in (("gram_partial", "gram_traffic.json"), ("conv_fwd", "fwd_traffic.json")):
+        for key, fname in (("gram_partial", "gram_traffic.json"), ("conv_fwd", "fwd_traffic.json"),
+                           ("conv_wgrad", "wgrad_traffic.json")):
             tpath = os.path.join(ROOT, "profiles", fname)
             if os.path.exists(tpath) and args.arch == "resnet101" and args.batch == 16:
                 roofs[key]["traffic"] = json.load(open(tpath)).get("hbm_bytes_per_launch")
