@@ -4,7 +4,10 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "pleas_hip.h"
 
@@ -64,5 +67,71 @@ struct ProfScope {
         if (on) prof_end(s);
     }
 };
+
+
+// ---- XCD-aware work-item order for grouped launches (host side).
+// Workgroup b of a grid runs on XCD b % 8, and every XCD has a private L2.  Items that read the same operand rows
+// (same `key`) are therefore given grid positions of ONE residue class, so that their re-reads hit that L2 instead
+// of crossing to the MALL / HBM once per XCD.  Groups go to the least-loaded of 8 queues (longest items first), the
+// queues are interleaved (position 8 j + x = j-th item of queue x) and short queues are padded with `noop`.
+// PLEAS_XCD_ORDER=0 in the environment keeps the plain longest-first order (A/B experiments).
+template <class Item>
+struct XcdWork {
+    double w;       // relative duration of the item
+    int64_t key;    // sharing key
+    Item it;
+};
+template <class Item>
+inline std::vector<Item> xcd_order_items(std::vector<XcdWork<Item>>& work, const Item& noop) {
+    std::vector<Item> out;
+    const char* env = std::getenv("PLEAS_XCD_ORDER");
+    if (env && env[0] == '0') {
+        std::stable_sort(work.begin(), work.end(), [](const XcdWork<Item>& a, const XcdWork<Item>& b) { return a.w > b.w; });
+        for (auto& x : work) out.push_back(x.it);
+        return out;
+    }
+    struct Group { double total = 0, longest = 0; std::vector<size_t> idx; };
+    std::vector<Group> groups;
+    {
+        std::vector<size_t> order(work.size());
+        for (size_t i = 0; i < work.size(); ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return work[a].key < work[b].key; });
+        int64_t last = 0;
+        for (size_t n = 0; n < order.size(); ++n) {
+            const size_t i = order[n];
+            if (n == 0 || work[i].key != last) groups.emplace_back();
+            last = work[i].key;
+            Group& g = groups.back();
+            g.total += work[i].w;
+            g.longest = std::max(g.longest, work[i].w);
+            g.idx.push_back(i);
+        }
+    }
+    // balance first (largest groups placed first, each on the least-loaded queue), then run every queue longest items first
+    std::stable_sort(groups.begin(), groups.end(), [](const Group& a, const Group& b) { return a.total > b.total; });
+    constexpr int kXcds = 8;
+    std::vector<size_t> qgroups[kXcds];
+    double load[kXcds] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+        int best = 0;
+        for (int x = 1; x < kXcds; ++x)
+            if (load[x] < load[best]) best = x;
+        load[best] += groups[gi].total;
+        qgroups[best].push_back(gi);
+    }
+    std::vector<size_t> queue[kXcds];
+    for (int x = 0; x < kXcds; ++x) {
+        std::stable_sort(qgroups[x].begin(), qgroups[x].end(),
+                         [&](size_t a, size_t b) { return groups[a].longest > groups[b].longest; });
+        for (size_t gi : qgroups[x])
+            for (size_t i : groups[gi].idx) queue[x].push_back(i);
+    }
+    size_t rows = 0;
+    for (int x = 0; x < kXcds; ++x) rows = std::max(rows, queue[x].size());
+    out.assign(rows * kXcds, noop);
+    for (int x = 0; x < kXcds; ++x)
+        for (size_t j = 0; j < queue[x].size(); ++j) out[j * kXcds + x] = work[queue[x][j]].it;
+    return out;
+}
 
 }  // namespace pleas

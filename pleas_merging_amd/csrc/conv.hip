@@ -233,6 +233,7 @@ __global__ __launch_bounds__(cThreads) void wgrad_batch_kernel(const WgradLayerD
                                                                const WgradItemDev* __restrict__ items) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const WgradItemDev it = items[blockIdx.x];
+    if (it.layer < 0) return;   // padding of the XCD-aware item order
     const WgradLayerDev L = layers[it.layer];
     switch (L.variant & 3) {  // block-uniform
         case 0: wgrad_dispatch<128, 128>(L, it, smem); break;
@@ -385,8 +386,7 @@ static int build_wgrad_plan(WgradPlan& P, const pleas_wgrad_layer* ly, int n) {
     P.lds = 0;
     std::vector<size_t> slab_off(n, 0);
     size_t slabs = 0;
-    struct Work { double w; WgradItemDev it; };
-    std::vector<Work> work;
+    std::vector<XcdWork<WgradItemDev>> work;
     int blk = 0;
     for (int i = 0; i < n; ++i) {
         const pleas_wgrad_layer& l = ly[i];
@@ -432,15 +432,14 @@ static int build_wgrad_plan(WgradPlan& P, const pleas_wgrad_layer* ly, int n) {
             for (int r = 0; r < R; ++r)
                 for (int tm = 0; tm < tms; ++tm)
                     for (int tn = 0; tn < tns; ++tn) {
-                        Work w;
+                        XcdWork<WgradItemDev> w;
                         w.it = WgradItemDev{i, tm, tn, r, s, s * cps, std::min((s + 1) * cps, nchunks), 0};
                         w.w = (double)(w.it.c_end - w.it.c_begin) * TM * TN;
+                        w.key = (int64_t)i * 65536 + s;   // every (tile, tap) of one K range reads the same residual / input rows
                         work.push_back(w);
                     }
     }
-    std::stable_sort(work.begin(), work.end(), [](const Work& a, const Work& b) { return a.w > b.w; });
-    P.items.reserve(work.size());
-    for (auto& w : work) P.items.push_back(w.it);
+    P.items = xcd_order_items(work, WgradItemDev{-1, 0, 0, 0, 0, 0, 0, 0});
     size_t off = 0;
     P.off_layers = off;
     off = walign(off + P.layers.size() * sizeof(WgradLayerDev));

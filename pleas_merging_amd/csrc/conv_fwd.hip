@@ -386,6 +386,7 @@ __global__ __launch_bounds__(fThreads) void fwd_batch_kernel(const FwdLayerDev* 
                                                              float* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const FwdItemDev it = items[blockIdx.x];
+    if (it.layer < 0) return;   // padding of the XCD-aware item order
     const FwdLayerDev L = layers[it.layer];
     switch (L.variant & 3) {
         case 0: fwd_tile<128, 4>(L, it, smem, partials); break;
@@ -458,8 +459,7 @@ static int build_fwd_plan(FwdPlan& P, const pleas_fwd_layer* ly, int n) {
     P.loss.assign(n, FwdLossDev());
     P.flops = P.bytes = 0;
     P.lds = 0;
-    struct Work { double w; FwdItemDev it; };
-    std::vector<Work> work;
+    std::vector<XcdWork<FwdItemDev>> work;
     int parts = 0;
     for (int i = 0; i < n; ++i) {
         const pleas_fwd_layer& l = ly[i];
@@ -487,9 +487,12 @@ static int build_fwd_plan(FwdPlan& P, const pleas_fwd_layer* ly, int n) {
         int slot = 0;
         for (int tm = 0; tm < tms; ++tm)
             for (int tp = 0; tp < tps; ++tp) {
-                Work w;
+                XcdWork<FwdItemDev> w;
                 w.it = FwdItemDev{i, tm, tp, slot++};
                 w.w = (double)ceil_div(Kd, fBK) * TM;
+                // all items of a layer re-read its weights (and, across tm, its input): keep them on one XCD; layers
+                // with many pixel tiles are cut into runs of 32 tiles so that the 8 queues still balance
+                w.key = (int64_t)i * 65536 + tp / 32;
                 work.push_back(w);
             }
         P.loss[i] = FwdLossDev{parts, slot, l.loss_scale, 0};
@@ -498,9 +501,7 @@ static int build_fwd_plan(FwdPlan& P, const pleas_fwd_layer* ly, int n) {
         P.flops += 2.0 * l.Cout * (double)Kd * (double)Ptot;
         P.bytes += ((double)l.Cin * l.N * l.Hin * l.Win + 3.0 * l.Cout * (double)Ptot) * sizeof(float);
     }
-    std::stable_sort(work.begin(), work.end(), [](const Work& a, const Work& b) { return a.w > b.w; });
-    P.items.reserve(work.size());
-    for (auto& w : work) P.items.push_back(w.it);
+    P.items = xcd_order_items(work, FwdItemDev{-1, 0, 0, 0});
     P.n_parts = parts;
     size_t off = 0;
     P.off_layers = off;

@@ -257,6 +257,7 @@ __global__ __launch_bounds__(kThreads) void gram_batch_kernel(const GramNodeDev*
                                                               const GramItemDev* __restrict__ items) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const GramItemDev it = items[blockIdx.x];
+    if (it.node < 0) return;   // padding of the XCD-aware item order
     const GramNodeDev nd = nodes[it.node];
     GramGeom g;
     g.x = nd.x;
@@ -440,7 +441,7 @@ extern "C" int pleas_gram_accum(const float* x, const float* y, int B, int C, in
 namespace pleas {
 
 static int g_item_chunks = 112;
-static int g_xcd_order = 1;  // K chunks per work item (K = 3584): nodes with longer K are split
+static int g_xcd_order = 2;  // 0: longest first; 1: compact tile block per XCD inside a (node, split); 2: whole (node, split) per XCD
 
 struct BatchPlan {
     std::vector<int64_t> key;
@@ -473,6 +474,7 @@ static int build_batch_plan(BatchPlan& P, const pleas_gram_node* nd, int n, floa
     size_t slabs = 0;
     struct Work { double w; GramItemDev it; };
     std::vector<Work> work;
+    std::vector<XcdWork<GramItemDev>> xwork;
     for (int i = 0; i < n; ++i) {
         const int B = nd[i].B, C = nd[i].C;
         const int64_t HW = nd[i].HW;
@@ -504,15 +506,21 @@ static int build_batch_plan(BatchPlan& P, const pleas_gram_node* nd, int n, floa
                     w.it = GramItemDev{i, tm, tn, s, s * cps, std::min((s + 1) * cps, nchunks), 0, 0};
                     w.w = (double)(w.it.c_end - w.it.c_begin) * tile * tile;
                     work.push_back(w);
+                    // every tile of one (node, K range) streams the same operand rows, chunk by chunk and roughly in step
+                    xwork.push_back(XcdWork<GramItemDev>{w.w, (int64_t)i * 65536 + s, w.it});
                 }
     }
-    std::stable_sort(work.begin(), work.end(), [](const Work& a, const Work& b) { return a.w > b.w; });
-    P.items.reserve(work.size());
-    for (auto& w : work) P.items.push_back(w.it);
+    if (g_xcd_order == 2) {
+        P.items = xcd_order_items(xwork, GramItemDev{-1, 0, 0, 0, 0, 0, 0, 0});
+    } else {
+        std::stable_sort(work.begin(), work.end(), [](const Work& a, const Work& b) { return a.w > b.w; });
+        P.items.reserve(work.size());
+        for (auto& w : work) P.items.push_back(w.it);
+    }
     // XCD-aware tile order: workgroups b and b+8 share an XCD (private L2).  Inside every run of
     // items that belongs to one (node, split), give each XCD a compact sr x sc block of output
     // tiles, so the operand rows a tile row / column needs are fetched by one L2 instead of eight.
-    if (g_xcd_order) {
+    if (g_xcd_order == 1) {
         size_t pos = 0;
         while (pos < P.items.size()) {
             size_t end = pos;
@@ -580,7 +588,7 @@ static std::vector<int64_t> batch_key(const pleas_gram_node* nd, int n, float* c
     k.push_back(n);
     k.push_back(n_groups);
     k.push_back((int64_t)(uintptr_t)ws);
-    k.push_back(g_item_chunks * 2 + g_xcd_order);
+    k.push_back(g_item_chunks * 4 + g_xcd_order);
     for (int i = 0; i < n; ++i) {
         k.push_back(nd[i].B);
         k.push_back(nd[i].C);
