@@ -82,10 +82,10 @@ struct XcdWork {
     Item it;
 };
 template <class Item>
-inline std::vector<Item> xcd_order_items(std::vector<XcdWork<Item>>& work, const Item& noop) {
+inline std::vector<Item> xcd_order_items(std::vector<XcdWork<Item>>& work, const Item& noop, bool by_default = true) {
     std::vector<Item> out;
     const char* env = std::getenv("PLEAS_XCD_ORDER");
-    if (env && env[0] == '0') {
+    if (env ? env[0] == '0' : !by_default) {
         std::stable_sort(work.begin(), work.end(), [](const XcdWork<Item>& a, const XcdWork<Item>& b) { return a.w > b.w; });
         for (auto& x : work) out.push_back(x.it);
         return out;

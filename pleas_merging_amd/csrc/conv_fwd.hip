@@ -501,7 +501,10 @@ static int build_fwd_plan(FwdPlan& P, const pleas_fwd_layer* ly, int n) {
         P.flops += 2.0 * l.Cout * (double)Kd * (double)Ptot;
         P.bytes += ((double)l.Cin * l.N * l.Hin * l.Win + 3.0 * l.Cout * (double)Ptot) * sizeof(float);
     }
-    P.items = xcd_order_items(work, FwdItemDev{-1, 0, 0, 0});
+    // Off by default for this kernel (PLEAS_XCD_ORDER=1 turns it on): it cuts FETCH_SIZE by 32 % (8.3 -> 6.1 GB per launch)
+    // but costs 1-4 % of time -- co-resident workgroups of one layer reach their latency-bound epilogues together,
+    // while the plain longest-first order mixes layers on a CU.
+    P.items = xcd_order_items(work, FwdItemDev{-1, 0, 0, 0}, /*by_default=*/false);
     P.n_parts = parts;
     size_t off = 0;
     P.off_layers = off;
