@@ -128,7 +128,11 @@ def run_job(spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, ratio, dp, 
 
     perm, costs = activation_matching(spec, m1, m2, match_loader, len(match_loader), output_costs=True)
     m3 = partial_merge(spec, m1, m2, perm, costs, ratio)
-    fit = PleasFitter(m1, m2, m3, spec, perm, costs, ratio, n_pleas_sched, data_parallel=dp)
+    # Data parallel: each rank's share of an update is small (batch / world samples), so the host-side dispatch of the two
+    # source forwards (~10 ms) and the gradient all-reduce dominate: replay the sources from hipGraphs and enqueue the
+    # next batch's sources before the current update, so that they run beside its all-reduce.
+    fit = PleasFitter(m1, m2, m3, spec, perm, costs, ratio, n_pleas_sched, data_parallel=dp, graph_sources=dp)
+    lookahead = lookahead or dp
     for _ in fit.steps((x for x, _ in pleas_loader), lookahead=lookahead):
         pass
     return fit.finish(), perm, costs

@@ -360,7 +360,8 @@ class PleasFitter:
         x_static = x.clone()
         graph = torch.cuda.CUDAGraph()
         torch.cuda.current_stream(self.device).synchronize()
-        with torch.cuda.graph(graph):
+        # thread_local: other threads (e.g. the collective watchdog of torch.distributed) may keep calling the runtime
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             cap = torch.cuda.current_stream(self.device)
             side = self._side_streams or (cap, cap)
             for stream, model in zip(side, (self.src1, self.src2)):
