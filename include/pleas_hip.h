@@ -119,6 +119,22 @@ int pleas_merge_blocks(const float* w1, const float* w2, float* out, int64_t out
                        int64_t inner, int rows_src, int cols_src, const int32_t* row1, const int32_t* row2,
                        const int32_t* col1, const int32_t* col2, int n_merged_rows, void* stream);
 
+/* Grouped form: the 1-axis block merge of MANY tensors (the merged layer inputs of one PLeaS update,
+ * pleas_merging.py:125-147) in ONE launch.  items: HOST array; tensor pointers and maps are DEVICE pointers.
+ * Tensors are viewed [outer][rows][inner]; semantics per tensor as pleas_merge_blocks without column maps.
+ * Tensors with inner % 4 == 0 must be 16-byte aligned.  ws / ws_fresh as in pleas_gram_batch. */
+typedef struct pleas_merge_item {
+    const float* w1;      /* [outer][rows_src][inner] */
+    const float* w2;
+    float* out;           /* [outer][rows_out][inner] */
+    const int32_t* row1;  /* [rows_out], -1 = absent */
+    const int32_t* row2;
+    int64_t outer, inner;
+    int rows_out, rows_src, n_merged;
+} pleas_merge_item;
+size_t pleas_merge_batch_ws_bytes(const pleas_merge_item* items, int n_items);
+int pleas_merge_batch(const pleas_merge_item* items, int n_items, void* ws, size_t ws_bytes, int ws_fresh, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Frozen-source forward: inference BatchNorm (+ residual add) (+ ReLU) in one pass.
  *

@@ -25,6 +25,8 @@ SIGNATURES = {
     "pleas_lsap_batched": (c_int, [POINTER(c_void_p), POINTER(c_int), c_int, c_int, POINTER(c_void_p), c_void_p]),
     "pleas_merge_blocks": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int, c_int, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "pleas_merge_batch_ws_bytes": (c_size_t, [c_void_p, c_int]),
+    "pleas_merge_batch": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "pleas_bn_act": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_void_p]),
     "pleas_masked_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
                                   c_float, c_int, c_void_p]),
@@ -55,6 +57,12 @@ SIGNATURES = {
     "pleas_gram_batch": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_int), c_int, c_int, c_int, c_void_p,
                                  c_size_t, c_int, c_void_p]),
 }
+
+
+class MergeItem(ctypes.Structure):
+    """struct pleas_merge_item"""
+    _fields_ = [("w1", c_void_p), ("w2", c_void_p), ("out", c_void_p), ("row1", c_void_p), ("row2", c_void_p),
+                ("outer", c_int64), ("inner", c_int64), ("rows_out", c_int), ("rows_src", c_int), ("n_merged", c_int)]
 
 
 class FwdLayer(ctypes.Structure):

@@ -334,6 +334,60 @@ def loss_final(partials: torch.Tensor, n_partials: torch.Tensor, scale: torch.Te
     check(rc, "pleas_loss_final")
 
 
+class MergeBatch:
+    """Block gather / average of many tensors along one axis in ONE grouped launch (``pleas_merge_batch``): the merged
+    inputs of all layers of a PLeaS update.  ``add`` returns the output tensor (filled at ``flush``)."""
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self._keep: list = []
+        self._geo: list = []
+        self._arr = None
+        self._ws = None
+        self._fresh = 1
+
+    def add(self, w1: torch.Tensor, w2: torch.Tensor, row_axis: int, row1: torch.Tensor, row2: torch.Tensor,
+            n_merged_rows: int) -> torch.Tensor:
+        if w1.shape != w2.shape or not w1.is_cuda or w1.dtype != torch.float32 or w2.dtype != torch.float32:
+            raise PleasHipError("MergeBatch.add: fp32 CUDA sources of equal shape expected")
+        w1, w2 = w1.contiguous(), w2.contiguous()
+        shape = list(w1.shape)
+        row_axis = row_axis % w1.dim()
+        rows_out = int(row1.numel())
+        out = torch.empty(shape[:row_axis] + [rows_out] + shape[row_axis + 1:], dtype=torch.float32, device=w1.device)
+        self._keep.append((w1, w2, out, row1, row2))
+        self._geo.append((math.prod(shape[:row_axis]), math.prod(shape[row_axis + 1:]), rows_out, shape[row_axis],
+                          int(n_merged_rows)))
+        return out
+
+    def flush(self) -> None:
+        n = len(self._keep)
+        if n == 0:
+            return
+        if self._arr is None or len(self._arr) != n:
+            self._arr = (_lib.MergeItem * n)()
+        for i, ((w1, w2, out, row1, row2), geo) in enumerate(zip(self._keep, self._geo)):
+            a = self._arr[i]
+            a.w1, a.w2, a.out, a.row1, a.row2 = w1.data_ptr(), w2.data_ptr(), out.data_ptr(), row1.data_ptr(), row2.data_ptr()
+            a.outer, a.inner, a.rows_out, a.rows_src, a.n_merged = geo
+        lib = _lib.lib()
+        if self._ws is None:
+            need = int(lib.pleas_merge_batch_ws_bytes(self._arr, n))
+            if need == 0:
+                raise PleasHipError("pleas_merge_batch_ws_bytes rejected the tensor list: %s" % lib.pleas_last_error().decode())
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._fresh = 1
+        rc = lib.pleas_merge_batch(self._arr, n, self._ws.data_ptr(), self._ws.numel(), self._fresh, _stream())
+        self._fresh = 0
+        if rc == -12:
+            self._ws = None
+            self.flush()
+            return
+        check(rc, "pleas_merge_batch")
+        self._keep.clear()
+        self._geo.clear()
+
+
 class FwdBatch:
     """Forward + target + residual + loss of all merged layers of one update in ONE grouped launch
     (``pleas_fwd_batch``).  ``add`` per layer, ``flush(loss)`` once per update."""

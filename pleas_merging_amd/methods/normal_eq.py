@@ -73,9 +73,11 @@ class NormalEqFitter(PleasFitter):
             if name not in self.t1_in or name not in self.t2_in:
                 print("Key error on %s" % name)
                 continue
-            ip = ops.merge_blocks(self.t1_in[name], self.t2_in[name], 1, *plan.in_maps)
-            op = ops.merge_blocks(self.t1_out[name], self.t2_out[name], 1, *plan.out_maps)
             mod = plan.mod
+            grouped = self._hip_geometry_ok(plan, self.t1_in[name]) and plan.b is None
+            merge = self.merge.add if grouped else ops.merge_blocks     # grouped: filled by merge.flush() below
+            ip = merge(self.t1_in[name], self.t2_in[name], 1, *plan.in_maps)
+            op = merge(self.t1_out[name], self.t2_out[name], 1, *plan.out_maps)
             if self._hip_geometry_ok(plan, ip):
                 if plan.is_conv:
                     geo = (tuple(mod.kernel_size), mod.stride[0], mod.padding[0])
@@ -99,6 +101,7 @@ class NormalEqFitter(PleasFitter):
                 s[0].add_(rows_u.sum(0))
                 s[1].add_(op.reshape(-1, op.shape[-1]).sum(0))
                 s[2].add_(float(rows_u.shape[0]))
+        self.merge.flush()
         self.neq.flush()
         self.wgrad.flush()
         self.batches_seen += 1

@@ -271,6 +271,7 @@ class PleasFitter:
             raise ValueError("forward must be 'hip' (fused MFMA kernel) or 'vendor' (MIOpen + pleas_target_residual)")
         self.forward = forward
         self.fwd = hip_ops.FwdBatch(dev)
+        self.merge = hip_ops.MergeBatch(dev)
         self._fwd_loss = None
         self._fwd_index = None
         # graph_sources=True: from the second batch of a shape on, the two source forwards (~420 launches, ~35 us of host
@@ -291,16 +292,19 @@ class PleasFitter:
         name = plan.name
         ip1, ip2 = self.t1_in[name], self.t2_in[name]
         o1, o2 = self.t1_out[name], self.t2_out[name]
-        ip = ops.merge_blocks(ip1, ip2, 1, *plan.in_maps)
         mod = plan.mod
         r1, r2, nm = plan.out_maps
         cout = plan.w_shape[0]
         if cout != r1.numel():
             raise RuntimeError("layer %s: %d merged outputs vs %d target blocks" % (name, cout, r1.numel()))
         square = plan.is_conv and _square_conv(mod)
-        linear = (not plan.is_conv) and ip.dim() == 2
+        linear = (not plan.is_conv) and ip1.dim() == 2
         geo = (tuple(mod.kernel_size), mod.stride[0], mod.padding[0]) if plan.is_conv else ((1, 1), 1, 0)
-        if self.forward == "hip" and (square or linear):
+        hip_forward = self.forward == "hip" and (square or linear)
+        # merged input: queued for the ONE grouped merge launch that precedes the grouped forward (merge.flush); the
+        # vendor-forward path consumes it right here and takes the single-tensor launch
+        ip = self.merge.add(ip1, ip2, 1, *plan.in_maps) if hip_forward else ops.merge_blocks(ip1, ip2, 1, *plan.in_maps)
+        if hip_forward:
             resid = torch.empty((ip.shape[0], cout) + tuple(o1.shape[2:]), dtype=torch.float32, device=ip.device)
             n = resid.numel() * self.world           # the mean runs over the full (global) batch
             self.fwd.add(ip, plan.w, plan.b, o1, o2, r1, r2, nm, resid, 2.0 / n, 1.0 / n, *geo,
@@ -476,6 +480,7 @@ class PleasFitter:
                     print("Key error on %s" % plan.name)
                     continue
                 self._fit_layer(idx, plan)
+        self.merge.flush()   # ONE grouped launch: the merged inputs of every layer
         if self._fwd_rows:   # ONE grouped MFMA launch: forward + target + residual + loss of every merged layer
             if self._fwd_loss is None or self._fwd_loss.numel() != len(self._fwd_rows):
                 self._fwd_loss = torch.zeros(len(self._fwd_rows), dtype=torch.float32, device=self.device)

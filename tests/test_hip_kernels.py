@@ -230,6 +230,38 @@ def test_fwd_batch_rejects_kpos_major_with_ragged_channels(ops):
         batch.flush(torch.zeros(1, device="cuda"))
 
 
+def test_merge_batch_equals_single_tensor_launches(ops):
+    """Grouped block merge of many tensors == pleas_merge_blocks per tensor, bit for bit: 16-B and scalar pieces,
+    ragged tails, 2-D tensors, absent rows that must not leak (NaN planted in the row an absent source is read from)."""
+    from pleas_merging_amd.methods.partial_matching import block_maps
+
+    g = torch.Generator().manual_seed(41)
+    cases = [((3, 9, 5, 5), (torch.tensor([0, 2, 4, 6]), torch.tensor([1, 3, 5, 7]), torch.tensor([1, 3, 5, 7, 8]), torch.tensor([0, 2, 4, 6, 8]))),
+             ((4, 64, 14, 14), None), ((2, 40, 7, 7), None), ((5, 33), None), ((16, 256, 28, 28), None), ((1, 8, 1, 1), None)]
+    batch = ops.MergeBatch(torch.device("cuda"))
+    outs, wants = [], []
+    for shape, blk in cases:
+        C = shape[1]
+        if blk is None:
+            p = torch.randperm(C, generator=g)
+            nm = C // 3
+            blk = (torch.arange(nm), p[:nm], torch.arange(nm, C), p[nm:])
+        x1, x2 = torch.randn(shape, generator=g).cuda(), torch.randn(shape, generator=g).cuda()
+        x2[:, 0] = float("nan") if 0 not in blk[1].tolist() + blk[3].tolist() else x2[:, 0]
+        r1, r2, nm = block_maps(blk, "cuda")
+        outs.append(batch.add(x1, x2, 1, r1, r2, nm))
+        wants.append(ops.merge_blocks(x1, x2, 1, r1, r2, nm))
+    batch.flush()
+    for o, w in zip(outs, wants):
+        assert o.shape == w.shape and torch.equal(o, w)
+    # a different tensor list re-plans instead of reusing stale tables
+    x1, x2 = torch.randn(2, 6, 4, generator=g).cuda(), torch.randn(2, 6, 4, generator=g).cuda()
+    r = torch.arange(6, dtype=torch.int32, device="cuda")
+    out = batch.add(x1, x2, 1, r, r, 6)
+    batch.flush()
+    assert torch.equal(out, (x1 + x2) * 0.5)
+
+
 def test_masked_adam_matches_torch(ops):
     g = torch.Generator().manual_seed(5)
     p0 = torch.randn(1000, generator=g)
