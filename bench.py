@@ -71,8 +71,8 @@ def parse():
     ap.add_argument("--lookahead", type=int, default=0, help="1: the next batch's source forwards are enqueued before the "
                     "current PLeaS update and share the GPU with it (PleasFitter.steps(lookahead=True): about -3 %% "
                     "wall-clock, but per-kernel durations then include the contention); 0 (default): one batch at a time")
-    ap.add_argument("--profile-all", action="store_true", help="also bracket the many-launch elementwise kernels "
-                    "(bn_act, merge_blocks) with events: complete phases_ms, slightly slower timed region")
+    ap.add_argument("--profile-all", action="store_true", help="also bracket the many-launch elementwise kernel "
+                    "(bn_act) with events: complete phases_ms, slightly slower timed region")
     ap.add_argument("--cpu-sample-batch", type=int, default=2)
     ap.add_argument("--alt-solver", action="store_true", help="also time the closed-form PLeaS phase "
                                                               "(solver=normal_eq) after the headline run")
@@ -279,10 +279,10 @@ def main():
                 args.ratio, dp, bool(args.lookahead))
 
     log("warm-up done")
-    # ---- timed region.  Events bracket the few-launches-per-step kernels only: the elementwise kernels launched
-    # hundreds of times per step (bn_act, merge_blocks) would pay two event records per launch inside the timed region.
+    # ---- timed region.  Events bracket the few-launches-per-step kernels only: bn_act runs ~200 times per step and would
+    # pay two event records per launch inside the timed region.
     hip_ops.profile_reset()
-    hip_ops.profile_enable(True, skip=() if args.profile_all else ("bn_act", "merge_blocks"))
+    hip_ops.profile_enable(True, skip=() if args.profile_all else ("bn_act",))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
