@@ -127,7 +127,7 @@ def run_job(spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, ratio, dp, 
     from pleas_merging_amd.methods.pleas_merging import PleasFitter
 
     perm, costs = activation_matching(spec, m1, m2, match_loader, len(match_loader), output_costs=True)
-    m3 = partial_merge(spec, m1, m2, perm, costs, ratio)
+    m3 = partial_merge(spec, m1, m2, perm, costs, ratio, device=next(m1.parameters()).device)   # stays on the GPU
     # Data parallel: each rank's share of an update is small (batch / world samples), so the host-side dispatch of the two
     # source forwards (~10 ms) and the gradient all-reduce dominate: replay the sources from hipGraphs and enqueue the
     # next batch's sources before the current update, so that they run beside its all-reduce.

@@ -116,21 +116,25 @@ def merged_state(spec: PermutationSpec, state1: Dict[str, torch.Tensor], state2:
     return out
 
 
-def build_partial_merge_model(spec: PermutationSpec, model1: nn.Module, model2: nn.Module, blocks: Blocks) -> nn.Module:
-    """Reference: partial_matching.py:91-185 -> a NEW eval-mode CPU module whose permutable
-    tensors are frozen ``Parameter``s of the merged width; everything else is model1's."""
+def build_partial_merge_model(spec: PermutationSpec, model1: nn.Module, model2: nn.Module, blocks: Blocks,
+                              device=None) -> nn.Module:
+    """Reference: partial_matching.py:91-185 -> a NEW eval-mode module whose permutable tensors are frozen
+    ``Parameter``s of the merged width; everything else is model1's.  ``device=None``: on the CPU like the reference
+    (its callers ``.cuda()`` it next); a device keeps the merged tensors where the kernel assembled them."""
     new = merged_state(spec, model1.state_dict(), model2.state_dict(), blocks)
-    model3 = deepcopy(model1).eval().cpu()
+    target = torch.device("cpu") if device is None else torch.device(device)
+    model3 = deepcopy(model1).eval().to(target)
     for name, w in new.items():
-        set_attr(model3, name.split("."), nn.Parameter(w.cpu(), requires_grad=False))
+        set_attr(model3, name.split("."), nn.Parameter(w.to(target), requires_grad=False))
     return model3
 
 
 def partial_merge(spec: PermutationSpec, model1: nn.Module, model2: nn.Module, perm: Permutation,
                   costs: Dict[Axis, torch.Tensor], ratios: Ratios, zero_augmented: bool = False,
-                  return_blocks: bool = False):
+                  return_blocks: bool = False, device=None):
     """Reference: partial_matching.py:188-202 (same positional order; ``zero_augmented`` lands in
-    the unused solver slot of ``get_blocks`` exactly as there)."""
+    the unused solver slot of ``get_blocks`` exactly as there).  ``device`` (addition): where the merged model is
+    built; default CPU as in the reference."""
     blocks = get_blocks(spec, perm, costs, ratios, zero_augmented)
-    model3 = build_partial_merge_model(spec, model1, model2, blocks)
+    model3 = build_partial_merge_model(spec, model1, model2, blocks, device)
     return (model3, blocks) if return_blocks else model3

@@ -52,17 +52,23 @@ def get_gradient_mask(perm_blocks, model_weights: Dict[str, nn.Module]) -> List[
     """
     masks = []
     for name, layer in model_weights.items():
-        bi = perm_blocks.get(Axis("%s.weight" % name, 1))
-        bo = perm_blocks.get(Axis("%s.weight" % name, 0))
-        ni, mi = (len(bi[0]), len(bi[2])) if bi is not None else (3, 0)
-        no, mo = (len(bo[0]), len(bo[2])) if bo is not None else (1000, 0)
+        frozen = _frozen_blocks(perm_blocks, name)
         for p in layer.parameters():
             mask = torch.ones_like(p)
             if p.dim() >= 2:
-                mask[ni:ni + mi, no + mo:no + 2 * mo] = 0.0
-                mask[ni + mi:ni + 2 * mi, no:no + mo] = 0.0
+                for rows, cols in frozen:
+                    mask[rows, cols] = 0.0
             masks.append(mask)
     return masks
+
+
+def _frozen_blocks(perm_blocks, name: str):
+    """The two (axis-0 slice, axis-1 slice) blocks of ``name.weight`` that stay frozen (reference :31-37, :57-58)."""
+    bi = perm_blocks.get(Axis("%s.weight" % name, 1))
+    bo = perm_blocks.get(Axis("%s.weight" % name, 0))
+    ni, mi = (len(bi[0]), len(bi[2])) if bi is not None else (3, 0)
+    no, mo = (len(bo[0]), len(bo[2])) if bo is not None else (1000, 0)
+    return ((slice(ni, ni + mi), slice(no + mo, no + 2 * mo)), (slice(ni + mi, ni + 2 * mi), slice(no, no + mo)))
 
 
 def _square_conv(mod: nn.Conv2d) -> bool:
@@ -223,8 +229,7 @@ class PleasFitter:
         self.g = torch.zeros(total, dtype=torch.float32, device=dev)
         self.m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.v = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.mask = torch.ones(total, dtype=torch.float32, device=dev)
-        masks = get_gradient_mask(self.perm_blocks, layers)
+        self.mask = torch.ones(total, dtype=torch.float32, device=dev)   # frozen blocks are zeroed in place below
         self.plans: List[_LayerPlan] = []
         off, k = 0, 0
         for name, mod in layers.items():
@@ -240,9 +245,18 @@ class PleasFitter:
                 n = prm.numel()
                 kp = plan.kpos and pname == "weight"
                 shape = (prm.shape[0], prm.shape[2], prm.shape[3], prm.shape[1]) if kp else tuple(prm.shape)
-                self.p[off:off + n].copy_((prm.detach().permute(0, 2, 3, 1) if kp else prm.detach()).reshape(-1))
-                self.mask[off:off + n].copy_((masks[k].permute(0, 2, 3, 1) if kp else masks[k]).reshape(-1))
+                # model3 may live on the host: move first, permute on the device (a strided copy of a 3x3 weight on the CPU
+                # costs milliseconds), and write the mask's frozen blocks straight into the arena
+                src = prm.detach().to(dev, non_blocking=True)
                 view, gview = self.p[off:off + n].view(shape), self.g[off:off + n].view(shape)
+                view.copy_(src.permute(0, 2, 3, 1) if kp else src)
+                if prm.dim() >= 2:
+                    mview = self.mask[off:off + n].view(shape)
+                    for rows, cols in _frozen_blocks(self.perm_blocks, name):
+                        if kp:
+                            mview[rows, :, :, cols] = 0.0
+                        else:
+                            mview[rows, cols] = 0.0
                 if pname == "weight":
                     plan.w, plan.gw, plan.w_shape, plan.off_w = view, gview, tuple(prm.shape), off
                 else:

@@ -65,6 +65,32 @@ def test_plug_points_generic_path(tiny_basic):
         assert (hip_solve_lsa(costs[k]) == t.per_key("am_perm")[k]).all()
 
 
+def test_partial_merge_on_device_equals_reference_placement(tiny_basic):
+    """``partial_merge(..., device=...)`` (addition) keeps the merged model on the GPU; the default is a CPU module as
+    in the reference.  Same tensors either way, and the fitter accepts both."""
+    from pleas.methods.partial_matching import partial_merge
+    from pleas.methods.pleas_merging import PleasFitter
+
+    t = tiny_basic
+    m1, m2 = _cuda_pair(t)
+    perm = t.per_key("am_perm")
+    costs = {k: v.cuda() for k, v in t.per_key("am_cost").items()}
+    host = partial_merge(t.spec, m1, m2, perm, costs, 0.5)
+    dev = partial_merge(t.spec, m1, m2, perm, costs, 0.5, device="cuda")
+    assert all(not p.is_cuda for p in host.parameters()) and all(p.is_cuda for p in dev.parameters())
+    for (k, a), (_, b) in zip(host.state_dict().items(), dev.state_dict().items()):
+        assert torch.equal(a, b.cpu()), k
+    outs = []
+    for m3 in (host, dev):
+        fit = PleasFitter(m1, m2, m3, t.spec, perm, costs, 0.5, 3, num_classes=10)
+        for x, _ in t.batches():
+            fit.step(x)
+        outs.append({k: v.cpu().clone() for k, v in fit.finish().state_dict().items()})
+    for k in outs[0]:
+        if k != DEGENERATE and outs[0][k].dtype.is_floating_point:
+            assert _rel(outs[0][k], outs[1][k]) < 1e-6, k
+
+
 def test_models_keep_mode_and_device(tiny_basic):
     from pleas.methods.activation_matching import activation_matching
 
