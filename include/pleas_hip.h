@@ -149,6 +149,10 @@ int pleas_merge_batch(const pleas_merge_item* items, int n_items, void* ws, size
  */
 int pleas_bn_act(const float* x, const float* scale, const float* shift, const float* res, float* y, int64_t n,
                  int channels, int64_t inner, int relu, void* stream);
+/* Same pass with the intermediate values kept, for activation matching (activation_matching.py:49-100 measures EVERY
+ * node of the chain): y_bn = x * scale + shift and y_sum = y_bn + res are written when non-NULL, y is the final value. */
+int pleas_bn_act_tracked(const float* x, const float* scale, const float* shift, const float* res, float* y_bn,
+                         float* y_sum, float* y, int64_t n, int channels, int64_t inner, int relu, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Fused masked Adam step over a flat parameter arena.

@@ -28,6 +28,8 @@ SIGNATURES = {
     "pleas_merge_batch_ws_bytes": (c_size_t, [c_void_p, c_int]),
     "pleas_merge_batch": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "pleas_bn_act": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_void_p]),
+    "pleas_bn_act_tracked": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
+                                     c_int64, c_int, c_void_p]),
     "pleas_masked_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
                                   c_float, c_int, c_void_p]),
     "pleas_sqerr_ws_bytes": (c_size_t, [c_int64]),

@@ -118,14 +118,16 @@ __global__ __launch_bounds__(kEwThreads) void merge_blocks_kernel(
 
 // ------------------------------------------------------------------------------------------
 // Inference BatchNorm folded to one affine map per channel, optional residual add, optional ReLU:
-//   y[n][c][i] = act(x[n][c][i] * scale[c] + shift[c] (+ res[n][c][i]))
-// One pass over x (and res), one write: replaces the vendor BN + in-place add + in-place ReLU chain
-// (3 kernels, 7 tensor passes) of a frozen source model.  `inner_v` = HW / VEC.
+//   bn = x[n][c][i] * scale[c] + shift[c];   sum = bn (+ res[n][c][i]);   act = relu ? max(sum, 0) : sum
+// One pass over x (and res): replaces the vendor BN + in-place add + in-place ReLU chain (3 kernels, 7 tensor passes)
+// of a frozen source model.  `y_act` is always written; `y_bn` / `y_sum` (nullable) are the intermediate values for
+// callers that track them (activation matching measures every node).  `inner_v` = HW / VEC.
 template <int VEC>
 __global__ __launch_bounds__(kEwThreads) void bn_act_kernel(const float* __restrict__ x,
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift,
-                                                            const float* __restrict__ res, float* __restrict__ y,
+                                                            const float* __restrict__ res, float* __restrict__ y_bn,
+                                                            float* __restrict__ y_sum, float* __restrict__ y,
                                                             int64_t total_v, unsigned inner_v, unsigned channels,
                                                             int relu) {
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total_v;
@@ -137,16 +139,22 @@ __global__ __launch_bounds__(kEwThreads) void bn_act_kernel(const float* __restr
             const f32x4 q = reinterpret_cast<const f32x4*>(x)[idx];
             f32x4 r = {0.f, 0.f, 0.f, 0.f};
             if (res) r = reinterpret_cast<const f32x4*>(res)[idx];
-            f32x4 o;
+            f32x4 bn, sm, o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float t = fmaf(q[e], a, b) + r[e];
-                o[e] = relu ? fmaxf(t, 0.f) : t;
+                bn[e] = fmaf(q[e], a, b);
+                sm[e] = bn[e] + r[e];
+                o[e] = relu ? fmaxf(sm[e], 0.f) : sm[e];
             }
+            if (y_bn) reinterpret_cast<f32x4*>(y_bn)[idx] = bn;
+            if (y_sum) reinterpret_cast<f32x4*>(y_sum)[idx] = sm;
             reinterpret_cast<f32x4*>(y)[idx] = o;
         } else {
-            const float t = fmaf(x[idx], a, b) + (res ? res[idx] : 0.f);
-            y[idx] = relu ? fmaxf(t, 0.f) : t;
+            const float bn = fmaf(x[idx], a, b);
+            const float sm = bn + (res ? res[idx] : 0.f);
+            if (y_bn) y_bn[idx] = bn;
+            if (y_sum) y_sum[idx] = sm;
+            y[idx] = relu ? fmaxf(sm, 0.f) : sm;
         }
     }
 }
@@ -272,24 +280,37 @@ extern "C" int pleas_merge_blocks(const float* w1, const float* w2, float* out, 
     return PLEAS_OK;
 }
 
-extern "C" int pleas_bn_act(const float* x, const float* scale, const float* shift, const float* res, float* y,
-                            int64_t n, int channels, int64_t inner, int relu, void* stream_) {
+static int bn_act_launch(const float* x, const float* scale, const float* shift, const float* res, float* y_bn,
+                         float* y_sum, float* y, int64_t n, int channels, int64_t inner, int relu, void* stream_) {
     if (!x || !scale || !shift || !y) return bad_arg("null pointer");
     if (n < 0 || channels <= 0 || inner <= 0) return bad_arg("negative size");
     const int64_t total = n * channels * inner;
     if (total == 0) return PLEAS_OK;
     if (n * channels >= ((int64_t)1 << 31) || inner >= ((int64_t)1 << 31)) return bad_arg("tensor too large");
     hipStream_t stream = (hipStream_t)stream_;
-    const bool vec = inner % 4 == 0 && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) & 15) == 0);
-    ProfScope prof(kProfBnAct, 0.0, (res ? 3.0 : 2.0) * total * sizeof(float), stream);
+    const uintptr_t all = (uintptr_t)x | (uintptr_t)y | (uintptr_t)res | (uintptr_t)y_bn | (uintptr_t)y_sum;
+    const bool vec = inner % 4 == 0 && (all & 15) == 0;
+    const double passes = 2.0 + (res ? 1.0 : 0.0) + (y_bn ? 1.0 : 0.0) + (y_sum ? 1.0 : 0.0);
+    ProfScope prof(kProfBnAct, 0.0, passes * total * sizeof(float), stream);
     if (vec)
         hipLaunchKernelGGL((bn_act_kernel<4>), dim3(ew_grid(total / 4)), dim3(kEwThreads), 0, stream, x, scale, shift, res,
-                           y, total / 4, (unsigned)(inner / 4), (unsigned)channels, relu);
+                           y_bn, y_sum, y, total / 4, (unsigned)(inner / 4), (unsigned)channels, relu);
     else
-        hipLaunchKernelGGL((bn_act_kernel<1>), dim3(ew_grid(total)), dim3(kEwThreads), 0, stream, x, scale, shift, res, y,
-                           total, (unsigned)inner, (unsigned)channels, relu);
+        hipLaunchKernelGGL((bn_act_kernel<1>), dim3(ew_grid(total)), dim3(kEwThreads), 0, stream, x, scale, shift, res,
+                           y_bn, y_sum, y, total, (unsigned)inner, (unsigned)channels, relu);
     PLEAS_LAUNCH_CHECK("bn_act_kernel");
     return PLEAS_OK;
+}
+
+extern "C" int pleas_bn_act(const float* x, const float* scale, const float* shift, const float* res, float* y,
+                            int64_t n, int channels, int64_t inner, int relu, void* stream_) {
+    return bn_act_launch(x, scale, shift, res, nullptr, nullptr, y, n, channels, inner, relu, stream_);
+}
+
+extern "C" int pleas_bn_act_tracked(const float* x, const float* scale, const float* shift, const float* res, float* y_bn,
+                                    float* y_sum, float* y, int64_t n, int channels, int64_t inner, int relu,
+                                    void* stream_) {
+    return bn_act_launch(x, scale, shift, res, y_bn, y_sum, y, n, channels, inner, relu, stream_);
 }
 
 extern "C" int pleas_masked_adam(float* p, const float* g, const float* mask, float* m, float* v, int64_t n, float lr,

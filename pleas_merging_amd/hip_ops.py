@@ -234,6 +234,33 @@ def bn_act(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, res: Optio
     return y
 
 
+def bn_act_tracked(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, res: Optional[torch.Tensor], relu: bool):
+    """One pass, every node of the chain kept: returns ``(bn, sum, act)`` = ``(x * scale + shift, bn + res, relu(sum))``;
+    ``sum`` is None without a residual and ``act`` is None without ``relu`` (``pleas_bn_act_tracked``)."""
+    _need_gpu(x, scale, shift)
+    x = x.contiguous()
+    if res is not None:
+        if res.shape != x.shape or res.dtype != torch.float32:
+            raise PleasHipError("bn_act_tracked: residual shape/dtype differs from x")
+        res = res.contiguous()
+    C = x.shape[1]
+    if scale.numel() != C or shift.numel() != C:
+        raise PleasHipError("bn_act_tracked: scale/shift must hold one entry per channel")
+    # the last value of the chain goes to `y`; earlier ones to the optional outputs
+    y_bn = torch.empty_like(x) if (res is not None or relu) else None
+    y_sum = torch.empty_like(x) if (res is not None and relu) else None
+    y = torch.empty_like(x)
+    rc = _lib.lib().pleas_bn_act_tracked(x.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                         res.data_ptr() if res is not None else None,
+                                         y_bn.data_ptr() if y_bn is not None else None,
+                                         y_sum.data_ptr() if y_sum is not None else None, y.data_ptr(), x.shape[0], C,
+                                         math.prod(x.shape[2:]), int(relu), _stream())
+    check(rc, "pleas_bn_act_tracked")
+    if res is None:
+        return (y_bn, None, y) if relu else (y, None, None)
+    return (y_bn, y_sum, y) if relu else (y_bn, y, None)
+
+
 # ---------------------------------------------------------------------------------------- merge blocks
 def merge_blocks(w1: torch.Tensor, w2: torch.Tensor, row_axis: int, row1: torch.Tensor, row2: torch.Tensor,
                  n_merged_rows: int, col1: Optional[torch.Tensor] = None, col2: Optional[torch.Tensor] = None,

@@ -56,6 +56,17 @@ def _foldable(bn: nn.Module) -> bool:
             and bn.running_var is not None and bn.running_mean.dtype == torch.float32)
 
 
+def fold_bn(bn: nn.BatchNorm2d):
+    """``(scale, shift)`` fp32 tensors with ``bn(x) == x * scale + shift`` in eval mode (computed in fp64)."""
+    with torch.no_grad():
+        var = bn.running_var.double()
+        w = bn.weight.double() if bn.weight is not None else torch.ones_like(var)
+        b = bn.bias.double() if bn.bias is not None else torch.zeros_like(var)
+        scale64 = w / torch.sqrt(var + bn.eps)
+        shift64 = b - bn.running_mean.double() * scale64
+    return scale64.float().contiguous(), shift64.float().contiguous()
+
+
 def fuse_bn_act(model: nn.Module, op: Callable = _bn_act) -> Optional[torch.fx.GraphModule]:
     """fx copy of ``model`` (sharing its submodules) with every eval-mode BatchNorm2d chain replaced by
     ``op(x, scale, shift, residual_or_None, relu)`` -- the HIP kernel ``hip_ops.bn_act`` unless a test
@@ -74,15 +85,10 @@ def fuse_bn_act(model: nn.Module, op: Callable = _bn_act) -> Optional[torch.fx.G
         if len(node.args) != 1 or node.kwargs:
             continue
         bn = mods[node.target]
-        with torch.no_grad():
-            var = bn.running_var.double()
-            w = bn.weight.double() if bn.weight is not None else torch.ones_like(var)
-            b = bn.bias.double() if bn.bias is not None else torch.zeros_like(var)
-            scale64 = w / torch.sqrt(var + bn.eps)
-            shift64 = b - bn.running_mean.double() * scale64
+        scale, shift = fold_bn(bn)
         tag = node.name
-        gm.register_buffer("_pleas_scale_%s" % tag, scale64.float().contiguous(), persistent=False)
-        gm.register_buffer("_pleas_shift_%s" % tag, shift64.float().contiguous(), persistent=False)
+        gm.register_buffer("_pleas_scale_%s" % tag, scale, persistent=False)
+        gm.register_buffer("_pleas_shift_%s" % tag, shift, persistent=False)
 
         chain, res, relu = [node], None, False
         users = list(node.users)

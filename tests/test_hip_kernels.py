@@ -208,6 +208,27 @@ def test_bn_act_matches_eval_batchnorm(ops, shape, with_res, relu):
         assert (got >= 0).all()
 
 
+@pytest.mark.parametrize("shape", [(3, 16, 8, 8), (2, 7, 7, 7)])
+@pytest.mark.parametrize("with_res,relu", [(False, True), (True, True), (True, False), (False, False)])
+def test_bn_act_tracked_keeps_every_node_of_the_chain(ops, shape, with_res, relu):
+    g = torch.Generator().manual_seed(32)
+    C = shape[1]
+    scale, shift = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+    x, res = torch.randn(shape, generator=g).cuda(), torch.randn(shape, generator=g).cuda()
+    bn, sm, act = ops.bn_act_tracked(x, scale, shift, res if with_res else None, relu)
+    want_bn = x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    assert torch.allclose(bn, want_bn, rtol=1e-6, atol=1e-6)
+    assert (sm is None) == (not with_res) and (act is None) == (not relu)
+    last = bn
+    if with_res:
+        assert torch.equal(sm, bn + res)
+        last = sm
+    if relu:
+        assert torch.equal(act, torch.relu(last))
+    # the single-output form is the same pass without the extra stores
+    assert torch.equal(ops.bn_act(x, scale, shift, res if with_res else None, relu), act if relu else last)
+
+
 def test_bn_act_rejects_bad_operands(ops):
     x = torch.randn(2, 4, 3, 3).cuda()
     s = torch.ones(4).cuda()

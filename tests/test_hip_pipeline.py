@@ -220,10 +220,34 @@ def test_two_stream_twin_forward_equals_interleaved(tiny_bottleneck):
     data = t.batches() + t.batches()
     main = torch.cuda.current_stream()
     a = accumulate_costs_fused(t.spec, m1, m2, data, 8, hip_ops.EPI_NEG_CDIST, overlap=False)
-    b = accumulate_costs_fused(t.spec, m1, m2, data, 8, hip_ops.EPI_NEG_CDIST, overlap=True)
+    b = accumulate_costs_fused(t.spec, m1, m2, data, 8, hip_ops.EPI_NEG_CDIST, overlap=True, fuse_bn=False)
     assert torch.cuda.current_stream() == main
     for k in t.spec:
         assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("fx", ["tiny_basic", "tiny_bottleneck"])
+def test_matching_with_fused_bn_chains_equals_module_chains(fx, request):
+    """Twin forward with every eval-mode BatchNorm -> [+identity] -> [ReLU] chain as ONE launch that keeps all nodes
+    (default) vs the vendor BN / add / ReLU modules: same costs up to the fp32 rounding of the fold, same matching."""
+    from pleas_merging_amd import hip_ops
+    from pleas_merging_amd.methods.activation_matching import accumulate_costs_fused, solve_all
+    from pleas_merging_amd.core.solvers import hip_solve_lsa
+
+    t = request.getfixturevalue(fx)
+    m1, m2 = _cuda_pair(t)
+    data = t.batches()
+    a = accumulate_costs_fused(t.spec, m1, m2, data, 4, hip_ops.EPI_NEG_CDIST, fuse_bn=False)
+    b = accumulate_costs_fused(t.spec, m1, m2, data, 4, hip_ops.EPI_NEG_CDIST, fuse_bn=True)
+    for k in t.spec:
+        assert _rel(a[k], b[k]) < 1e-5, k
+    pa, pb = solve_all(a, hip_solve_lsa), solve_all(b, hip_solve_lsa)
+    for k in t.spec:
+        assert (pa[k] == pb[k]).all(), k
+    m1.train()   # training-mode BatchNorm is never folded: the module path must still work
+    c = accumulate_costs_fused(t.spec, m1.eval(), m2, data, 4, hip_ops.EPI_NEG_CDIST, fuse_bn=True)
+    for k in t.spec:
+        assert torch.equal(b[k], c[k]), k
 
 
 def _layer_objective(t, m3, ratio, perm, costs, batches):
