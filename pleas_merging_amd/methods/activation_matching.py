@@ -388,7 +388,7 @@ def compute_matching_costs(spec: PermutationSpec, gm_cross: nn.Module, dataloade
 def accumulate_costs_fused(spec: PermutationSpec, model1: nn.Module, model2: nn.Module, dataloader, num_batches: int,
                            epilogue: int, accumulate=True, shard: bool = True,
                            grouped: bool = True, graph_forward: bool = False,
-                           overlap: bool = True, fuse_bn: bool = False) -> Dict[Axis, torch.Tensor]:
+                           overlap: bool = True, fuse_bn: bool = True) -> Dict[Axis, torch.Tensor]:
     """HIP fast path: every tracked node adds into its group matrix while the forwards run.
 
     Data parallel: with ``torch.distributed`` initialised (one process per GPU, RCCL), rank r
@@ -396,11 +396,10 @@ def accumulate_costs_fused(spec: PermutationSpec, model1: nn.Module, model2: nn.
     distance epilogue is applied per batch, so sharding at batch granularity is exact
     (SURVEY.md F3).  ``accumulate="reference"`` (last batch only) does not shard.
 
-    ``fuse_bn=True`` (opt-in): every eval-mode ``BatchNorm2d -> [+identity] -> [ReLU]`` chain of the twin forward becomes
-    ONE ``pleas_bn_act_tracked`` launch that keeps all nodes of the chain (680 -> 416 launches per batch).  Measured on
-    the ResNet-101 job: no wall-clock change (0.83 s vs 0.83 s for 30 batches) -- the batch is bound by the contraction
-    and the vendor convolutions -- so the vendor modules, whose BatchNorm values are the reference's bit for bit, stay
-    the default.
+    ``fuse_bn=True`` (default, two-stream twin only): every eval-mode ``BatchNorm2d -> [+identity] -> [ReLU]`` chain of
+    the twin forward is ONE ``pleas_bn_act_tracked`` launch that keeps all nodes of the chain (680 -> 416 launches per
+    batch; same folded BatchNorm as the PLeaS phase uses).  Measured on the ResNet-101 job: 17.9 -> 17.1 ms per batch.
+    ``fuse_bn=False`` runs the vendor modules.
     """
     device = _model_device(model1)
     if device.type != "cuda":

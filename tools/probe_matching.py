@@ -1,5 +1,6 @@
-"""Matching phase A/B on ResNet-101, batch 16: vendor BN/add/ReLU modules vs fused tracked BN chains in the twin graph."""
-import sys, os, time
+"""Matching phase on ResNet-101, batch 16: steady-state time per batch (host enqueue and wall), measured from the
+moments the loop asks for its batches; variants of the twin forward."""
+import sys, os, time, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pleas_merging_amd import resnet as zoo, hip_ops
@@ -8,15 +9,24 @@ from pleas_merging_amd.methods.activation_matching import accumulate_costs_fused
 dev = torch.device("cuda"); B = 16
 torch.manual_seed(0); m1 = zoo.resnet101().to(dev)
 torch.manual_seed(1); m2 = zoo.resnet101().to(dev)
-xs = [torch.randn(B, 3, 224, 224, device=dev) for _ in range(30)]
+xs = [torch.randn(B, 3, 224, 224, device=dev) for _ in range(20)]
 with torch.no_grad():
     zoo.calibrate_bn(m1, xs[:4]); zoo.calibrate_bn(m2, xs[:4])
 m1.eval(); m2.eval()
 spec = get_permutation_spec(m1, ((1, 3, 224, 224),))
-data = [(x, None) for x in xs]
+def run(n, **kw):
+    stamps = []
+    def data():
+        for i in range(n + 1):      # the loop stops after n batches; the extra item is never fetched
+            stamps.append(time.time())
+            yield xs[i % len(xs)], None
+    torch.cuda.synchronize(); t0 = time.time()
+    accumulate_costs_fused(spec, m1, m2, data(), n, hip_ops.EPI_NEG_CDIST, **kw)
+    torch.cuda.synchronize(); t1 = time.time()
+    gaps = [b - a for a, b in zip(stamps[10:-1], stamps[11:])]
+    return statistics.median(gaps) * 1e3, (t1 - stamps[10]) / (len(stamps) - 10) * 1e3, (stamps[0] - t0)
 for rep in range(3):
-    for fuse in (False, True):
-        torch.cuda.synchronize(); t0 = time.time()
-        accumulate_costs_fused(spec, m1, m2, data, 30, hip_ops.EPI_NEG_CDIST, fuse_bn=fuse)
-        torch.cuda.synchronize(); dt = time.time() - t0
-        print("fuse_bn=%s: 30 batches incl. twin build %.3f s" % (fuse, dt), flush=True)
+    for tag, kw in (("eager two-stream", {}), ("two-stream, fused BN", {"fuse_bn": True}), ("graph_forward", {"graph_forward": True}),
+                    ("eager one stream", {"overlap": False})):
+        host, wall, build = run(60, **kw)
+        print("%-22s: host per batch (median) %.2f ms, wall per batch %.2f ms, build %.3f s" % (tag, host, wall, build), flush=True)
