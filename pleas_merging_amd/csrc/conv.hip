@@ -229,7 +229,7 @@ __device__ __forceinline__ void wgrad_dispatch(const WgradLayerDev& L, const Wgr
     else wgrad_tile<TM, TN, 1, true>(L, it, smem);
 }
 
-__global__ __launch_bounds__(cThreads) void wgrad_batch_kernel(const WgradLayerDev* __restrict__ layers,
+__global__ __launch_bounds__(cThreads, 2) void wgrad_batch_kernel(const WgradLayerDev* __restrict__ layers,
                                                                const WgradItemDev* __restrict__ items) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const WgradItemDev it = items[blockIdx.x];

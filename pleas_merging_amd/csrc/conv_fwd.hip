@@ -381,7 +381,7 @@ __device__ __forceinline__ void fwd_tile(const FwdLayerDev& L, const FwdItemDev&
 #endif
 }
 
-__global__ __launch_bounds__(fThreads) void fwd_batch_kernel(const FwdLayerDev* __restrict__ layers,
+__global__ __launch_bounds__(fThreads, 2) void fwd_batch_kernel(const FwdLayerDev* __restrict__ layers,
                                                              const FwdItemDev* __restrict__ items,
                                                              float* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
