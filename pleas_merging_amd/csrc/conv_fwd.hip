@@ -161,20 +161,15 @@ __device__ __forceinline__ void fwd_tile(const FwdLayerDev& L, const FwdItemDev&
                 const int kh = r / L.KW, kw = r - kh * L.KW;
                 const bool ok_tap = (tapmask >> r) & 1ull;
                 const uint32_t ch0 = (uint32_t)cb * fBK + bhalf * 16;
-                // address = (wave-uniform base: input + channel offset, on the scalar unit) + (one 32-bit byte offset per
-                // thread and chunk): the loads take the SGPR-base + VGPR-offset form, no 64-bit vector arithmetic per
-                // load (the host guarantees numel(ip) < 2^30)
-                const uint32_t vbyte = ok_tap ? (uint32_t)((long long)pbase + pixoff + (kh * L.Win + kw)) * 4u : 0u;
+                const long long voff = ok_tap ? (long long)pbase + pixoff + (kh * L.Win + kw) : 0ll;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const uint32_t ch = ch0 + q;
                     const bool ok = ok_tap && ch < (uint32_t)L.Cin;
                     okb |= (ok ? 1u : 0u) << q;
-                    const unsigned long long lin = (unsigned long long)min(ch, (uint32_t)L.Cin - 1u) * HWi;   // masked lanes read ip[lin]
-                    const char __attribute__((address_space(1)))* sbase =
-                        reinterpret_cast<const char __attribute__((address_space(1)))*>(PLEAS_GLOBAL(L.ip)) + lin * 4ull;
-                    if constexpr ((PLEAS_FWD_ABLATE & 4) != 0) rb[q] = (float)((vbyte + lin) & 7); else
-                    rb[q] = *reinterpret_cast<const float __attribute__((address_space(1)))*>(sbase + vbyte);
+                    const long long lin = (long long)min(ch, (uint32_t)L.Cin - 1u) * HWi;   // scalar; masked lanes read ip[lin]
+                    if constexpr ((PLEAS_FWD_ABLATE & 4) != 0) rb[q] = (float)((voff + lin) & 7); else
+                    rb[q] = PLEAS_GLOBAL(L.ip)[voff + lin];
                 }
             } else {
                 // general kernel: the tap validity of this thread's pixel is a precomputed bit mask and its pixel
@@ -475,9 +470,7 @@ static int build_fwd_plan(FwdPlan& P, const pleas_fwd_layer* ly, int n) {
         if (Hout <= 0 || Wout <= 0) return bad_arg("conv_fwd: empty output");
         if (l.KH * l.KW > 64) return bad_arg("conv_fwd: kernels larger than 64 taps are not supported");
         const int64_t HWo = (int64_t)Hout * Wout, Ptot = (int64_t)l.N * HWo, Kd = (int64_t)l.Cin * l.KH * l.KW;
-        if (Ptot >= (1ll << 31) || (int64_t)l.Cout * Kd >= (1ll << 32) ||
-            (int64_t)l.N * l.Cin * l.Hin * l.Win >= (1ll << 30))   // 32-bit byte offsets into the input
-            return bad_arg("conv_fwd: tensor too large");
+        if (Ptot >= (1ll << 31) || (int64_t)l.Cout * Kd >= (1ll << 32)) return bad_arg("conv_fwd: tensor too large");
         FwdLayerDev& d = P.layers[i];
         d.Cout = l.Cout; d.Cin = l.Cin; d.Hin = l.Hin; d.Win = l.Win; d.Hout = Hout; d.Wout = Wout;
         d.KH = l.KH; d.KW = l.KW; d.stride = l.stride; d.pad = l.pad; d.Csrc = l.Csrc; d.n_merged = l.n_merged;
