@@ -78,6 +78,17 @@ typedef struct pleas_gram_node {
     int C;
     int64_t HW;
     int group;
+    /* Derived node (derived != 0): its operands are per-channel affine images of node `source`'s operands,
+     *   x' = scale_x[c] * x + shift_x[c],  y' = scale_y[c] * y + shift_y[c]   (DEVICE arrays of length C)
+     * -- an eval-mode BatchNorm of a tracked convolution output.  Its inner products and norms follow from the
+     * source's products, squared norms and row sums, so it is NOT contracted: x / y are ignored, `source` must be a
+     * contracted node of the same shape in this list.  Zero-initialised fields = an ordinary node. */
+    int derived;
+    int source;
+    const float* scale_x;
+    const float* shift_x;
+    const float* scale_y;
+    const float* shift_y;
 } pleas_gram_node;
 size_t pleas_gram_batch_ws_bytes(const pleas_gram_node* nodes, int n_nodes, const int* group_C, int n_groups);
 int pleas_gram_batch(const pleas_gram_node* nodes, int n_nodes, float* const* group_acc, const int* group_C,

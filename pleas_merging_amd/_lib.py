@@ -90,7 +90,9 @@ class WgradLayer(ctypes.Structure):
 
 class GramNode(ctypes.Structure):
     """struct pleas_gram_node"""
-    _fields_ = [("x", c_void_p), ("y", c_void_p), ("B", c_int), ("C", c_int), ("HW", c_int64), ("group", c_int)]
+    _fields_ = [("x", c_void_p), ("y", c_void_p), ("B", c_int), ("C", c_int), ("HW", c_int64), ("group", c_int),
+                ("derived", c_int), ("source", c_int), ("scale_x", c_void_p), ("shift_x", c_void_p),
+                ("scale_y", c_void_p), ("shift_y", c_void_p)]
 
 PROF_KERNELS = ["gram_partial", "gram_finalize", "lsap", "merge_blocks", "masked_adam", "sqerr", "conv_fwd",
                 "conv_wgrad", "normal_eq", "solve", "bn_act"]

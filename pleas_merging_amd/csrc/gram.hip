@@ -37,6 +37,8 @@ struct GramGeom {
     const float* y;
     float* gpart;  // [S][C][C]
     float* npart;  // [S][2][C]
+    float* spart;  // [S][2][C] row sums (only when `sums`): lets the reduce pass derive affine images of this node
+    int sums;
     int C;
     uint32_t HW;
     uint32_t Ktot;  // B * HW
@@ -71,9 +73,10 @@ __device__ __forceinline__ void gram_tile(const GramGeom& g, float* smem, const 
     const int scol = (tid % LANES_PER_ROW) * VEC;
 
     Stage<PASSES, VEC> ra, rb;
-    float sqa[PASSES], sqb[PASSES];
+    float sqa[PASSES], sqb[PASSES], sma[PASSES], smb[PASSES];
 #pragma unroll
-    for (int q = 0; q < PASSES; ++q) sqa[q] = sqb[q] = 0.f;
+    for (int q = 0; q < PASSES; ++q) sqa[q] = sqb[q] = sma[q] = smb[q] = 0.f;
+    const bool want_sums = g.sums != 0;   // block-uniform
     f32x16 acc[MT][MT];
 #pragma unroll
     for (int a = 0; a < MT; ++a)
@@ -146,6 +149,13 @@ __device__ __forceinline__ void gram_tile(const GramGeom& g, float* smem, const 
             for (int e = 0; e < VEC; ++e) {
                 sqa[q] = fmaf(ra.v[q][e], ra.v[q][e], sqa[q]);
                 sqb[q] = fmaf(rb.v[q][e], rb.v[q][e], sqb[q]);
+            }
+            if (want_sums) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    sma[q] += ra.v[q][e];
+                    smb[q] += rb.v[q][e];
+                }
             }
         }
     };
@@ -220,6 +230,22 @@ __device__ __forceinline__ void gram_tile(const GramGeom& g, float* smem, const 
             if (tm == 0 && j0 + row < g.C) PLEAS_GLOBAL_W(g.npart)[((size_t)split * 2 + 1) * g.C + j0 + row] = sb;
         }
     }
+    if (want_sums) {   // plain row sums of the same K range, same layout
+#pragma unroll
+        for (int q = 0; q < PASSES; ++q) {
+            float sa = sma[q], sb = smb[q];
+#pragma unroll
+            for (int off = 1; off < LANES_PER_ROW; off <<= 1) {
+                sa += __shfl_xor(sa, off);
+                sb += __shfl_xor(sb, off);
+            }
+            if ((tid % LANES_PER_ROW) == 0) {
+                const int row = srow + q * ROWS_PER_PASS;
+                if (tn == 0 && i0 + row < g.C) PLEAS_GLOBAL_W(g.spart)[((size_t)split * 2 + 0) * g.C + i0 + row] = sa;
+                if (tm == 0 && j0 + row < g.C) PLEAS_GLOBAL_W(g.spart)[((size_t)split * 2 + 1) * g.C + j0 + row] = sb;
+            }
+        }
+    }
 }
 
 // Single-node launch: grid = tiles x tiles x S.
@@ -241,19 +267,25 @@ struct GramNodeDev {      // device node table entry
     const float* y;
     float* gpart;         // [S][C][C] slabs of this node
     float* npart;         // [S][2][C]
+    float* spart;         // [S][2][C] row sums, sources of derived nodes only
+    const float* ax;      // derived node: value = ax[c] * source_x + bx[c] (per channel), likewise ay / by for y
+    const float* bx;
+    const float* ay;
+    const float* by;
     int C;
     uint32_t HW;
     uint32_t Ktot;
     int variant;          // 0: <128,4>  1: <128,1>  2: <64,4>  3: <64,1>
     int S;
     int group;
-    int pad[2];
+    int source;           // >= 0: derived from that node's slabs (no contraction of its own); -1: contracted
+    int sums;             // this node also writes row sums
 };
 struct GramItemDev {      // one workgroup of the grouped launch
     int node, tm, tn, split, c_begin, c_end, pad0, pad1;
 };
 
-__global__ __launch_bounds__(kThreads) void gram_batch_kernel(const GramNodeDev* __restrict__ nodes,
+__global__ __launch_bounds__(kThreads, 2) void gram_batch_kernel(const GramNodeDev* __restrict__ nodes,
                                                               const GramItemDev* __restrict__ items) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const GramItemDev it = items[blockIdx.x];
@@ -264,6 +296,8 @@ __global__ __launch_bounds__(kThreads) void gram_batch_kernel(const GramNodeDev*
     g.y = nd.y;
     g.gpart = nd.gpart;
     g.npart = nd.npart;
+    g.spart = nd.spart;
+    g.sums = nd.sums;
     g.C = nd.C;
     g.HW = nd.HW;
     g.Ktot = nd.Ktot;
@@ -317,6 +351,31 @@ __global__ __launch_bounds__(256) void gram_group_reduce_kernel(const GramNodeDe
     float out = accumulate ? gr.acc[idx] : 0.f;
     for (int t = gr.node_begin; t < gr.node_end; ++t) {
         const GramNodeDev nd = nodes[group_nodes[t]];
+        if (nd.source >= 0) {
+            // Derived node: x' = ax[i] x + bx[i], y' = ay[j] y + by[j] (an eval-mode BatchNorm of a contracted node).
+            // Its inner products and norms follow from the source's G, squared norms and row sums -- no contraction:
+            //   <x'_i, y'_j> = ax ay G + ax by Sx_i + bx ay Sy_j + K bx by,   |x'_i|^2 = ax^2 Nx_i + 2 ax bx Sx_i + K bx^2.
+            // Combined in fp64 (this pass is HBM-bound); the fp32 sums are the same ones a contraction would produce.
+            const GramNodeDev src = nodes[nd.source];
+            float gsum = 0.f, nx = 0.f, ny = 0.f, sx = 0.f, sy = 0.f;
+            for (int s = 0; s < src.S; ++s) {
+                gsum += src.gpart[(size_t)s * total + idx];
+                nx += src.npart[((size_t)s * 2 + 0) * gr.C + i];
+                ny += src.npart[((size_t)s * 2 + 1) * gr.C + j];
+                sx += src.spart[((size_t)s * 2 + 0) * gr.C + i];
+                sy += src.spart[((size_t)s * 2 + 1) * gr.C + j];
+            }
+            const double ax = nd.ax[i], bx = nd.bx[i], ay = nd.ay[j], by = nd.by[j], K = (double)src.Ktot;
+            const double inner = ax * ay * (double)gsum + ax * by * (double)sx + bx * ay * (double)sy + K * bx * by;
+            if (epilogue == PLEAS_EPI_NEG_CDIST) {
+                const double n1 = ax * ax * (double)nx + 2.0 * ax * bx * (double)sx + K * bx * bx;
+                const double n2 = ay * ay * (double)ny + 2.0 * ay * by * (double)sy + K * by * by;
+                out += -sqrtf(fmaxf((float)(n1 + n2 - 2.0 * inner), 0.f));
+            } else {
+                out += (float)inner;
+            }
+            continue;
+        }
         float gsum = 0.f, nx = 0.f, ny = 0.f;
         for (int s = 0; s < nd.S; ++s) {
             gsum += nd.gpart[(size_t)s * total + idx];
@@ -405,6 +464,8 @@ extern "C" int pleas_gram_accum(const float* x, const float* y, int B, int C, in
     g.y = y;
     g.gpart = (float*)ws;
     g.npart = g.gpart + (size_t)p.S * C * C;
+    g.spart = nullptr;
+    g.sums = 0;
     g.C = C;
     g.HW = (uint32_t)HW;
     g.Ktot = (uint32_t)((int64_t)B * HW);
@@ -470,11 +531,20 @@ static int build_batch_plan(BatchPlan& P, const pleas_gram_node* nd, int n, floa
     P.blk_group.clear();
     P.flops = P.bytes = P.slab_bytes = 0;
     P.lds = 0;
-    std::vector<size_t> slab_off(n);
+    std::vector<size_t> slab_off(n), spart_off(n);
     size_t slabs = 0;
     struct Work { double w; GramItemDev it; };
     std::vector<Work> work;
     std::vector<XcdWork<GramItemDev>> xwork;
+    std::vector<char> is_source(n, 0);
+    for (int i = 0; i < n; ++i) {
+        if (!nd[i].derived) continue;
+        const int src = nd[i].source;
+        if (src < 0 || src >= n || src == i || nd[src].derived) return bad_arg("gram_batch: derived node needs a contracted source node");
+        if (nd[src].C != nd[i].C || nd[src].B != nd[i].B || nd[src].HW != nd[i].HW) return bad_arg("gram_batch: derived node shape differs from its source");
+        if (!nd[i].scale_x || !nd[i].shift_x || !nd[i].scale_y || !nd[i].shift_y) return bad_arg("gram_batch: derived node without scale / shift");
+        is_source[src] = 1;
+    }
     for (int i = 0; i < n; ++i) {
         const int B = nd[i].B, C = nd[i].C;
         const int64_t HW = nd[i].HW;
@@ -491,10 +561,21 @@ static int build_batch_plan(BatchPlan& P, const pleas_gram_node* nd, int n, floa
         d.HW = (uint32_t)HW;
         d.Ktot = (uint32_t)((int64_t)B * HW);
         d.variant = (tile == 128 ? 0 : 2) + (vec == 4 ? 0 : 1);
-        d.S = S;
         d.group = nd[i].group;
+        d.source = nd[i].derived ? nd[i].source : -1;
+        d.sums = is_source[i];
+        d.ax = nd[i].scale_x; d.bx = nd[i].shift_x; d.ay = nd[i].scale_y; d.by = nd[i].shift_y;
+        if (nd[i].derived) {   // no contraction, no slabs: the reduce pass reads the source's
+            d.S = 0;
+            slab_off[i] = 0;
+            spart_off[i] = 0;
+            continue;
+        }
+        d.S = S;
         slab_off[i] = slabs;
         slabs += (size_t)S * ((size_t)C * C + 2 * (size_t)C);
+        spart_off[i] = slabs;
+        if (is_source[i]) slabs += (size_t)S * 2 * (size_t)C;
         P.lds = std::max(P.lds, (size_t)4 * tile * kLds * sizeof(float));
         const double kk = (double)B * (double)HW;
         P.flops += 2.0 * C * (double)C * kk;
@@ -576,6 +657,7 @@ static int build_batch_plan(BatchPlan& P, const pleas_gram_node* nd, int n, floa
     for (int i = 0; i < n; ++i) {
         P.nodes[i].gpart = reinterpret_cast<float*>(slab_off[i]);
         P.nodes[i].npart = reinterpret_cast<float*>(slab_off[i] + (size_t)P.nodes[i].S * P.nodes[i].C * P.nodes[i].C);
+        P.nodes[i].spart = reinterpret_cast<float*>(spart_off[i]);
     }
     P.uploaded = false;
     return PLEAS_OK;
@@ -594,6 +676,9 @@ static std::vector<int64_t> batch_key(const pleas_gram_node* nd, int n, float* c
         k.push_back(nd[i].C);
         k.push_back(nd[i].HW);
         k.push_back(nd[i].group);
+        k.push_back(nd[i].derived ? nd[i].source : -1);
+        if (nd[i].derived)
+            for (const float* ptr : {nd[i].scale_x, nd[i].shift_x, nd[i].scale_y, nd[i].shift_y}) k.push_back((int64_t)(uintptr_t)ptr);
     }
     for (int g = 0; g < n_groups; ++g) {
         k.push_back(group_C[g]);
@@ -623,6 +708,7 @@ extern "C" int pleas_gram_batch(const pleas_gram_node* nodes, int n_nodes, float
     if (!nodes || n_nodes <= 0 || !group_acc || !group_C || n_groups <= 0) return bad_arg("gram_batch: empty input");
     if (epilogue != PLEAS_EPI_INNER && epilogue != PLEAS_EPI_NEG_CDIST) return bad_arg("epilogue");
     for (int i = 0; i < n_nodes; ++i) {
+        if (nodes[i].derived) continue;
         if (!nodes[i].x || !nodes[i].y) return bad_arg("gram_batch: null operand");
         if (nodes[i].HW % 4 == 0 && ((((uintptr_t)nodes[i].x | (uintptr_t)nodes[i].y) & 15) != 0))
             return bad_arg("gram_batch: operands must be 16-byte aligned");
@@ -651,6 +737,7 @@ extern "C" int pleas_gram_batch(const pleas_gram_node* nodes, int n_nodes, float
         for (auto& d : abs_nodes) {
             d.gpart = slab0 + reinterpret_cast<size_t>(d.gpart);
             d.npart = slab0 + reinterpret_cast<size_t>(d.npart);
+            d.spart = slab0 + reinterpret_cast<size_t>(d.spart);
         }
         PLEAS_HIP_CHECK(hipMemcpyAsync(base + P.off_nodes, abs_nodes.data(), abs_nodes.size() * sizeof(GramNodeDev),
                                        hipMemcpyHostToDevice, stream));

@@ -140,12 +140,28 @@ class GramBatch:
         self._ws = None
         self.device = self.mats[0].device
 
-    def add(self, x: torch.Tensor, y: torch.Tensor, axis: int, group: int) -> None:
+    def add(self, x: torch.Tensor, y: torch.Tensor, axis: int, group: int) -> int:
+        """Queue one contracted node; returns its index in this batch (the handle ``add_derived`` refers to)."""
         if x.shape != y.shape or not x.is_cuda or x.dtype != torch.float32 or y.dtype != torch.float32:
             raise PleasHipError("GramBatch.add: fp32 CUDA operands of equal shape expected")
         x, y = x.contiguous(), y.contiguous()
         self._keep.append((x, y))
-        self._meta.append(_as_bchw(x, axis) + (group,))
+        self._meta.append(_as_bchw(x, axis) + (group, None))
+        return len(self._keep) - 1
+
+    def add_derived(self, source: int, scale_x: torch.Tensor, shift_x: torch.Tensor, scale_y: torch.Tensor,
+                    shift_y: torch.Tensor, group: int) -> int:
+        """Queue a node whose operands are per-channel affine images ``scale * v + shift`` of node ``source``'s operands
+        (an eval-mode BatchNorm of a tracked convolution): no contraction, the reduce pass derives its contribution."""
+        if not 0 <= source < len(self._keep) or self._meta[source][4] is not None:
+            raise PleasHipError("GramBatch.add_derived: source must be a contracted node of this batch")
+        B, C, HW = self._meta[source][:3]
+        for t in (scale_x, shift_x, scale_y, shift_y):
+            if not t.is_cuda or t.dtype != torch.float32 or t.numel() != C or not t.is_contiguous():
+                raise PleasHipError("GramBatch.add_derived: scale / shift must be contiguous fp32 CUDA vectors of length C")
+        self._keep.append((scale_x, shift_x, scale_y, shift_y))
+        self._meta.append((B, C, HW, group, source))
+        return len(self._keep) - 1
 
     def flush(self, accumulate: bool = True, keep: bool = False) -> None:
         """Contract everything added since the last flush.  ``keep=True`` leaves the node list in place: used when
@@ -156,9 +172,16 @@ class GramBatch:
         if self._arr is None or len(self._arr) != n:
             self._arr = (_lib.GramNode * n)()
         arr = self._arr
-        for i, ((x, y), (B, C, HW, g)) in enumerate(zip(self._keep, self._meta)):
+        for i, (t, (B, C, HW, g, src)) in enumerate(zip(self._keep, self._meta)):
             a = arr[i]
-            a.x, a.y, a.B, a.C, a.HW, a.group = x.data_ptr(), y.data_ptr(), B, C, HW, g
+            a.B, a.C, a.HW, a.group = B, C, HW, g
+            if src is None:
+                a.x, a.y, a.derived, a.source = t[0].data_ptr(), t[1].data_ptr(), 0, 0
+                a.scale_x = a.shift_x = a.scale_y = a.shift_y = None
+            else:
+                a.x = a.y = None
+                a.derived, a.source = 1, src
+                a.scale_x, a.shift_x, a.scale_y, a.shift_y = (v.data_ptr() for v in t)
         lib = _lib.lib()
         if self._ws is None:
             need = int(lib.pleas_gram_batch_ws_bytes(arr, n, self._gc, len(self.mats)))
@@ -234,9 +257,12 @@ def bn_act(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, res: Optio
     return y
 
 
-def bn_act_tracked(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, res: Optional[torch.Tensor], relu: bool):
+def bn_act_tracked(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, res: Optional[torch.Tensor], relu: bool,
+                   keep_bn: bool = True):
     """One pass, every node of the chain kept: returns ``(bn, sum, act)`` = ``(x * scale + shift, bn + res, relu(sum))``;
-    ``sum`` is None without a residual and ``act`` is None without ``relu`` (``pleas_bn_act_tracked``)."""
+    ``sum`` is None without a residual and ``act`` is None without ``relu`` (``pleas_bn_act_tracked``).
+    ``keep_bn=False``: the BatchNorm value itself is not needed by the caller (its matching cost is derived from the
+    convolution node, ``GramBatch.add_derived``) and is not written unless it is the chain's last value."""
     _need_gpu(x, scale, shift)
     x = x.contiguous()
     if res is not None:
@@ -247,7 +273,7 @@ def bn_act_tracked(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, re
     if scale.numel() != C or shift.numel() != C:
         raise PleasHipError("bn_act_tracked: scale/shift must hold one entry per channel")
     # the last value of the chain goes to `y`; earlier ones to the optional outputs
-    y_bn = torch.empty_like(x) if (res is not None or relu) else None
+    y_bn = torch.empty_like(x) if ((res is not None or relu) and keep_bn) else None
     y_sum = torch.empty_like(x) if (res is not None and relu) else None
     y = torch.empty_like(x)
     rc = _lib.lib().pleas_bn_act_tracked(x.data_ptr(), scale.data_ptr(), shift.data_ptr(),

@@ -94,7 +94,8 @@ class _SideStream:
 
 
 def _build_twin(model1: nn.Module, model2: nn.Module, axes: Iterable[Axis], emit: Callable,
-                keep_inputs: bool = False, side_stream: Optional[_SideStream] = None, fuse_bn: bool = False):
+                keep_inputs: bool = False, side_stream: Optional[_SideStream] = None, fuse_bn: bool = False,
+                emit_derived: Optional[Callable] = None):
     """Twin graph of ``model1``/``model2``; ``emit(graph, name, axis, node1, node2)`` adds the call
     made right after tracked node ``name`` and returns the fx node that holds its value.
     ``keep_inputs`` runs in-place activations out of place (same values, new tensor), so that tracked
@@ -104,7 +105,7 @@ def _build_twin(model1: nn.Module, model2: nn.Module, axes: Iterable[Axis], emit
     if side_stream is not None:
         if not keep_inputs:
             raise ValueError("a split twin graph defers its sinks: it needs keep_inputs=True")
-        return _build_split_twin(model1, model2, axes, emit, side_stream, fuse_bn)
+        return _build_split_twin(model1, model2, axes, emit, side_stream, fuse_bn, emit_derived)
     traced = torch.fx.symbolic_trace(model1)
     submods = dict(traced.named_modules())
     want: Dict[str, List[int]] = {}
@@ -177,7 +178,7 @@ def _bn_chains(traced: torch.fx.GraphModule, model1: nn.Module, model2: nn.Modul
 
 
 def _build_split_twin(model1: nn.Module, model2: nn.Module, axes: Iterable[Axis], emit: Callable, streams: _SideStream,
-                      fuse_bn: bool = False):
+                      fuse_bn: bool = False, emit_derived: Optional[Callable] = None):
     import operator
 
     from .. import hip_ops
@@ -187,6 +188,19 @@ def _build_split_twin(model1: nn.Module, model2: nn.Module, axes: Iterable[Axis]
     submods = dict(traced.named_modules())
     root = nn.ModuleList([model1, model2])
     chains, absorbed = _bn_chains(traced, model1, model2) if fuse_bn else ({}, set())
+    want_early: Dict[str, List[int]] = {}
+    for ax in axes:
+        want_early.setdefault(ax.key, []).append(ax.axis)
+    # BatchNorm nodes of fused chains that are tracked on the channel axis together with their input (the convolution
+    # output): their matching cost is derived from the input node's contraction instead of contracting again
+    derivable = set()
+    if emit_derived is not None:
+        for bn, _add, _relu, _res in chains.values():
+            src = bn.args[0]
+            if isinstance(src, torch.fx.Node) and src.op not in ("placeholder", "output") and src not in absorbed \
+                    and want_early.get(bn.name) == [1] and 1 in want_early.get(src.name, ()):
+                derivable.add(bn)
+    fold_attrs: Tuple[dict, dict] = ({}, {})
     want: Dict[str, List[int]] = {}
     for ax in axes:
         if ax.axis not in want.setdefault(ax.key, []):
@@ -218,9 +232,12 @@ def _build_split_twin(model1: nn.Module, model2: nn.Module, axes: Iterable[Axis]
                 names = ["_pleas_%s_%d_%s" % (kind, side, bn.name) for kind in ("scale", "shift")]
                 for nm_, buf in zip(names, fold_bn(mod)):
                     root.register_buffer(nm_, buf, persistent=False)
+                attrs = (twin.get_attr(names[0]), twin.get_attr(names[1]))
+                fold_attrs[side][bn] = attrs
                 fused = twin.call_function(hip_ops.bn_act_tracked,
-                                           (env[side][bn.args[0]], twin.get_attr(names[0]), twin.get_attr(names[1]),
-                                            env[side][res] if res is not None else None, relu is not None))
+                                           (env[side][bn.args[0]], attrs[0], attrs[1],
+                                            env[side][res] if res is not None else None, relu is not None,
+                                            bn not in derivable))
                 for slot, member in enumerate((bn, add, relu)):
                     if member is not None:
                         env[side][member] = twin.call_function(operator.getitem, (fused, slot))
@@ -241,7 +258,10 @@ def _build_split_twin(model1: nn.Module, model2: nn.Module, axes: Iterable[Axis]
     cross: Dict[Tuple[str, int], torch.fx.Node] = {}
     for node in traced.graph.nodes:
         for a in want.get(node.name, ()) if node.op not in ("placeholder", "output") else ():
-            cross[node.name, a] = emit(twin, node.name, a, env[0][node], env[1][node])
+            if node in derivable:
+                cross[node.name, a] = emit_derived(twin, node.name, node.args[0].name, a, fold_attrs[0][node], fold_attrs[1][node])
+            else:
+                cross[node.name, a] = emit(twin, node.name, a, env[0][node], env[1][node])
     twin.output(([env[0][ret], env[1][ret]], cross))
     gm = torch.fx.GraphModule(root, twin)
     gm.graph.lint()
@@ -289,12 +309,13 @@ class _FusedSink:
         self._accum = hip_ops.gram_accum
         self.arena, self.node_group, self.epilogue = arena, node_group, epilogue
         self.group_index = {key: i for i, key in enumerate(arena.keys)}
+        self.index: Dict[Tuple[str, int], int] = {}     # (node name, axis) -> position in the current GramBatch
         self.batch = hip_ops.GramBatch([arena.view[k] for k in arena.keys], epilogue) if grouped else None
 
     def bind(self, node_name: str):
         if self.batch is not None:
             def sink(x, y, a, _name=node_name):
-                self.batch.add(x, y, a, self.group_index[self.node_group[Axis(_name, a)]])
+                self.index[_name, a] = self.batch.add(x, y, a, self.group_index[self.node_group[Axis(_name, a)]])
                 return None
         else:
             def sink(x, y, a, _name=node_name):
@@ -304,9 +325,20 @@ class _FusedSink:
         sink.__name__ = sink.__qualname__ = "gram_sink_%s" % node_name
         return sink
 
+    def bind_derived(self, node_name: str, source_name: str):
+        """Sink of an eval-mode BatchNorm node whose input ``source_name`` is tracked on the same axis: nothing is
+        contracted, the group's reduce pass derives the node from the source's products, norms and row sums."""
+        def sink(scale1, shift1, scale2, shift2, a, _name=node_name, _src=source_name):
+            self.batch.add_derived(self.index[_src, a], scale1, shift1, scale2, shift2,
+                                   self.group_index[self.node_group[Axis(_name, a)]])
+            return None
+
+        sink.__name__ = sink.__qualname__ = "gram_derived_sink_%s" % node_name
+        return sink
+
 
 def build_fused_module(spec: PermutationSpec, model1: nn.Module, model2: nn.Module, arena: GroupArena, epilogue: int,
-                       grouped: bool = True, overlap: bool = False, fuse_bn: bool = False):
+                       grouped: bool = True, overlap: bool = False, fuse_bn: bool = False, derive_bn: bool = False):
     """Twin graph whose sinks feed the group arena (the HIP fast path).  Returns (module, sinks).
     ``overlap`` (grouped only): model2's forward runs on a second HIP stream next to model1's."""
     node_group = {nax: key for key, group in spec.items() for nax in group.node}
@@ -314,7 +346,10 @@ def build_fused_module(spec: PermutationSpec, model1: nn.Module, model2: nn.Modu
     sinks.streams = _SideStream(arena.flat.device) if (overlap and grouped) else None
     gm = _build_twin(model1, model2, list(node_group.keys()),
                      lambda g, name, a, n1, n2: g.call_function(sinks.bind(name), (n1, n2, a)), keep_inputs=grouped,
-                     side_stream=sinks.streams, fuse_bn=fuse_bn and sinks.streams is not None)
+                     side_stream=sinks.streams, fuse_bn=fuse_bn and sinks.streams is not None,
+                     emit_derived=(lambda g, name, src, a, f1, f2: g.call_function(sinks.bind_derived(name, src),
+                                                                                   (f1[0], f1[1], f2[0], f2[1], a)))
+                     if (derive_bn and fuse_bn and sinks.streams is not None) else None)
     return gm, sinks
 
 
@@ -388,7 +423,7 @@ def compute_matching_costs(spec: PermutationSpec, gm_cross: nn.Module, dataloade
 def accumulate_costs_fused(spec: PermutationSpec, model1: nn.Module, model2: nn.Module, dataloader, num_batches: int,
                            epilogue: int, accumulate=True, shard: bool = True,
                            grouped: bool = True, graph_forward: bool = False,
-                           overlap: bool = True, fuse_bn: bool = True) -> Dict[Axis, torch.Tensor]:
+                           overlap: bool = True, fuse_bn: bool = True, derive_bn: bool = True) -> Dict[Axis, torch.Tensor]:
     """HIP fast path: every tracked node adds into its group matrix while the forwards run.
 
     Data parallel: with ``torch.distributed`` initialised (one process per GPU, RCCL), rank r
@@ -400,13 +435,20 @@ def accumulate_costs_fused(spec: PermutationSpec, model1: nn.Module, model2: nn.
     the twin forward is ONE ``pleas_bn_act_tracked`` launch that keeps all nodes of the chain (680 -> 416 launches per
     batch; same folded BatchNorm as the PLeaS phase uses).  Measured on the ResNet-101 job: 17.9 -> 17.1 ms per batch.
     ``fuse_bn=False`` runs the vendor modules.
+
+    ``derive_bn=True`` (default, needs ``fuse_bn``): a tracked eval-mode BatchNorm whose input (the convolution output) is
+    tracked on the same channel axis is NOT contracted.  With ``bn(x)_i = a_i x_i + b_i`` its products and distances
+    follow from the convolution node's ``G = sum x_i y_j``, squared norms and row sums
+    (``<bn x_i, bn' y_j> = a a' G + a b' Sx_i + b a' Sy_j + K b b'``), which the group's reduce pass evaluates in fp64:
+    104 of ResNet-101's 344 tracked nodes, i.e. ~30 % of the contraction's flops, and the BatchNorm tensors are not
+    written at all.
     """
     device = _model_device(model1)
     if device.type != "cuda":
         raise RuntimeError("activation_matching: models must be on the GPU for the HIP path (got %s)" % device)
     arena = GroupArena(spec, device)
     gm, sinks = build_fused_module(spec, model1, model2, arena, epilogue, grouped,
-                                   overlap=overlap and grouped and not graph_forward, fuse_bn=fuse_bn)
+                                   overlap=overlap and grouped and not graph_forward, fuse_bn=fuse_bn, derive_bn=derive_bn)
     rank, world = _dist_info() if (shard and accumulate is True) else (0, 1)
     # graph_forward=True (opt-in): after two eager batches (vendor warm-up) the whole twin forward (~1400 launches)
     # is captured into ONE hipGraph and replayed per batch on a static input; the sinks' tensors are then fixed

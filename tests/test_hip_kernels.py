@@ -335,6 +335,35 @@ def test_gram_batch_matches_per_node_sums(ops):
             assert _rel(got, ref) < 1e-5, _rel(got, ref)  # different K splits: only rounding may differ
 
 
+@pytest.mark.parametrize("epi", ["cdist", "inner"])
+def test_gram_batch_derived_affine_nodes_match_contracted_ones(ops, epi):
+    """A node declared as a per-channel affine image of another node (eval-mode BatchNorm of a convolution output) is
+    derived from the source's products, norms and row sums; it must agree with contracting the transformed tensors."""
+    g = torch.Generator().manual_seed(77)
+    epilogue = ops.EPI_NEG_CDIST if epi == "cdist" else ops.EPI_INNER
+    shapes = [(4, 96, 7, 7), (3, 40, 6, 6), (2, 130, 1, 1)]      # scalar / vector pieces, ragged tiles, linear nodes
+    mats_a = [torch.zeros(s[1], s[1], device="cuda") for s in shapes]
+    mats_b = [torch.zeros(s[1], s[1], device="cuda") for s in shapes]
+    direct, derived = ops.GramBatch(mats_a, epilogue), ops.GramBatch(mats_b, epilogue)
+    for gi, shape in enumerate(shapes):
+        C = shape[1]
+        x = (torch.randn(shape, generator=g) * 1.5 + 0.7).cuda()      # non-zero mean: the shift terms matter
+        y = (torch.randn(shape, generator=g) * 0.8 - 0.4).cuda()
+        sx, tx = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+        sy, ty = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+        view = (1, C) + (1,) * (len(shape) - 2)
+        direct.add(x, y, 1, gi)
+        direct.add(x * sx.view(view) + tx.view(view), y * sy.view(view) + ty.view(view), 1, gi)
+        src = derived.add(x, y, 1, gi)
+        derived.add_derived(src, sx, tx, sy, ty, gi)
+    direct.flush(accumulate=False)
+    derived.flush(accumulate=False)
+    for a, b in zip(mats_a, mats_b):
+        assert _rel(b, a) < 2e-5
+    with pytest.raises(ops.PleasHipError):
+        derived.add_derived(0, sx, tx, sy, ty, 0)      # nothing queued yet after the flush
+
+
 def test_gram_batch_deterministic_and_overwrite(ops):
     x, y = torch.randn(8, 256, 14, 14).cuda(), torch.randn(8, 256, 14, 14).cuda()
     outs = []

@@ -238,16 +238,24 @@ def test_matching_with_fused_bn_chains_equals_module_chains(fx, request):
     m1, m2 = _cuda_pair(t)
     data = t.batches()
     a = accumulate_costs_fused(t.spec, m1, m2, data, 4, hip_ops.EPI_NEG_CDIST, fuse_bn=False)
-    b = accumulate_costs_fused(t.spec, m1, m2, data, 4, hip_ops.EPI_NEG_CDIST, fuse_bn=True)
+    b = accumulate_costs_fused(t.spec, m1, m2, data, 4, hip_ops.EPI_NEG_CDIST, fuse_bn=True, derive_bn=False)
+    d = accumulate_costs_fused(t.spec, m1, m2, data, 4, hip_ops.EPI_NEG_CDIST, fuse_bn=True, derive_bn=True)
     for k in t.spec:
         assert _rel(a[k], b[k]) < 1e-5, k
-    pa, pb = solve_all(a, hip_solve_lsa), solve_all(b, hip_solve_lsa)
+        # BatchNorm nodes derived from the convolution node's products, norms and row sums instead of contracted
+        assert _rel(d[k], b[k]) < 2e-5, k
+    pa, pb, pd = solve_all(a, hip_solve_lsa), solve_all(b, hip_solve_lsa), solve_all(d, hip_solve_lsa)
     for k in t.spec:
-        assert (pa[k] == pb[k]).all(), k
+        assert (pa[k] == pb[k]).all() and (pa[k] == pd[k]).all(), k
+    for epi in (hip_ops.EPI_INNER,):
+        u = accumulate_costs_fused(t.spec, m1, m2, data, 4, epi, fuse_bn=True, derive_bn=False)
+        v = accumulate_costs_fused(t.spec, m1, m2, data, 4, epi, fuse_bn=True, derive_bn=True)
+        for k in t.spec:
+            assert _rel(v[k], u[k]) < 2e-5, k
     m1.train()   # training-mode BatchNorm is never folded: the module path must still work
     c = accumulate_costs_fused(t.spec, m1.eval(), m2, data, 4, hip_ops.EPI_NEG_CDIST, fuse_bn=True)
     for k in t.spec:
-        assert torch.equal(b[k], c[k]), k
+        assert torch.equal(d[k], c[k]), k
 
 
 def _layer_objective(t, m3, ratio, perm, costs, batches):

@@ -26,7 +26,6 @@ def run(n, **kw):
     gaps = [b - a for a, b in zip(stamps[10:-1], stamps[11:])]
     return statistics.median(gaps) * 1e3, (t1 - stamps[10]) / (len(stamps) - 10) * 1e3, (stamps[0] - t0)
 for rep in range(3):
-    for tag, kw in (("eager two-stream", {}), ("two-stream, fused BN", {"fuse_bn": True}), ("graph_forward", {"graph_forward": True}),
-                    ("eager one stream", {"overlap": False})):
+    for tag, kw in (("vendor BN modules", {"fuse_bn": False}), ("fused BN, contracted", {"derive_bn": False}), ("fused BN, derived", {})):
         host, wall, build = run(60, **kw)
         print("%-22s: host per batch (median) %.2f ms, wall per batch %.2f ms, build %.3f s" % (tag, host, wall, build), flush=True)
