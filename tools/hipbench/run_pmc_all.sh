@@ -9,6 +9,7 @@ done
 /tmp/fwd_batch_rn101 $REPO/tools/hipbench/rn101_layers.txt 5
 /tmp/wgrad_batch_rn101 $REPO/tools/hipbench/rn101_layers.txt 5
 /tmp/gram_batch_rn101 $REPO/tools/hipbench/rn101_nodes.txt 5
+/tmp/gram_batch_rn101 $REPO/tools/hipbench/rn101_nodes_derived.txt 5
 cd /tmp && export TMPDIR=/tmp
 run() {  # harness, input file, tag, kernel filters...
   local h=$1 inp=$2 tag=$3; shift 3
@@ -22,3 +23,4 @@ run() {  # harness, input file, tag, kernel filters...
 run fwd_batch_rn101 $REPO/tools/hipbench/rn101_layers.txt fwd fwd_batch
 run wgrad_batch_rn101 $REPO/tools/hipbench/rn101_layers.txt wgrad wgrad_batch wgrad_reduce
 run gram_batch_rn101 $REPO/tools/hipbench/rn101_nodes.txt gram gram_batch gram_group_reduce
+run gram_batch_rn101 $REPO/tools/hipbench/rn101_nodes_derived.txt gramderived gram_batch gram_group_reduce
