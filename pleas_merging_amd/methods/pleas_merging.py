@@ -11,20 +11,20 @@ of the two source layers.  ``solver="adam"`` reproduces the reference's optimise
 minimises the same objective in closed form (normal equations + Cholesky), which is what
 the Adam loop approximates.
 
-MI355X design of one Adam step
-  * both source forwards run once under PyTorch-ROCm with hooks that keep each layer's input
-    AND output (the reference re-runs every source layer a second time, :113-114);
-  * ``ip``/``op`` are assembled by one ``pleas_merge_blocks`` launch each (reference: 8
+MI355X design of one Adam step (13 ms for a ResNet-101 pair at batch 16)
+  * the two frozen source forwards run once each, on two HIP streams side by side, under hooks that keep every
+    layer's input AND output (the reference re-runs every source layer a second time, :113-114); between the hooked
+    layers BatchNorm + residual add + ReLU are one ``pleas_bn_act`` pass (``source_forward.py``);
+  * the merged inputs ``ip`` of ALL layers are assembled by ONE grouped launch (``pleas_merge_batch``; reference: 8
     ``index_select`` + 2 ``cat`` per layer);
-  * the regression target is never materialised: ``pleas_target_residual`` gathers/averages the
-    source outputs on the fly, turns the merged layer's output into the scaled residual
-    ``2 (out - op) / numel`` in place and emits the loss partials (one launch per layer);
-  * the weight gradients of ALL merged layers are ONE grouped fp32-MFMA launch
-    (``pleas_wgrad_batch``) that reads residuals and inputs in place from NCHW (autograd in the
-    reference also back-propagates into both source layers, and the vendor path needs NHWC
-    transposes);
-  * all parameters, gradients, masks and Adam moments live in flat fp32 arenas, so the masked
-    Adam update of the whole model is ONE ``pleas_masked_adam`` launch.
+  * forward, regression target, residual and loss of ALL merged layers are ONE grouped fp32-MFMA launch
+    (``pleas_fwd_batch``): the target ``op`` is gathered / averaged from the source outputs inside its epilogue and
+    never materialised, only the scaled residual ``2 (out - op) / numel`` and the loss partials are written;
+  * the weight gradients of ALL merged layers are ONE grouped fp32-MFMA launch (``pleas_wgrad_batch``) that reads
+    residuals and inputs in place from NCHW (autograd in the reference also back-propagates into both source layers);
+  * all parameters, gradients, masks and Adam moments live in flat fp32 arenas (k x k weights kernel-position-major),
+    so the masked Adam update of the whole model is ONE ``pleas_masked_adam`` launch and the data-parallel gradient
+    exchange is one all-reduce.
 """
 from __future__ import annotations
 
