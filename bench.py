@@ -321,6 +321,15 @@ def main():
                     "algorithmic_flop_per_launch": round(rec[2] / max(rec[0], 1)), "total_ms": round(rec[1], 2)}
 
         roofs = {k: roof(k) for k in labels}
+        # `achieved` counts the flops the contraction kernel EXECUTES.  The path's algorithmic work per matching batch
+        # (6.368e10 flop per sample for ResNet-101, every tracked node contracted) is larger: the 104
+        # tracked BatchNorm nodes are derived from their convolution node in the reduce pass, not contracted.
+        if args.arch == "resnet101" and roofs["gram_partial"]["launches"]:
+            per_launch = 6.368e10 * args.batch / world if world > 1 else 6.368e10 * args.batch
+            us = roofs["gram_partial"]["avg_launch_us"]
+            roofs["gram_partial"]["path_equivalent"] = {
+                "flop_per_launch": per_launch, "tflops": round(per_launch / (us * 1e-6) / 1e12, 2) if us else 0.0,
+                "note": "all 344 tracked nodes as the reference contracts them; 240 are contracted here, 104 derived"}
         # HBM-side bytes per launch from rocprofv3 PMC passes on standalone replays of the same grids (profiles/)
         for key, fname in (("gram_partial", "gram_traffic.json"), ("conv_fwd", "fwd_traffic.json"),
                            ("conv_wgrad", "wgrad_traffic.json")):
