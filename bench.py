@@ -325,7 +325,7 @@ def main():
         # (6.368e10 flop per sample for ResNet-101, every tracked node contracted) is larger: the 104
         # tracked BatchNorm nodes are derived from their convolution node in the reduce pass, not contracted.
         if args.arch == "resnet101" and roofs["gram_partial"]["launches"]:
-            per_launch = 6.368e10 * args.batch / world if world > 1 else 6.368e10 * args.batch
+            per_launch = 6.368e10 * args.batch      # whole batches per rank: matching shards batch indices, not samples
             us = roofs["gram_partial"]["avg_launch_us"]
             roofs["gram_partial"]["path_equivalent"] = {
                 "flop_per_launch": per_launch, "tflops": round(per_launch / (us * 1e-6) / 1e12, 2) if us else 0.0,
