@@ -283,6 +283,33 @@ def test_merge_batch_equals_single_tensor_launches(ops):
     assert torch.equal(out, (x1 + x2) * 0.5)
 
 
+def test_degenerate_sizes_do_not_break_the_grouped_launches(ops):
+    """One channel, one pixel, K shorter than a chunk, an all-separate merge, a 1x1 LAP: the smallest inputs every
+    grouped launch may see."""
+    g = torch.Generator().manual_seed(9)
+    # contraction: C = 1 and K = 3 (< one 32-deep chunk), next to an ordinary node
+    x1, y1 = torch.randn(3, 1, 1, 1, generator=g).cuda(), torch.randn(3, 1, 1, 1, generator=g).cuda()
+    x2, y2 = torch.randn(2, 5, 3, 3, generator=g).cuda(), torch.randn(2, 5, 3, 3, generator=g).cuda()
+    m1, m2 = torch.zeros(1, 1, device="cuda"), torch.zeros(5, 5, device="cuda")
+    batch = ops.GramBatch([m1, m2], ops.EPI_INNER)
+    batch.add(x1, y1, 1, 0)
+    batch.add(x2, y2, 1, 1)
+    batch.flush(accumulate=False)
+    assert torch.allclose(m1, (x1.flatten() * y1.flatten()).sum().view(1, 1), atol=1e-6)
+    want = torch.einsum("nchw,ndhw->cd", x2.double(), y2.double()).float()
+    assert torch.allclose(m2, want, atol=1e-5)
+    # merge: no merged rows at all (ratio 1), single-element rows
+    a, b = torch.randn(2, 3, 1, 1, generator=g).cuda(), torch.randn(2, 3, 1, 1, generator=g).cuda()
+    r1 = torch.tensor([0, 1, 2, -1, -1, -1], dtype=torch.int32, device="cuda")
+    r2 = torch.tensor([-1, -1, -1, 0, 1, 2], dtype=torch.int32, device="cuda")
+    mb = ops.MergeBatch(torch.device("cuda"))
+    out = mb.add(a, b, 1, r1, r2, 0)
+    mb.flush()
+    assert torch.equal(out, torch.cat([a, b], 1))
+    # LAP: n = 1
+    assert ops.solve_lsa_batched([torch.tensor([[3.0]]).cuda()])[0].tolist() == [0]
+
+
 def test_masked_adam_matches_torch(ops):
     g = torch.Generator().manual_seed(5)
     p0 = torch.randn(1000, generator=g)
