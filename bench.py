@@ -124,14 +124,19 @@ def run_job(spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, ratio, dp, 
     """The timed hot path.  Returns (merged model, perm, costs)."""
     from pleas_merging_amd.methods.activation_matching import activation_matching
     from pleas_merging_amd.methods.partial_matching import partial_merge
-    from pleas_merging_amd.methods.pleas_merging import PleasFitter
+    from pleas_merging_amd.methods.pleas_merging import PleasFitter, prepare_sources
 
-    perm, costs = activation_matching(spec, m1, m2, match_loader, len(match_loader), output_costs=True)
+    # the fused source forwards of the PLeaS phase do not depend on the permutation: the host builds them while the
+    # batched LAP kernel runs
+    early = {}
+    perm, costs = activation_matching(spec, m1, m2, match_loader, len(match_loader), output_costs=True,
+                                      while_solving=lambda: early.update(sources=prepare_sources(m1, m2)))
     m3 = partial_merge(spec, m1, m2, perm, costs, ratio, device=next(m1.parameters()).device)   # stays on the GPU
     # Data parallel: each rank's share of an update is small (batch / world samples), so the host-side dispatch of the two
     # source forwards (~10 ms) and the gradient all-reduce dominate: replay the sources from hipGraphs and enqueue the
     # next batch's sources before the current update, so that they run beside its all-reduce.
-    fit = PleasFitter(m1, m2, m3, spec, perm, costs, ratio, n_pleas_sched, data_parallel=dp, graph_sources=dp)
+    fit = PleasFitter(m1, m2, m3, spec, perm, costs, ratio, n_pleas_sched, data_parallel=dp, graph_sources=dp,
+                      fused_sources=early.get("sources"))
     lookahead = lookahead or dp
     for _ in fit.steps((x for x, _ in pleas_loader), lookahead=lookahead):
         pass

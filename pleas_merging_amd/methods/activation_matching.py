@@ -500,19 +500,25 @@ def accumulate_costs_fused(spec: PermutationSpec, model1: nn.Module, model2: nn.
     return dict(arena.view)
 
 
-def solve_all(costs: Dict[Axis, torch.Tensor], lsa_solver: Callable) -> Permutation:
-    """One LAP per group.  The default solver runs all groups in ONE batched kernel launch."""
+def solve_all(costs: Dict[Axis, torch.Tensor], lsa_solver: Callable, while_solving: Optional[Callable] = None) -> Permutation:
+    """One LAP per group.  The default solver runs all groups in ONE batched kernel launch; ``while_solving()`` (if given)
+    is called after that launch is enqueued and before its results are awaited -- the largest group keeps two CUs busy
+    for ~0.25 s, time the host can spend on work that does not need the permutation."""
     if lsa_solver is hip_solve_lsa:
         from .. import hip_ops
 
         outs = hip_ops.solve_lsa_batched(list(costs.values()), maximize=True)
+        if while_solving is not None:
+            while_solving()
         return {k: o.cpu() for k, o in zip(costs.keys(), outs)}
+    if while_solving is not None:
+        while_solving()
     return {k: lsa_solver(v) for k, v in costs.items()}
 
 
 def activation_matching(spec: PermutationSpec, model1: nn.Module, model2: nn.Module, dataloader, num_batches=1000,
                         cross_features=cross_features_cdist, lsa_solver=hip_solve_lsa, output_costs=False,
-                        accumulate=True, grouped=True):
+                        accumulate=True, grouped=True, while_solving: Optional[Callable] = None):
     """Permutation of ``model2``'s units that best matches ``model1``'s activations.
 
     Reference: :139-177 (same positional arguments; additions: ``accumulate`` -- ``"reference"``
@@ -529,5 +535,5 @@ def activation_matching(spec: PermutationSpec, model1: nn.Module, model2: nn.Mod
         axes = [ax for group in spec.values() for ax in group.node]
         gm = build_cross_module(model1, model2, axes, cross_features)
         costs = compute_matching_costs(spec, gm, dataloader, num_batches, accumulate, _model_device(model1))
-    perm = solve_all(costs, lsa_solver)
+    perm = solve_all(costs, lsa_solver, while_solving)
     return (perm, costs) if output_costs else perm

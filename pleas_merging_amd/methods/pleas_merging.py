@@ -77,6 +77,17 @@ def _square_conv(mod: nn.Conv2d) -> bool:
             and mod.padding[0] == mod.padding[1] and mod.kernel_size[0] == mod.kernel_size[1])
 
 
+def prepare_sources(model1: nn.Module, model2: nn.Module):
+    """The two frozen sources as the fitter runs them (eval mode, BatchNorm / add / ReLU chains folded into one HIP pass
+    each; a model that cannot be rewritten is returned as it is).  Needs neither the permutation nor the merged model,
+    so it can be built early and handed to ``PleasFitter(fused_sources=...)``."""
+    from .source_forward import fuse_bn_act
+
+    model1.eval()
+    model2.eval()
+    return fuse_bn_act(model1) or model1, fuse_bn_act(model2) or model2
+
+
 class ActivationTap:
     """Forward hooks on every Conv2d / Linear / LayerNorm of a model that keep the module's
     input and output of the latest forward (reference keeps inputs only, :197-231)."""
@@ -178,7 +189,7 @@ class PleasFitter:
     def __init__(self, model1, model2, model3, spec, perm, costs, budget_ratios, max_steps: int, lr: float = 5e-4,
                  separate_classifier=False, num_classes=1000, model_type="rn50", data_parallel: bool = False,
                  forward: str = "hip", graph_sources: bool = False, fuse_sources: bool = True,
-                 overlap_sources: bool = True):
+                 overlap_sources: bool = True, fused_sources=None):
         from .. import hip_ops
         from .activation_matching import _dist_info
 
@@ -198,11 +209,10 @@ class PleasFitter:
         # the frozen sources run with BatchNorm (+ residual add) + ReLU folded into one HIP pass; the hooked
         # Conv2d / Linear modules are shared, so the taps see the same tensors (source_forward.py)
         self.src1, self.src2 = model1, model2
-        if fuse_sources:
-            from .source_forward import fuse_bn_act
-
-            self.src1 = fuse_bn_act(model1) or model1
-            self.src2 = fuse_bn_act(model2) or model2
+        if fused_sources is not None:       # built ahead of time (prepare_sources), e.g. while the LAP kernel ran
+            self.src1, self.src2 = fused_sources
+        elif fuse_sources:
+            self.src1, self.src2 = prepare_sources(model1, model2)
 
         # the two source forwards are independent chains of small kernels (one conv of a batch-16 ResNet fills a
         # fraction of 256 CUs): the two models run on two side streams, joined before the taps are read
