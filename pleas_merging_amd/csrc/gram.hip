@@ -77,6 +77,7 @@ __device__ __forceinline__ void gram_tile(const GramGeom& g, float* smem, const 
 #pragma unroll
     for (int q = 0; q < PASSES; ++q) sqa[q] = sqb[q] = sma[q] = smb[q] = 0.f;
     const bool want_sums = g.sums != 0;   // block-uniform
+    const bool norm_a = tn == 0, norm_b = tm == 0;
     f32x16 acc[MT][MT];
 #pragma unroll
     for (int a = 0; a < MT; ++a)
@@ -145,16 +146,22 @@ __device__ __forceinline__ void gram_tile(const GramGeom& g, float* smem, const 
                 a[row * kLds + scol] = ra.v[q][0];
                 b[row * kLds + scol] = rb.v[q][0];
             }
+            // row norms / sums are stored by the first block column (x rows) and the first block row (y rows) only:
+            // the other tiles skip the arithmetic (block-uniform conditions)
+            if (norm_a) {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                sqa[q] = fmaf(ra.v[q][e], ra.v[q][e], sqa[q]);
-                sqb[q] = fmaf(rb.v[q][e], rb.v[q][e], sqb[q]);
+                for (int e = 0; e < VEC; ++e) sqa[q] = fmaf(ra.v[q][e], ra.v[q][e], sqa[q]);
+                if (want_sums) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) sma[q] += ra.v[q][e];
+                }
             }
-            if (want_sums) {
+            if (norm_b) {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    sma[q] += ra.v[q][e];
-                    smb[q] += rb.v[q][e];
+                for (int e = 0; e < VEC; ++e) sqb[q] = fmaf(rb.v[q][e], rb.v[q][e], sqb[q]);
+                if (want_sums) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) smb[q] += rb.v[q][e];
                 }
             }
         }
