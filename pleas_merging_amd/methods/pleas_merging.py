@@ -227,7 +227,7 @@ class PleasFitter:
         self._src_events = None
         self._slice_batch = True   # data parallel: every update splits its batch's samples over the ranks
         self._pending = None     # (batch as passed, its device copy, taps of model1, taps of model2, events): prefetched
-        self._after = None       # second half of a paired source forward: becomes `_pending` after the first update
+        self._after: list = []   # further generations of a grouped source forward: each becomes `_pending` in turn
         self._cur_x = None
         self.t1_in = self.t1_out = self.t2_in = self.t2_out = None   # taps of the update being applied
 
@@ -368,14 +368,14 @@ class PleasFitter:
         for resid, plan in self._bias_grads:
             plan.gb.copy_(resid.sum((0, 2, 3)) if plan.is_conv else resid.reshape(-1, resid.shape[-1]).sum(0))
 
-    def _launch_sources(self, x: torch.Tensor, slice_pair: bool = False):
+    def _launch_sources(self, x: torch.Tensor, parts: int = 1):
         """Enqueue both source forwards for ``x``; returns the generation (device batch, taps, events) the update will
-        consume.  ``slice_pair``: ``x`` is two batches back to back, each of which is sample-sliced on its own."""
+        consume.  ``parts`` > 1: ``x`` is that many batches back to back, each of which is sample-sliced on its own."""
         x = x.to(self.device, non_blocking=True)
         if self._slice_batch:
-            if slice_pair and self.world > 1:
-                h = x.shape[0] // 2
-                x = torch.cat([dp_slice(x[:h], self.rank, self.world), dp_slice(x[h:], self.rank, self.world)], 0)
+            if parts > 1 and self.world > 1:
+                h = x.shape[0] // parts
+                x = torch.cat([dp_slice(x[i * h:(i + 1) * h], self.rank, self.world) for i in range(parts)], 0)
             else:
                 x = dp_slice(x, self.rank, self.world)
         if self.graph_sources:
@@ -474,48 +474,64 @@ class PleasFitter:
         finally:
             caller.wait_stream(upd)
 
-    def steps(self, batches, lookahead: bool = False, pair_sources: bool = True):
+    def steps(self, batches, lookahead: bool = False, pair_sources: bool = True, sources_per_forward: int = 2):
         """Run one update per tensor of ``batches``; yields the index of each finished update.  The whole loop stays on
         the fitter's stream (also current for the consumer's code between two updates).
 
-        ``pair_sources=True`` (default): two consecutive batches of equal shape go through the frozen sources as ONE
-        forward of twice the batch, and the two updates read the halves (views) of its taps -- the sources are in eval
-        mode, so every sample's activations are what a separate forward gives (up to the vendor kernels' rounding at
-        another batch size), the update order is unchanged, and a batch-32 forward costs 6.2 ms per 16 samples instead
-        of 6.6 ms and half the host dispatch.
+        ``pair_sources=True`` (default): up to ``sources_per_forward`` consecutive batches of equal shape go through the
+        frozen sources as ONE forward of the concatenated batch, and the updates read their slices (views) of its taps --
+        the sources are in eval mode, so every sample's activations are what a separate forward gives (up to the vendor
+        kernels' rounding at another batch size) and the update order is unchanged.  ResNet-101 pair, 16 samples per
+        update: 6.6 ms of source forwards per update one by one, 6.2 ms in pairs, and the host dispatches them once per
+        group (whole job 7.22 -> 6.94 s).  Groups of four bring nothing more (7.05 s) and every new batch size costs the
+        vendor library its first-use set-up, so two is the default.
 
-        ``lookahead=True`` (without pairing): the next batch's source forwards are enqueued before the current update's
+        ``lookahead=True`` (without grouping): the next batch's source forwards are enqueued before the current update's
         kernels and run beside them (two tap generations in flight).  Measured on the ResNet-101 job: -3 % wall-clock
         (7.96 s vs 8.19 s), while every grouped kernel takes longer because it shares the CUs (fused forward 2.9 -> 4.3 ms
         per launch).  Off by default: per-kernel timings stay interpretable."""
+        group = max(1, int(sources_per_forward)) if (pair_sources and not lookahead) else 1
         with self._session():
             it = iter(batches)
-            nxt = next(it, None)
+            ahead: List[torch.Tensor] = []        # batches fetched from `it` but not applied yet
             idx = 0
-            while nxt is not None:
-                cur, nxt = nxt, next(it, None)
-                if (pair_sources and not lookahead and self._pending is None and nxt is not None
-                        and torch.is_tensor(cur) and torch.is_tensor(nxt) and cur.shape == nxt.shape and cur.shape[0] > 0):
-                    self._launch_pair(cur, nxt)           # both generations ready: cur now, nxt in the next iteration
-                self.step(cur, next_x=nxt if (lookahead and self._after is None) else None)
-                if self._after is not None:
-                    self._pending, self._after = self._after, None
+            while True:
+                want = group if (group > 1 and not self._after and self._pending is None) else (2 if lookahead else 1)
+                while len(ahead) < want:
+                    nxt = next(it, None)
+                    if nxt is None:
+                        break
+                    ahead.append(nxt)
+                if not ahead:
+                    break
+                if group > 1 and self._pending is None and not self._after:
+                    run = [ahead[0]]
+                    for cand in ahead[1:group]:
+                        if torch.is_tensor(cand) and torch.is_tensor(run[0]) and cand.shape == run[0].shape and cand.shape[0] > 0:
+                            run.append(cand)
+                        else:
+                            break
+                    if len(run) > 1:
+                        self._launch_group(run)     # `_pending` + `_after` now hold one generation per batch of the run
+                cur = ahead.pop(0)
+                self.step(cur, next_x=ahead[0] if (lookahead and ahead) else None)
+                if self._after:
+                    self._pending = self._after.pop(0)
                 yield idx
                 idx += 1
 
     @torch.no_grad()
-    def _launch_pair(self, a: torch.Tensor, b: torch.Tensor) -> None:
-        """One source forward for two batches; ``_pending`` / ``_after`` become their generations (views of its taps)."""
-        n = a.shape[0]
-        both = torch.cat([a.to(self.device, non_blocking=True), b.to(self.device, non_blocking=True)], 0)
-        xdev, (in1, out1), (in2, out2), events = self._launch_sources(both, slice_pair=True)
-        halves = []
-        for lo in (0, xdev.shape[0] // 2):
-            hi = lo + xdev.shape[0] // 2
-            cut = lambda d: {k: v[lo:hi] for k, v in d.items()}
-            halves.append((xdev, (cut(in1), cut(out1)), (cut(in2), cut(out2)), events))
-        self._pending = (a,) + halves[0]
-        self._after = (b,) + halves[1]
+    def _launch_group(self, run: List[torch.Tensor]) -> None:
+        """One source forward for several batches; ``_pending`` / ``_after`` become their generations (views of its taps)."""
+        both = torch.cat([b.to(self.device, non_blocking=True) for b in run], 0)
+        xdev, (in1, out1), (in2, out2), events = self._launch_sources(both, parts=len(run))
+        n = xdev.shape[0] // len(run)
+        gens = []
+        for i, b in enumerate(run):
+            lo, hi = i * n, (i + 1) * n
+            cut = lambda d, lo=lo, hi=hi: {k: v[lo:hi] for k, v in d.items()}
+            gens.append((b, xdev, (cut(in1), cut(out1)), (cut(in2), cut(out2)), events))
+        self._pending, self._after = gens[0], gens[1:]
 
     @torch.no_grad()
     def step(self, x: torch.Tensor, next_x: Optional[torch.Tensor] = None) -> None:

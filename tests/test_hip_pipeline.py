@@ -514,28 +514,29 @@ def test_lookahead_steps_equal_sequential_steps(tiny_bottleneck):
 
 
 def test_paired_source_forwards_equal_one_forward_per_batch(tiny_bottleneck):
-    """steps() runs the frozen sources once per TWO batches (one forward of twice the batch, the updates read halves of
-    its taps): same updates in the same order as one forward per batch, also with an odd number of batches."""
+    """steps() runs the frozen sources once per GROUP of batches (one forward of the concatenated batch, the updates read
+    their slices of its taps): same updates in the same order as one forward per batch, also with ragged tails."""
     from pleas.methods.partial_matching import partial_merge
     from pleas.methods.pleas_merging import PleasFitter
 
     t = tiny_bottleneck
     m1, m2 = _cuda_pair(t)
-    xs = [x for x, _ in t.batches() + t.batches()][:7]
+    xs = [x for x, _ in t.batches() + t.batches() + t.batches()][:11]
     perm = t.per_key("am_perm")
     costs = {k: v.cuda() for k, v in t.per_key("am_cost").items()}
     outs = []
-    for paired in (False, True):
+    for kw in ({"pair_sources": False}, {}, {"sources_per_forward": 4}, {"sources_per_forward": 3}):   # default: pairs
         m3 = partial_merge(t.spec, m1, m2, perm, costs, 0.5)
         fit = PleasFitter(m1, m2, m3, t.spec, perm, costs, 0.5, len(xs) - 1, num_classes=10)
-        assert list(fit.steps(xs, pair_sources=paired)) == list(range(len(xs)))
-        assert fit.step_count == len(xs) and fit._pending is None and fit._after is None
+        assert list(fit.steps(xs, **kw)) == list(range(len(xs)))
+        assert fit.step_count == len(xs) and fit._pending is None and not fit._after
         outs.append({k: v.clone() for k, v in fit.finish().state_dict().items()})
-    for k in outs[0]:
-        if k == DEGENERATE:
-            assert torch.allclose(outs[0][k], outs[1][k], atol=2 * 5e-4 * len(xs))
-        elif outs[0][k].dtype.is_floating_point:   # vendor kernels may round differently at another batch size
-            assert _rel(outs[0][k], outs[1][k]) < 1e-5, k
+    for other in outs[1:]:
+        for k in outs[0]:
+            if k == DEGENERATE:
+                assert torch.allclose(outs[0][k], other[k], atol=2 * 5e-4 * len(xs))
+            elif outs[0][k].dtype.is_floating_point:   # vendor kernels may round differently at another batch size
+                assert _rel(outs[0][k], other[k]) < 1e-5, k
 
 
 def test_config4_zip_budget_partial_merge_and_train_vs_oracle():
