@@ -69,8 +69,10 @@ class Workspace:
 
     def reserve(self, nbytes: int) -> torch.Tensor:
         if self.buf.numel() < nbytes:
-            # the old buffer may still be in use by queued kernels: the caching allocator keeps it
-            # alive on this stream until they have run
+            # the old buffer may still be in use by kernels queued on the current stream, which need not be the stream it
+            # was allocated on: tell the caching allocator before dropping it
+            if self.buf.numel():
+                self.buf.record_stream(torch.cuda.current_stream(self.device))
             self.buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
         return self.buf
 
