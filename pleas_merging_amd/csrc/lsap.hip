@@ -256,8 +256,10 @@ __global__ __launch_bounds__(kLsapThreads) void lsap_kernel(const LsapBatch batc
         lsap_solve<2>(sh, cost, n, sign, out, wave_best);
     else if (n <= 4 * kLsapThreads)
         lsap_solve<4>(sh, cost, n, sign, out, wave_best);
-    else
+    else if (n <= 8 * kLsapThreads)
         lsap_solve<8>(sh, cost, n, sign, out, wave_best);
+    else
+        lsap_solve<16>(sh, cost, n, sign, out, wave_best);   // only reachable with fewer than 256 threads (experiments)
 }
 
 }  // namespace pleas
