@@ -244,14 +244,30 @@ __device__ __forceinline__ void fwd_tile(const FwdLayerDev& L, const FwdItemDev&
     store_chunk(0);
     __syncthreads();
     PLEAS_FWD_STAMP(st1);
-    for (int c = 0; c < nchunks; ++c) {
+    // The block maps and biases of the epilogue are requested before the LAST chunk's MFMAs (no staging loads are in
+    // flight then): their round trip is covered by that chunk instead of opening the epilogue.
+    constexpr int ROWS = TM / 8, GB = 8, NB = ROWS / GB;
+    int m1[ROWS], m2[ROWS];
+    float bias_v[ROWS];
+    auto load_maps = [&]() {
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            const int co = min(i0 + (tid >> 5) + 8 * j, L.Cout - 1);
+            m1[j] = PLEAS_GLOBAL_I(L.row1)[co];
+            m2[j] = PLEAS_GLOBAL_I(L.row2)[co];
+            bias_v[j] = L.bias ? PLEAS_GLOBAL(L.bias)[co] : 0.f;
+        }
+    };
+    for (int c = 0; c + 1 < nchunks; ++c) {
         const int buf = c & 1;
-        const bool more = c + 1 < nchunks;
-        if (more) load_chunk(c + 1);
+        load_chunk(c + 1);
         compute(buf);
-        if (more) store_chunk(buf ^ 1);
+        store_chunk(buf ^ 1);
         __syncthreads();
     }
+    load_maps();
+    compute((nchunks - 1) & 1);
+    __syncthreads();
     PLEAS_FWD_STAMP(st2);
 
     // ---- epilogue.  Accumulators hold one pixel per lane; go through LDS once ([co][pixel], stride 132) so that
@@ -291,16 +307,6 @@ __device__ __forceinline__ void fwd_tile(const FwdLayerDev& L, const FwdItemDev&
     // is exposed once instead of once per step: block maps + bias -> first batch of target gathers (8 channels, branch
     // free: absent / out-of-range rows read element 0 and are masked) -> accumulators through LDS (the gathers are in
     // flight meanwhile) -> second batch issued -> first consumed -> second consumed.
-    constexpr int ROWS = TM / 8, GB = 8, NB = ROWS / GB;
-    int m1[ROWS], m2[ROWS];
-    float bias_v[ROWS];
-#pragma unroll
-    for (int j = 0; j < ROWS; ++j) {
-        const int co = min(i0 + (tid >> 5) + 8 * j, L.Cout - 1);
-        m1[j] = PLEAS_GLOBAL_I(L.row1)[co];
-        m2[j] = PLEAS_GLOBAL_I(L.row2)[co];
-        bias_v[j] = L.bias ? PLEAS_GLOBAL(L.bias)[co] : 0.f;
-    }
     if (vec_ok) {
         f32x4 ta[NB][GB], tb[NB][GB];
         auto gather = [&](const int bt) {
