@@ -511,6 +511,25 @@ static int build_fwd_plan(FwdPlan& P, const pleas_fwd_layer* ly, int n) {
     // but costs 1-4 % of time -- co-resident workgroups of one layer reach their latency-bound epilogues together,
     // while the plain longest-first order mixes layers on a CU.
     P.items = xcd_order_items(work, FwdItemDev{-1, 0, 0, 0}, /*by_default=*/false);
+    if (const char* env = std::getenv("PLEAS_FWD_ORDER")) {   // experiments: 1 = pseudo-random order, 2 = long / short interleaved
+        const int mode = std::atoi(env);
+        if (mode == 1) {
+            uint64_t st = 0x9E3779B97F4A7C15ull;
+            for (size_t i = P.items.size(); i > 1; --i) {
+                st = st * 6364136223846793005ull + 1442695040888963407ull;
+                std::swap(P.items[i - 1], P.items[(size_t)((st >> 33) % i)]);
+            }
+        } else if (mode == 2) {   // longest-first list folded: item k from the front, then item k from the back
+            std::vector<FwdItemDev> folded;
+            folded.reserve(P.items.size());
+            size_t lo = 0, hi = P.items.size();
+            while (lo < hi) {
+                folded.push_back(P.items[lo++]);
+                if (lo < hi) folded.push_back(P.items[--hi]);
+            }
+            P.items.swap(folded);
+        }
+    }
     P.n_parts = parts;
     size_t off = 0;
     P.off_layers = off;
