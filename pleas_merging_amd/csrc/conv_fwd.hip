@@ -491,8 +491,13 @@ static int build_fwd_plan(FwdPlan& P, const pleas_fwd_layer* ly, int n) {
         d.part_base = parts;
         const int tms = (int)ceil_div(l.Cout, TM), tps = (int)ceil_div(Ptot, fTN);
         int slot = 0;
-        for (int tm = 0; tm < tms; ++tm)
-            for (int tp = 0; tp < tps; ++tp) {
+        // Within a layer the output-channel tile runs fastest (PLEAS_FWD_ORDER=3 restores pixel-tile-fastest): with
+        // workgroup b on XCD b % 8, an XCD then keeps meeting the same few weight tiles, which stay in its L2, while
+        // every input tile is streamed once per XCD that needs it.
+        static const bool tp_major = !(std::getenv("PLEAS_FWD_ORDER") && std::atoi(std::getenv("PLEAS_FWD_ORDER")) == 3);
+        for (int outer = 0; outer < (tp_major ? tps : tms); ++outer)
+            for (int inner = 0; inner < (tp_major ? tms : tps); ++inner) {
+                const int tm = tp_major ? inner : outer, tp = tp_major ? outer : inner;
                 XcdWork<FwdItemDev> w;
                 w.it = FwdItemDev{i, tm, tp, slot++};
                 w.w = (double)ceil_div(Kd, fBK) * TM;
