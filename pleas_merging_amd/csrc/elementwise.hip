@@ -30,8 +30,8 @@ static hipEvent_t prof_event() {
         g_prof_free.pop_back();
         return e;
     }
-    hipEvent_t e;
-    hipEventCreate(&e);
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);   // a failed creation surfaces as an invalid-handle error at collect time
     return e;
 }
 void prof_begin(int kernel, double flops, double bytes, hipStream_t stream) {
@@ -42,12 +42,12 @@ void prof_begin(int kernel, double flops, double bytes, hipStream_t stream) {
     r.kernel = kernel;
     r.flops = flops;
     r.bytes = bytes;
-    hipEventRecord(r.a, stream);
+    (void)hipEventRecord(r.a, stream);
     g_prof_recs.push_back(r);
 }
 void prof_end(hipStream_t stream) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    hipEventRecord(g_prof_recs.back().b, stream);
+    (void)hipEventRecord(g_prof_recs.back().b, stream);
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
