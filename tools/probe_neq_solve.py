@@ -1,0 +1,27 @@
+"""Where does NormalEqFitter.solve() spend its 1.4 s?  cProfile + kernel profile of one solve after 3 accumulated batches."""
+import sys, os, time, cProfile, pstats
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pleas_merging_amd import resnet as zoo, hip_ops
+from pleas_merging_amd.core.compiler import get_permutation_spec
+from pleas_merging_amd.core.utils import make_identity_perm
+from pleas_merging_amd.methods.partial_matching import partial_merge
+from pleas_merging_amd.methods.normal_eq import NormalEqFitter
+dev = torch.device("cuda"); B = 16
+torch.manual_seed(0); m1 = zoo.resnet101().to(dev)
+torch.manual_seed(1); m2 = zoo.resnet101().to(dev)
+xs = [torch.randn(B, 3, 224, 224, device=dev) for _ in range(8)]
+with torch.no_grad():
+    zoo.calibrate_bn(m1, xs[:4]); zoo.calibrate_bn(m2, xs[:4])
+spec = get_permutation_spec(m1, ((1, 3, 224, 224),))
+perm = make_identity_perm(spec); costs = {k: torch.eye(g.size, device=dev) for k, g in spec.items()}
+m3 = partial_merge(spec, m1, m2, perm, costs, 0.0, device=dev)
+fit = NormalEqFitter(m1, m2, m3, spec, perm, costs, 0.0, 400)
+for _ in fit.steps(xs): pass
+torch.cuda.synchronize()
+hip_ops.profile_reset(); hip_ops.profile_enable(True)
+pr = cProfile.Profile(); t0 = time.time(); pr.enable(); info = fit.solve(); torch.cuda.synchronize(); pr.disable(); dt = time.time() - t0
+hip_ops.profile_enable(False); p = hip_ops.profile_collect()
+print("solve: %.3f s; fp64 fallbacks %s" % (dt, info.get("fp64_fallbacks", 0)))
+for k, v in p.items(): print("  %-12s %6d launches %9.2f ms" % (k, v[0], v[1]))
+pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
