@@ -104,9 +104,10 @@ def fuse_bn_act(model: nn.Module, op: Callable = _bn_act) -> Optional[torch.fx.G
                 relu = True
         last = chain[-1]
         with graph.inserting_before(last):
-            s = graph.get_attr("_pleas_scale_%s" % tag)
-            t = graph.get_attr("_pleas_shift_%s" % tag)
-            fused = graph.call_function(op, (node.args[0], s, t, res, relu))
+            # explicit base names: fx would otherwise derive them from the targets character by character
+            s = graph.create_node("get_attr", "_pleas_scale_%s" % tag, (), {}, name="bn_scale")
+            t = graph.create_node("get_attr", "_pleas_shift_%s" % tag, (), {}, name="bn_shift")
+            fused = graph.create_node("call_function", op, (node.args[0], s, t, res, relu), {}, name="bn_act")
         last.replace_all_uses_with(fused)
         for dead in reversed(chain):
             graph.erase_node(dead)
