@@ -79,6 +79,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                                                       "the multi-rank logic on a single GPU)")
     ap.add_argument("--all-ranks-on-gpu0", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="profiling aid, single process: time rank 0's share of an N-rank job with the collectives "
+                         "skipped (PLEAS_EMULATE_WORLD); the line is tagged emulated and is NOT a benchmark result")
     return ap.parse_args()
 
 
@@ -132,12 +135,11 @@ def run_job(spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, ratio, dp, 
     perm, costs = activation_matching(spec, m1, m2, match_loader, len(match_loader), output_costs=True,
                                       while_solving=lambda: early.update(sources=prepare_sources(m1, m2)))
     m3 = partial_merge(spec, m1, m2, perm, costs, ratio, device=next(m1.parameters()).device)   # stays on the GPU
-    # Data parallel: each rank's share of an update is small (batch / world samples), so the host-side dispatch of the two
-    # source forwards (~10 ms) and the gradient all-reduce dominate: replay the sources from hipGraphs and enqueue the
-    # next batch's sources before the current update, so that they run beside its all-reduce.
-    fit = PleasFitter(m1, m2, m3, spec, perm, costs, ratio, n_pleas_sched, data_parallel=dp, graph_sources=dp,
+    # Data parallel: each rank's share of an update is small (batch / world samples); the frozen sources therefore forward
+    # 2 * world updates' samples at once (steps() default), which keeps their host dispatch off the per-update path.
+    # (Replaying them from a hipGraph costs the host MORE than dispatching them: 9.6 ms per replay of ~600 nodes.)
+    fit = PleasFitter(m1, m2, m3, spec, perm, costs, ratio, n_pleas_sched, data_parallel=dp,
                       fused_sources=early.get("sources"))
-    lookahead = lookahead or dp
     for _ in fit.steps((x for x, _ in pleas_loader), lookahead=lookahead):
         pass
     return fit.finish(), perm, costs
@@ -274,16 +276,21 @@ def main():
     m1, m2 = build_models(args.arch, device, args.batch)
     log("models built + BN calibrated")
     spec = get_permutation_spec(m1, ((1, 3, 224, 224),))
-    # the PLeaS loop runs the frozen sources on pairs of batches: a warm-up of at least 3 updates meets both batch sizes
-    # (a pair and a single), so the vendor library's first-use set-up for a shape never lands in the timed region
-    warm_updates = max(args.warmup, 3) if args.warmup > 0 else 0
+    # the PLeaS loop runs the frozen sources on groups of 2 * ranks updates: a warm-up of one more update than that meets
+    # both forward sizes (a group and a single), so the vendor library's first-use set-up for a shape never lands in the timed region
+    ranks = max(world, args.emulate_world)
+    warm_updates = max(args.warmup, 2 * ranks + 1) if args.warmup > 0 else 0
     pool = Pool(max(n_match, n_pleas, args.warmup + 1, warm_updates), args.batch, device)
     dp = world > 1
+    if args.emulate_world > 1:
+        assert world == 1, "--emulate-world is a single-process aid"
+        os.environ["PLEAS_EMULATE_WORLD"] = str(args.emulate_world)
+        dp = True
     log("spec (%d groups) + %d synthetic batches resident" % (len(spec), len(pool.items)))
 
     # ---- warm-up: W matching batches + W updates on throw-away state (MIOpen find, allocator, graph build)
     if args.warmup > 0:
-        run_job(spec, m1, m2, pool.loader(0, args.warmup * world), pool.loader(0, warm_updates), max(1, warm_updates - 1),
+        run_job(spec, m1, m2, pool.loader(0, args.warmup * max(world, args.emulate_world)), pool.loader(0, warm_updates), max(1, warm_updates - 1),
                 args.ratio, dp, bool(args.lookahead))
 
     log("warm-up done")
@@ -364,7 +371,10 @@ def main():
             "roofline": roofline,
             "roofline_other": other,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if args.emulate_world > 1:
+            out["emulated"] = "rank 0's share of a %d-rank job, collectives skipped: NOT a benchmark result" % args.emulate_world
+            out["metric"] = "EMULATED " + out["metric"]
+        if world == 1 and not args.no_cpu_baseline and args.emulate_world <= 1:
             out["cpu_baseline"] = cpu_baseline(spec, args.arch, args.batch, args.cpu_sample_batch, n_match, n_pleas,
                                                args.ratio)
         if args.alt_solver and world == 1:

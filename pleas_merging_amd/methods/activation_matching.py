@@ -16,6 +16,8 @@ the reference's plug points (generic path).
 """
 from __future__ import annotations
 
+import os
+
 from typing import Callable, Dict, Iterable, List, Optional, Tuple
 
 import torch
@@ -365,7 +367,17 @@ def _dist_info():
 
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         return dist.get_rank(), dist.get_world_size()
-    return 0, 1
+    # PLEAS_EMULATE_WORLD=N (profiling aid, bench.py --emulate-world): this process does rank 0's share of an N-rank job
+    # with the collectives skipped -- the per-rank critical path of a multi-GPU run, timed on one GPU.  The RESULTS of such
+    # a run are partial sums and must not be used.
+    emulated = int(os.environ.get("PLEAS_EMULATE_WORLD", "0") or 0)
+    return (0, emulated) if emulated > 1 else (0, 1)
+
+
+def _collectives_on() -> bool:
+    import torch.distributed as dist
+
+    return dist.is_available() and dist.is_initialized()
 
 
 def _model_device(model: nn.Module) -> torch.device:
@@ -384,7 +396,7 @@ def shard_batches(dataloader, num_batches: int, rank: int, world: int):
 def allreduce_sum_(flat: torch.Tensor, world: int) -> torch.Tensor:
     """The one exchange step of the matching path: sum the flat cost arena over ranks
     (RCCL over xGMI under the ``nccl`` backend; gloo in the CPU tests)."""
-    if world > 1:
+    if world > 1 and _collectives_on():
         import torch.distributed as dist
 
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)

@@ -178,7 +178,8 @@ def dp_sum_(flat: torch.Tensor, world: int) -> torch.Tensor:
     if world > 1:
         import torch.distributed as dist
 
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if dist.is_initialized():       # not under PLEAS_EMULATE_WORLD (activation_matching._dist_info)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
 
 
@@ -474,7 +475,7 @@ class PleasFitter:
         finally:
             caller.wait_stream(upd)
 
-    def steps(self, batches, lookahead: bool = False, pair_sources: bool = True, sources_per_forward: int = 2):
+    def steps(self, batches, lookahead: bool = False, pair_sources: bool = True, sources_per_forward: Optional[int] = None):
         """Run one update per tensor of ``batches``; yields the index of each finished update.  The whole loop stays on
         the fitter's stream (also current for the consumer's code between two updates).
 
@@ -484,12 +485,18 @@ class PleasFitter:
         kernels' rounding at another batch size) and the update order is unchanged.  ResNet-101 pair, 16 samples per
         update: 6.6 ms of source forwards per update one by one, 6.2 ms in pairs, and the host dispatches them once per
         group (whole job 7.22 -> 6.94 s).  Groups of four bring nothing more (7.05 s) and every new batch size costs the
-        vendor library its first-use set-up, so two is the default.
+        vendor library its first-use set-up, so the default is two per rank: ``2 * world`` under data parallelism, where an
+        update's share is ``batch / world`` samples -- the source forward then has the same size for every ``world``, and its
+        ~5 ms of host dispatch (which bounds a rank at 6.8 ms per update when every update forwards its own 2 samples,
+        ``tools/probe_dp_rank.py``) is paid once per group.  Only FULL groups are formed; what is left when ``batches`` runs
+        out goes one by one, so the job meets two forward shapes in total.
 
         ``lookahead=True`` (without grouping): the next batch's source forwards are enqueued before the current update's
         kernels and run beside them (two tap generations in flight).  Measured on the ResNet-101 job: -3 % wall-clock
         (7.96 s vs 8.19 s), while every grouped kernel takes longer because it shares the CUs (fused forward 2.9 -> 4.3 ms
         per launch).  Off by default: per-kernel timings stay interpretable."""
+        if sources_per_forward is None:
+            sources_per_forward = 2 * self.world
         group = max(1, int(sources_per_forward)) if (pair_sources and not lookahead) else 1
         with self._session():
             it = iter(batches)
@@ -511,7 +518,7 @@ class PleasFitter:
                             run.append(cand)
                         else:
                             break
-                    if len(run) > 1:
+                    if len(run) == group:
                         self._launch_group(run)     # `_pending` + `_after` now hold one generation per batch of the run
                 cur = ahead.pop(0)
                 self.step(cur, next_x=ahead[0] if (lookahead and ahead) else None)
