@@ -68,9 +68,12 @@ def parse():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--ratio", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--lookahead", type=int, default=0, help="1: the next batch's source forwards are enqueued before the "
-                    "current PLeaS update and share the GPU with it (PleasFitter.steps(lookahead=True): about -3 %% "
-                    "wall-clock, but per-kernel durations then include the contention); 0 (default): one batch at a time")
+    ap.add_argument("--emulate-allreduce-us", type=float, default=0.0,
+                    help="with --emulate-world: hold the update stream this long where the gradient all-reduce would run")
+    ap.add_argument("--lookahead", type=int, default=-1, help="1: the next group's source forwards are enqueued before the "
+                    "current group's PLeaS updates and share the GPU with them (PleasFitter.steps(lookahead=True): about "
+                    "-3 %% wall-clock on one GPU, but per-kernel durations then include the contention); 0: one group at a "
+                    "time; -1 (default): 0 on one GPU, 1 under data parallelism (fills the all-reduce gaps)")
     ap.add_argument("--profile-all", action="store_true", help="also bracket the many-launch elementwise kernel "
                     "(bn_act) with events: complete phases_ms, slightly slower timed region")
     ap.add_argument("--cpu-sample-batch", type=int, default=2)
@@ -123,7 +126,7 @@ def build_models(arch, device, batch):
     return models
 
 
-def run_job(spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, ratio, dp, lookahead=True):
+def run_job(spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, ratio, dp, lookahead=None):
     """The timed hot path.  Returns (merged model, perm, costs)."""
     from pleas_merging_amd.methods.activation_matching import activation_matching
     from pleas_merging_amd.methods.partial_matching import partial_merge
@@ -285,13 +288,14 @@ def main():
     if args.emulate_world > 1:
         assert world == 1, "--emulate-world is a single-process aid"
         os.environ["PLEAS_EMULATE_WORLD"] = str(args.emulate_world)
+        os.environ["PLEAS_EMULATE_ALLREDUCE_US"] = str(args.emulate_allreduce_us)
         dp = True
     log("spec (%d groups) + %d synthetic batches resident" % (len(spec), len(pool.items)))
 
     # ---- warm-up: W matching batches + W updates on throw-away state (MIOpen find, allocator, graph build)
     if args.warmup > 0:
         run_job(spec, m1, m2, pool.loader(0, args.warmup * max(world, args.emulate_world)), pool.loader(0, warm_updates), max(1, warm_updates - 1),
-                args.ratio, dp, bool(args.lookahead))
+                args.ratio, dp, None if args.lookahead < 0 else bool(args.lookahead))
 
     log("warm-up done")
     # ---- timed region.  Events bracket the few-launches-per-step kernels only: bn_act runs ~200 times per step and would
@@ -303,7 +307,7 @@ def main():
         dist.barrier()
     t0 = time.perf_counter()
     m3, perm, costs = run_job(spec, m1, m2, pool.loader(0, n_match), pool.loader(0, n_pleas), max(1, n_sched), args.ratio, dp,
-                              bool(args.lookahead))
+                              None if args.lookahead < 0 else bool(args.lookahead))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -372,7 +376,9 @@ def main():
             "roofline_other": other,
         }
         if args.emulate_world > 1:
-            out["emulated"] = "rank 0's share of a %d-rank job, collectives skipped: NOT a benchmark result" % args.emulate_world
+            out["emulated"] = ("rank 0's share of a %d-rank job, collectives %s: NOT a benchmark result"
+                               % (args.emulate_world, "replaced by a %.0f us stall of the update stream" % args.emulate_allreduce_us
+                                  if args.emulate_allreduce_us > 0 else "skipped"))
             out["metric"] = "EMULATED " + out["metric"]
         if world == 1 and not args.no_cpu_baseline and args.emulate_world <= 1:
             out["cpu_baseline"] = cpu_baseline(spec, args.arch, args.batch, args.cpu_sample_batch, n_match, n_pleas,

@@ -28,6 +28,7 @@ MI355X design of one Adam step (13 ms for a ResNet-101 pair at batch 16)
 """
 from __future__ import annotations
 
+import collections
 import contextlib
 import math
 from typing import Dict, List, Optional, Tuple
@@ -178,9 +179,33 @@ def dp_sum_(flat: torch.Tensor, world: int) -> torch.Tensor:
     if world > 1:
         import torch.distributed as dist
 
-        if dist.is_initialized():       # not under PLEAS_EMULATE_WORLD (activation_matching._dist_info)
+        if dist.is_initialized():
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        else:                           # PLEAS_EMULATE_WORLD (activation_matching._dist_info): no peers
+            _emulated_collective(flat)
     return flat
+
+
+_SPIN = {}
+
+
+def _emulated_collective(flat: torch.Tensor) -> None:
+    """Profiling aid: with PLEAS_EMULATE_ALLREDUCE_US=T the stream is held for T microseconds where the all-reduce
+    would run (a spin kernel on one CU), so that what overlaps a collective can be studied on one GPU."""
+    import os
+
+    us = float(os.environ.get("PLEAS_EMULATE_ALLREDUCE_US", "0") or 0)
+    if us <= 0 or not flat.is_cuda:
+        return
+    if "per_us" not in _SPIN:           # calibrate the spin kernel's cycle unit once
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(1000)
+        a.record()
+        torch.cuda._sleep(2_000_000)
+        b.record()
+        b.synchronize()
+        _SPIN["per_us"] = 2_000_000 / (a.elapsed_time(b) * 1e3)
+    torch.cuda._sleep(int(us * _SPIN["per_us"]))
 
 
 class PleasFitter:
@@ -227,8 +252,9 @@ class PleasFitter:
         self._upd_stream = torch.cuda.Stream(self.device) if overlap_sources else None
         self._src_events = None
         self._slice_batch = True   # data parallel: every update splits its batch's samples over the ranks
-        self._pending = None     # (batch as passed, its device copy, taps of model1, taps of model2, events): prefetched
-        self._after: list = []   # further generations of a grouped source forward: each becomes `_pending` in turn
+        # generations whose source forwards are enqueued, in update order:
+        # (batch as passed, its device copy, taps of model1, taps of model2, events)
+        self._queue: collections.deque = collections.deque()
         self._cur_x = None
         self.t1_in = self.t1_out = self.t2_in = self.t2_out = None   # taps of the update being applied
 
@@ -238,7 +264,9 @@ class PleasFitter:
         total = sum(pad4(p.numel()) for m in layers.values() for p in m.parameters())
         dev = self.device
         self.p = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.g = torch.zeros(total, dtype=torch.float32, device=dev)
+        # the gradient arena carries this update's per-layer losses in its tail: ONE collective per update sums both
+        self._g_ext = torch.zeros(total + len(layers), dtype=torch.float32, device=dev)
+        self.g = self._g_ext[:total]
         self.m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.v = torch.zeros(total, dtype=torch.float32, device=dev)
         self.mask = torch.ones(total, dtype=torch.float32, device=dev)   # frozen blocks are zeroed in place below
@@ -285,7 +313,7 @@ class PleasFitter:
         self.max_steps = max_steps
         self.lrs = cosine_lrs(lr, max_steps, max_steps + 1)
         self.step_count = 0
-        self.loss_now = torch.zeros(len(self.plans), dtype=torch.float32, device=dev)   # this step, per layer
+        self.loss_now = self._g_ext[total:]                                             # this step, per layer
         self.loss_sum = torch.zeros(len(self.plans), dtype=torch.float32, device=dev)   # since last report
         self.loss_parts = torch.zeros(len(self.plans), hip_ops.target_residual_max_partials(), dtype=torch.float32,
                                       device=dev)
@@ -441,12 +469,11 @@ class PleasFitter:
     def _begin_update(self, x: torch.Tensor, next_x: Optional[torch.Tensor]) -> None:
         """Taps of ``x`` become current (running its sources now unless they were prefetched); the sources of
         ``next_x`` are enqueued BEFORE this update's own kernels, so that they overlap them on the side streams."""
-        if self._pending is not None and self._pending[0] is not x:
-            raise RuntimeError("PleasFitter.step: a different batch was prefetched with next_x than the one passed now")
-        cur = self._pending if self._pending is not None else (x,) + self._launch_sources(x)
-        self._pending = None
-        if next_x is not None and (self._side_streams is not None or self.graph_sources):
-            self._pending = (next_x,) + self._launch_sources(next_x)
+        if self._queue and self._queue[0][0] is not x:
+            raise RuntimeError("PleasFitter.step: a different batch was prefetched than the one passed now")
+        cur = self._queue.popleft() if self._queue else (x,) + self._launch_sources(x)
+        if next_x is not None and not self._queue and (self._side_streams is not None or self.graph_sources):
+            self._queue.append((next_x,) + self._launch_sources(next_x))
         _, self._cur_x, (self.t1_in, self.t1_out), (self.t2_in, self.t2_out), events = cur
         if events is not None:
             main = torch.cuda.current_stream(self.device)
@@ -475,7 +502,7 @@ class PleasFitter:
         finally:
             caller.wait_stream(upd)
 
-    def steps(self, batches, lookahead: bool = False, pair_sources: bool = True, sources_per_forward: Optional[int] = None):
+    def steps(self, batches, lookahead: Optional[bool] = None, pair_sources: bool = True, sources_per_forward: Optional[int] = None):
         """Run one update per tensor of ``batches``; yields the index of each finished update.  The whole loop stays on
         the fitter's stream (also current for the consumer's code between two updates).
 
@@ -491,45 +518,54 @@ class PleasFitter:
         ``tools/probe_dp_rank.py``) is paid once per group.  Only FULL groups are formed; what is left when ``batches`` runs
         out goes one by one, so the job meets two forward shapes in total.
 
-        ``lookahead=True`` (without grouping): the next batch's source forwards are enqueued before the current update's
-        kernels and run beside them (two tap generations in flight).  Measured on the ResNet-101 job: -3 % wall-clock
-        (7.96 s vs 8.19 s), while every grouped kernel takes longer because it shares the CUs (fused forward 2.9 -> 4.3 ms
-        per launch).  Off by default: per-kernel timings stay interpretable."""
+        ``lookahead=True``: the source forwards of the NEXT group (or batch) are enqueued before the current group's updates
+        and run beside them on the side streams (two tap generations in flight).  On one GPU the update kernels already
+        fill the chip: -3 % wall-clock (7.96 s vs 8.19 s, ungrouped) while every grouped kernel takes longer because it
+        shares the CUs (fused forward 2.9 -> 4.3 ms per launch), so it is off there and per-kernel timings stay
+        interpretable.  Under data parallelism (the default then) the stream that applies the updates idles during every
+        gradient all-reduce, and the prefetched source forwards are what fills those gaps."""
         if sources_per_forward is None:
             sources_per_forward = 2 * self.world
-        group = max(1, int(sources_per_forward)) if (pair_sources and not lookahead) else 1
+        group = max(1, int(sources_per_forward)) if pair_sources else 1
+        if lookahead is None:
+            lookahead = self.world > 1
+        keep = group if lookahead else 0      # sources are launched whenever no more than `keep` generations are queued
         with self._session():
             it = iter(batches)
-            ahead: List[torch.Tensor] = []        # batches fetched from `it` but not applied yet
+            ahead: List[torch.Tensor] = []        # fetched from `it`, sources not launched yet
+            exhausted = False
             idx = 0
             while True:
-                want = group if (group > 1 and not self._after and self._pending is None) else (2 if lookahead else 1)
-                while len(ahead) < want:
-                    nxt = next(it, None)
-                    if nxt is None:
+                while len(self._queue) <= keep:
+                    while len(ahead) < group and not exhausted:
+                        nxt = next(it, None)
+                        if nxt is None:
+                            exhausted = True
+                        else:
+                            ahead.append(nxt)
+                    if not ahead:
                         break
-                    ahead.append(nxt)
-                if not ahead:
-                    break
-                if group > 1 and self._pending is None and not self._after:
                     run = [ahead[0]]
                     for cand in ahead[1:group]:
                         if torch.is_tensor(cand) and torch.is_tensor(run[0]) and cand.shape == run[0].shape and cand.shape[0] > 0:
                             run.append(cand)
                         else:
                             break
-                    if len(run) == group:
-                        self._launch_group(run)     # `_pending` + `_after` now hold one generation per batch of the run
-                cur = ahead.pop(0)
-                self.step(cur, next_x=ahead[0] if (lookahead and ahead) else None)
-                if self._after:
-                    self._pending = self._after.pop(0)
+                    if group > 1 and len(run) == group:
+                        self._launch_group(run)      # one generation per batch of the run
+                        del ahead[:group]
+                    else:
+                        b = ahead.pop(0)
+                        self._queue.append((b,) + self._launch_sources(b))
+                if not self._queue:
+                    break
+                self.step(self._queue[0][0])
                 yield idx
                 idx += 1
 
     @torch.no_grad()
     def _launch_group(self, run: List[torch.Tensor]) -> None:
-        """One source forward for several batches; ``_pending`` / ``_after`` become their generations (views of its taps)."""
+        """One source forward for several batches; their generations (views of its taps) join the queue."""
         both = torch.cat([b.to(self.device, non_blocking=True) for b in run], 0)
         xdev, (in1, out1), (in2, out2), events = self._launch_sources(both, parts=len(run))
         n = xdev.shape[0] // len(run)
@@ -538,7 +574,7 @@ class PleasFitter:
             lo, hi = i * n, (i + 1) * n
             cut = lambda d, lo=lo, hi=hi: {k: v[lo:hi] for k, v in d.items()}
             gens.append((b, xdev, (cut(in1), cut(out1)), (cut(in2), cut(out2)), events))
-        self._pending, self._after = gens[0], gens[1:]
+        self._queue.extend(gens)
 
     @torch.no_grad()
     def step(self, x: torch.Tensor, next_x: Optional[torch.Tensor] = None) -> None:
@@ -570,8 +606,7 @@ class PleasFitter:
             self.loss_now.index_copy_(0, self._fwd_index, self._fwd_loss)
         self._finish_vendor_parts()
         self.wgrad.flush()  # ONE grouped MFMA launch: weight gradients of every merged layer
-        dp_sum_(self.g, self.world)
-        dp_sum_(self.loss_now, self.world)
+        dp_sum_(self._g_ext, self.world)     # gradients + losses
         self.loss_sum.add_(self.loss_now)
         lr = self.lrs[min(self.step_count, len(self.lrs) - 1)]
         self.step_count += 1

@@ -492,8 +492,8 @@ def test_lookahead_steps_equal_sequential_steps(tiny_bottleneck):
         m3 = partial_merge(t.spec, m1, m2, perm, costs, 0.5)
         fit = PleasFitter(m1, m2, m3, t.spec, perm, costs, 0.5, len(xs) - 1, num_classes=10)
         if lookahead:
-            assert list(fit.steps(xs, lookahead=True)) == list(range(len(xs)))
-            assert fit._pending is None
+            assert list(fit.steps(xs, lookahead=True, pair_sources=False)) == list(range(len(xs)))
+            assert not fit._queue
         else:
             for x in xs:
                 fit.step(x)
@@ -525,11 +525,12 @@ def test_paired_source_forwards_equal_one_forward_per_batch(tiny_bottleneck):
     perm = t.per_key("am_perm")
     costs = {k: v.cuda() for k, v in t.per_key("am_cost").items()}
     outs = []
-    for kw in ({"pair_sources": False}, {}, {"sources_per_forward": 4}, {"sources_per_forward": 3}):   # default: pairs
+    for kw in ({"pair_sources": False}, {}, {"sources_per_forward": 4}, {"sources_per_forward": 3},   # default: pairs
+               {"lookahead": True}, {"sources_per_forward": 3, "lookahead": True}):   # next group enqueued beforehand
         m3 = partial_merge(t.spec, m1, m2, perm, costs, 0.5)
         fit = PleasFitter(m1, m2, m3, t.spec, perm, costs, 0.5, len(xs) - 1, num_classes=10)
         assert list(fit.steps(xs, **kw)) == list(range(len(xs)))
-        assert fit.step_count == len(xs) and fit._pending is None and not fit._after
+        assert fit.step_count == len(xs) and not fit._queue
         outs.append({k: v.clone() for k, v in fit.finish().state_dict().items()})
     for other in outs[1:]:
         for k in outs[0]:
