@@ -1,0 +1,95 @@
+"""Two ranks on ONE MI355X (gloo rendezvous, both processes on cuda:0): the data-parallel HIP path end to end --
+batch-sharded matching with one all-reduce of the cost arena, sample-sharded PLeaS updates with grouped source
+forwards, look-ahead and one all-reduce (gradients + losses) per update -- against the single-process HIP path on the
+same inputs.  RCCL refuses two ranks on one device, so the collectives go through gloo here; the calls are the same."""
+import copy
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+N_MATCH, N_UPDATES = 4, 11      # 11 updates: two full groups of 2 * world = 4 batches and a tail of three singles
+
+
+def _batches(t):
+    xs = [x for x, _ in t.batches() + t.batches() + t.batches()]
+    return [x + 0.01 * i for i, x in enumerate(xs)][:N_UPDATES]
+
+
+def _job(t, data_parallel):
+    from pleas.methods.activation_matching import activation_matching
+    from pleas.methods.partial_matching import partial_merge
+    from pleas.methods.pleas_merging import PleasFitter
+
+    m1, m2 = copy.deepcopy(t.m1).cuda(), copy.deepcopy(t.m2).cuda()
+    perm, costs = activation_matching(t.spec, m1, m2, t.batches(), N_MATCH, output_costs=True)
+    m3 = partial_merge(t.spec, m1, m2, perm, costs, 0.5)
+    fit = PleasFitter(m1, m2, m3, t.spec, perm, costs, 0.5, N_UPDATES - 1, num_classes=10, data_parallel=data_parallel)
+    assert list(fit.steps(_batches(t))) == list(range(N_UPDATES))
+    loss = fit.loss_sum.clone()
+    torch.cuda.synchronize()
+    return ({k: v.cpu() for k, v in perm.items()}, {k: v.cpu() for k, v in costs.items()},
+            {k: v.cpu() for k, v in fit.finish().state_dict().items()}, loss.cpu(), fit.world)
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+
+    from conftest import Tiny
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        perm, costs, sd, loss, world = _job(Tiny("tiny_bottleneck.npz"), data_parallel=True)
+        as_np = lambda d: {k: v.numpy() for k, v in d.items()}   # plain arrays: nothing shared with a process that exits
+        q.put((rank, (as_np(perm), as_np(costs), as_np(sd), loss.numpy(), world)))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+def test_two_rank_job_equals_single_process_job(tiny_bottleneck):
+    want_perm, want_costs, want_sd, want_loss, world1 = _job(tiny_bottleneck, data_parallel=False)
+    assert world1 == 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, 29641, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=300) for _ in procs)
+    as_t = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}
+    results = {r: (as_t(p), as_t(c), as_t(sd), torch.from_numpy(l), w) for r, (p, c, sd, l, w) in results.items()}
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(results) == [0, 1]
+    for rank, (perm, costs, sd, loss, world) in results.items():
+        assert world == 2
+        for k in want_perm:
+            assert torch.equal(perm[k], want_perm[k]), (rank, k)
+            assert torch.allclose(costs[k], want_costs[k], rtol=1e-5, atol=1e-5), (rank, k)
+        assert torch.allclose(loss, want_loss, rtol=1e-4, atol=1e-7), rank
+        for k, v in want_sd.items():
+            if not v.dtype.is_floating_point:
+                continue
+            if k == "conv1.weight":   # degenerate stem: sign-like Adam steps amplify rounding
+                assert torch.allclose(sd[k], v, atol=2 * 5e-4 * N_UPDATES), (rank, k)
+            else:
+                assert _rel(sd[k], v) < 2e-5, (rank, k, _rel(sd[k], v))
+    # both ranks hold the same model, bit for bit (every rank applies the same all-reduced update)
+    for k, v in results[0][2].items():
+        assert torch.equal(v, results[1][2][k]), k
