@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--ratio", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prefetch-groups", type=int, default=8,
+                    help="groups of source forwards enqueued while the LAP kernel runs (0: none); also bounded by memory")
     ap.add_argument("--emulate-allreduce-us", type=float, default=0.0,
                     help="with --emulate-world: hold the update stream this long where the gradient all-reduce would run")
     ap.add_argument("--lookahead", type=int, default=-1, help="1: the next group's source forwards are enqueued before the "
@@ -126,24 +128,30 @@ def build_models(arch, device, batch):
     return models
 
 
-def run_job(spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, ratio, dp, lookahead=None):
+def run_job(spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, ratio, dp, lookahead=None, prefetch_groups=8):
     """The timed hot path.  Returns (merged model, perm, costs)."""
     from pleas_merging_amd.methods.activation_matching import activation_matching
     from pleas_merging_amd.methods.partial_matching import partial_merge
-    from pleas_merging_amd.methods.pleas_merging import PleasFitter, prepare_sources
+    from pleas_merging_amd.methods.pleas_merging import FrozenSources, PleasFitter
 
-    # the fused source forwards of the PLeaS phase do not depend on the permutation: the host builds them while the
-    # batched LAP kernel runs
+    # The frozen sources of the PLeaS phase do not depend on the permutation: while the batched LAP kernel runs (0.28 s, one
+    # workgroup per problem), the host builds their fused forwards and enqueues the first groups of source forwards on
+    # the side streams, where they also fill the GPU's idle time during partial merge and fitter set-up.
     early = {}
+    inputs = [x for x, _ in pleas_loader]
+
+    def while_solving():
+        early["sources"] = src = FrozenSources(m1, m2, data_parallel=dp)
+        src.prefetch(inputs, max_groups=prefetch_groups)
+
     perm, costs = activation_matching(spec, m1, m2, match_loader, len(match_loader), output_costs=True,
-                                      while_solving=lambda: early.update(sources=prepare_sources(m1, m2)))
+                                      while_solving=while_solving)
     m3 = partial_merge(spec, m1, m2, perm, costs, ratio, device=next(m1.parameters()).device)   # stays on the GPU
     # Data parallel: each rank's share of an update is small (batch / world samples); the frozen sources therefore forward
     # 2 * world updates' samples at once (steps() default), which keeps their host dispatch off the per-update path.
     # (Replaying them from a hipGraph costs the host MORE than dispatching them: 9.6 ms per replay of ~600 nodes.)
-    fit = PleasFitter(m1, m2, m3, spec, perm, costs, ratio, n_pleas_sched, data_parallel=dp,
-                      fused_sources=early.get("sources"))
-    for _ in fit.steps((x for x, _ in pleas_loader), lookahead=lookahead):
+    fit = PleasFitter(m1, m2, m3, spec, perm, costs, ratio, n_pleas_sched, data_parallel=dp, sources=early.get("sources"))
+    for _ in fit.steps(inputs, lookahead=lookahead):
         pass
     return fit.finish(), perm, costs
 
@@ -279,10 +287,11 @@ def main():
     m1, m2 = build_models(args.arch, device, args.batch)
     log("models built + BN calibrated")
     spec = get_permutation_spec(m1, ((1, 3, 224, 224),))
-    # the PLeaS loop runs the frozen sources on groups of 2 * ranks updates: a warm-up of one more update than that meets
-    # both forward sizes (a group and a single), so the vendor library's first-use set-up for a shape never lands in the timed region
+    # the PLeaS loop runs the frozen sources on groups of 2 * ranks updates and enqueues up to --prefetch-groups of them
+    # while the LAP kernel runs: a warm-up of one more update than that meets both forward sizes (a group and a single)
+    # and leaves the caching allocator with the blocks those prefetched generations need, so the vendor library's first-use set-up for a shape never lands in the timed region
     ranks = max(world, args.emulate_world)
-    warm_updates = max(args.warmup, 2 * ranks + 1) if args.warmup > 0 else 0
+    warm_updates = max(args.warmup, 2 * ranks * max(1, args.prefetch_groups) + 1) if args.warmup > 0 else 0
     pool = Pool(max(n_match, n_pleas, args.warmup + 1, warm_updates), args.batch, device)
     dp = world > 1
     if args.emulate_world > 1:
@@ -295,7 +304,7 @@ def main():
     # ---- warm-up: W matching batches + W updates on throw-away state (MIOpen find, allocator, graph build)
     if args.warmup > 0:
         run_job(spec, m1, m2, pool.loader(0, args.warmup * max(world, args.emulate_world)), pool.loader(0, warm_updates), max(1, warm_updates - 1),
-                args.ratio, dp, None if args.lookahead < 0 else bool(args.lookahead))
+                args.ratio, dp, None if args.lookahead < 0 else bool(args.lookahead), args.prefetch_groups)
 
     log("warm-up done")
     # ---- timed region.  Events bracket the few-launches-per-step kernels only: bn_act runs ~200 times per step and would
@@ -307,7 +316,7 @@ def main():
         dist.barrier()
     t0 = time.perf_counter()
     m3, perm, costs = run_job(spec, m1, m2, pool.loader(0, n_match), pool.loader(0, n_pleas), max(1, n_sched), args.ratio, dp,
-                              None if args.lookahead < 0 else bool(args.lookahead))
+                              None if args.lookahead < 0 else bool(args.lookahead), args.prefetch_groups)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

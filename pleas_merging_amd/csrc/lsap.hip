@@ -237,6 +237,9 @@ __device__ void lsap_solve(const LsapShared sh, const float* __restrict__ cost, 
 __global__ __launch_bounds__(kLsapThreads) void lsap_kernel(const LsapBatch batch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lsap_smem[];
     __shared__ Cand wave_best[2][kLsapWaves];
+    // The kernel is one long dependent chain on a single CU; other streams may fill the rest of the GPU meanwhile
+    // (source forwards enqueued during the solve), and their waves then share this CU's SIMDs: issue ours first.
+    __builtin_amdgcn_s_setprio(3);
     const int prob = blockIdx.x;
     const int n = batch.n[prob];
     LsapShared sh;

@@ -525,9 +525,19 @@ def solve_all(costs: Dict[Axis, torch.Tensor], lsa_solver: Callable, while_solvi
     if lsa_solver is hip_solve_lsa:
         from .. import hip_ops
 
-        outs = hip_ops.solve_lsa_batched(list(costs.values()), maximize=True)
-        if while_solving is not None:
+        mats = list(costs.values())
+        dev = mats[0].device if mats else None
+        if dev is None or dev.type != "cuda" or while_solving is None:
+            outs = hip_ops.solve_lsa_batched(mats, maximize=True)
+        else:
+            # the kernel gets a stream of its own: what `while_solving` enqueues elsewhere (source forwards on side
+            # streams) then runs beside it also when the caller is on torch's default stream
+            caller, solver = torch.cuda.current_stream(dev), torch.cuda.Stream(dev)
+            solver.wait_stream(caller)
+            with torch.cuda.stream(solver):
+                outs = hip_ops.solve_lsa_batched(mats, maximize=True)
             while_solving()
+            caller.wait_stream(solver)
         return {k: o.cpu() for k, o in zip(costs.keys(), outs)}
     if while_solving is not None:
         while_solving()

@@ -208,6 +208,202 @@ def _emulated_collective(flat: torch.Tensor) -> None:
     torch.cuda._sleep(int(us * _SPIN["per_us"]))
 
 
+class FrozenSources:
+    """The two frozen source models as the PLeaS loop runs them: eval mode, BatchNorm / add / ReLU chains folded into one
+    HIP pass each (``source_forward.py``), taps on every Conv2d / Linear, each model on its own side stream.  A forward
+    produces a GENERATION ``(device batch, taps of model1, taps of model2, events)``; ``queue`` holds the generations whose
+    forwards are enqueued, in update order, as ``(batch as passed,) + generation``.
+
+    Nothing here depends on the permutation or on the merged model, so the object can be built -- and the first forwards
+    enqueued (``prefetch``) -- while the LAP kernel is still running; ``PleasFitter(sources=...)`` then takes it over."""
+
+    def __init__(self, model1: nn.Module, model2: nn.Module, data_parallel: bool = False, fuse: bool = True,
+                 overlap: bool = True, graph: bool = False, fused=None):
+        from .. import hip_ops
+        from .activation_matching import _dist_info
+
+        self.ops = hip_ops
+        self.rank, self.world = _dist_info() if data_parallel else (0, 1)
+        self.device = next(iter(model1.parameters())).device
+        if self.device.type != "cuda":
+            raise hip_ops.PleasHipError("pleas_merging.train: source models must be on the GPU (got %s)" % self.device)
+        self.tap1, self.tap2 = ActivationTap(model1), ActivationTap(model2)
+        model1.eval()
+        model2.eval()
+        # the hooked Conv2d / Linear modules are shared with the rewritten graphs, so the taps see the same tensors
+        self.src1, self.src2 = model1, model2
+        if fused is not None:               # built ahead of time (prepare_sources)
+            self.src1, self.src2 = fused
+        elif fuse:
+            self.src1, self.src2 = prepare_sources(model1, model2)
+        # The two source forwards are independent chains of small kernels (one conv of a batch-16 ResNet fills a
+        # fraction of 256 CUs).  Each source gets its own stream: their chains then also run NEXT TO the big grouped
+        # kernels of an update when they are enqueued ahead of it.  Equal priorities: favouring either side was slower
+        # (chain first 8.7 s, update first 11.5 s).
+        self._side_streams = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)) if overlap else None
+        self._src_events = None
+        self._slice_batch = True   # data parallel: every update splits its batch's samples over the ranks
+        self.queue: collections.deque = collections.deque()
+        # graph=True: from the second batch of a shape on, the two source forwards (~420 launches, ~35 us of host
+        # time per vendor convolution) are replayed from hipGraphs instead of being dispatched op by op: TWO graphs with
+        # their own static input and taps take turns, so that the sources of the next batch can be replayed while the
+        # update of the current one still reads the other generation.  Inside a graph the two models sit on parallel
+        # branches (captured from the two side streams).  Capture costs ~0.05 s per graph; a capture problem falls back
+        # to eager dispatch for the rest of the run.  (Measured later: one replay of the ~600 nodes costs the host 9.6 ms,
+        # more than dispatching them -- kept as an option, used by nothing.)
+        self.graph_sources = graph
+        self._graphs = [None, None]     # per generation: dict(graph, x, taps1, taps2, shape)
+        self._graph_turn = 0
+        self._graph_seen: Dict[tuple, int] = {}
+        self._graph_stream = torch.cuda.Stream(self.device, priority=-1) if graph else None
+
+    def launch(self, x: torch.Tensor, parts: int = 1, after_current: bool = True):
+        """Enqueue both source forwards for ``x``; returns the generation (device batch, taps, events) the update will
+        consume.  ``parts`` > 1: ``x`` is that many batches back to back, each of which is sample-sliced on its own."""
+        x = x.to(self.device, non_blocking=True)
+        if self._slice_batch:
+            if parts > 1 and self.world > 1:
+                h = x.shape[0] // parts
+                x = torch.cat([dp_slice(x[i * h:(i + 1) * h], self.rank, self.world) for i in range(parts)], 0)
+            else:
+                x = dp_slice(x, self.rank, self.world)
+        if self.graph_sources:
+            gen = self._launch_graph(x)
+            if gen is not None:
+                return gen
+        self.run_eager(x, after_current)
+        events = self._src_events
+        self._src_events = None
+        return (x, self.tap1.take(), self.tap2.take(), events)
+
+    def _capture_sources(self, x: torch.Tensor) -> dict:
+        self.tap1.take()
+        self.tap2.take()
+        x_static = x.clone()
+        graph = torch.cuda.CUDAGraph()
+        torch.cuda.current_stream(self.device).synchronize()
+        # thread_local: other threads (e.g. the collective watchdog of torch.distributed) may keep calling the runtime
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            cap = torch.cuda.current_stream(self.device)
+            side = self._side_streams or (cap, cap)
+            for stream, model in zip(side, (self.src1, self.src2)):
+                if stream is not cap:
+                    stream.wait_stream(cap)
+                with torch.cuda.stream(stream), self.ops.pin_stream():
+                    model(x_static)
+            for stream in side:
+                if stream is not cap:
+                    cap.wait_stream(stream)
+        return {"graph": graph, "x": x_static, "taps1": self.tap1.take(), "taps2": self.tap2.take(),
+                "shape": tuple(x.shape)}
+
+    def _launch_graph(self, x: torch.Tensor):
+        """Replay (capturing first if needed) this generation's source graph on the graph stream; None = run eagerly."""
+        key = tuple(x.shape)
+        seen = self._graph_seen[key] = self._graph_seen.get(key, 0) + 1
+        if seen <= 1:                    # the first batch of a shape runs eagerly: vendor plans, allocator
+            return None
+        slot = self._graph_turn = (self._graph_turn + 1) % 2
+        main, gs = torch.cuda.current_stream(self.device), self._graph_stream
+        try:
+            # everything below is ordered after the work already enqueued on `main`: in particular after the update that
+            # last read this generation's static taps (two updates back with one batch of look-ahead)
+            gs.wait_stream(main)
+            with torch.cuda.stream(gs):
+                g = self._graphs[slot]
+                if g is None or g["shape"] != key:
+                    g = self._graphs[slot] = self._capture_sources(x)
+                g["x"].copy_(x, non_blocking=True)
+                g["graph"].replay()
+                ev = torch.cuda.Event()
+                ev.record(gs)
+            return (x, g["taps1"], g["taps2"], [ev])
+        except Exception as exc:  # noqa: BLE001 -- capture is an optimisation; eager dispatch is always valid
+            print("pleas: source-forward graph capture unavailable (%s); running eagerly" % (exc,))
+            self.graph_sources = False
+            self._graphs = [None, None]
+            self.tap1.take()
+            self.tap2.take()
+            return None
+
+    @torch.no_grad()
+    def launch_group(self, run: List[torch.Tensor], after_current: bool = True) -> None:
+        """One source forward for several batches; their generations (views of its taps) join the queue."""
+        first = self._side_streams[0] if (self._side_streams is not None and not after_current) else None
+        with (torch.cuda.stream(first) if first is not None else contextlib.nullcontext()):
+            both = torch.cat([b.to(self.device, non_blocking=True) for b in run], 0)
+            xdev, (in1, out1), (in2, out2), events = self.launch(both, parts=len(run), after_current=after_current)
+        n = xdev.shape[0] // len(run)
+        for i, b in enumerate(run):
+            lo, hi = i * n, (i + 1) * n
+            cut = lambda d, lo=lo, hi=hi: {k: v[lo:hi] for k, v in d.items()}
+            self.queue.append((b, xdev, (cut(in1), cut(out1)), (cut(in2), cut(out2)), events))
+
+    @torch.no_grad()
+    def prefetch(self, batches, group: Optional[int] = None, max_groups: int = 1, memory_fraction: float = 0.5) -> int:
+        """Enqueue the source forwards of the first batches NOW, on the side streams only -- not ordered after the work
+        already queued on the current stream, which is the point: called from ``activation_matching(while_solving=...)``
+        they run beside the LAP kernel (one workgroup per problem, 71 of 256 CUs, 0.28 s).  ``batches`` must be tensors
+        whose values are already in place (resident inputs, or host tensors); ``PleasFitter.steps`` must later be given
+        the same tensor objects first, in the same order.  Takes whole groups of ``group`` (default ``2 * world``) equal
+        batches, at most ``max_groups`` of them and as long as less than ``memory_fraction`` of the free HBM is used
+        (measured from the first group).  Returns the number of batches taken."""
+        if self._side_streams is None or self.graph_sources:
+            return 0
+        group = max(1, int(group or 2 * self.world))
+        batches = list(batches)
+        free0 = torch.cuda.mem_get_info(self.device)[0]
+        budget, per_group, taken = free0 * memory_fraction, None, 0
+        for g in range(max_groups):
+            run = batches[g * group:(g + 1) * group]
+            if len(run) < group or any(not torch.is_tensor(b) or b.shape != run[0].shape or b.shape[0] == 0 for b in run):
+                break
+            if per_group is not None and (g + 1) * per_group > budget:
+                break
+            if group > 1:
+                self.launch_group(run, after_current=False)
+            else:
+                self.queue.append((run[0],) + self.launch(run[0], after_current=False))
+            taken += group
+            if per_group is None:
+                per_group = max(free0 - torch.cuda.mem_get_info(self.device)[0], 1)
+        return taken
+
+    def run_eager(self, x: torch.Tensor, after_current: bool = True) -> None:
+        """Both source forwards, dispatched op by op; the hooks fill ``tap1`` / ``tap2`` (callers that read them right
+        away must synchronise: the models run on side streams).  ``after_current=False``: the side streams are not
+        ordered after the current stream's queue (``prefetch``); model2's stream then follows model1's up to here, which
+        is where the batch was put together."""
+        side = self._side_streams
+        if side is None:
+            with self.ops.pin_stream():
+                self.src1(x)
+                self.src2(x)
+            return
+        main = torch.cuda.current_stream(self.device)
+        # The sources' tensors live in the side streams' allocator pools.  They are consumed on `main` (by the update
+        # that owns this generation) and released by the host once that update is enqueued; a side stream re-uses them
+        # only after a LATER wait_stream(main), i.e. after every consumer enqueued on `main` up to then -- with one
+        # batch of look-ahead that is the update two generations back.  No record_stream bookkeeping needed.
+        events = []
+        for stream, model in zip(side, (self.src1, self.src2)):
+            if after_current:
+                stream.wait_stream(main)
+            elif stream is not side[0]:
+                stream.wait_stream(side[0])
+            with torch.cuda.stream(stream), self.ops.pin_stream():
+                model(x)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            events.append(ev)
+        self._src_events = events
+
+    def close(self) -> None:
+        self.tap1.remove()
+        self.tap2.remove()
+        self.queue.clear()
+
+
 class PleasFitter:
     """State of one PLeaS run: flat arenas + per-layer plans.  ``train`` drives it; the bench
     uses it directly to time single steps."""
@@ -215,46 +411,23 @@ class PleasFitter:
     def __init__(self, model1, model2, model3, spec, perm, costs, budget_ratios, max_steps: int, lr: float = 5e-4,
                  separate_classifier=False, num_classes=1000, model_type="rn50", data_parallel: bool = False,
                  forward: str = "hip", graph_sources: bool = False, fuse_sources: bool = True,
-                 overlap_sources: bool = True, fused_sources=None):
+                 overlap_sources: bool = True, fused_sources=None, sources: Optional[FrozenSources] = None):
         from .. import hip_ops
-        from .activation_matching import _dist_info
 
         self.ops = hip_ops
         # data parallel: every update splits the batch's samples over the ranks, gradients (one flat
         # arena) are summed with ONE all-reduce, so all ranks apply the same full-batch update
-        self.rank, self.world = _dist_info() if data_parallel else (0, 1)
+        self.sources = sources if sources is not None else FrozenSources(
+            model1, model2, data_parallel=data_parallel, fuse=fuse_sources, overlap=overlap_sources, graph=graph_sources,
+            fused=fused_sources)
+        self.rank, self.world, self.device = self.sources.rank, self.sources.world, self.sources.device
         self.model1, self.model2, self.model3 = model1, model2, model3
-        self.device = next(iter(model1.parameters())).device
-        if self.device.type != "cuda":
-            raise hip_ops.PleasHipError("pleas_merging.train: source models must be on the GPU (got %s)" % self.device)
         blocks = get_blocks(spec, perm, costs, budget_ratios, False)
         self.perm_blocks = spread_blocks(spec, blocks)
-        self.tap1, self.tap2 = ActivationTap(model1), ActivationTap(model2)
-        model1.eval()
-        model2.eval()
-        # the frozen sources run with BatchNorm (+ residual add) + ReLU folded into one HIP pass; the hooked
-        # Conv2d / Linear modules are shared, so the taps see the same tensors (source_forward.py)
-        self.src1, self.src2 = model1, model2
-        if fused_sources is not None:       # built ahead of time (prepare_sources), e.g. while the LAP kernel ran
-            self.src1, self.src2 = fused_sources
-        elif fuse_sources:
-            self.src1, self.src2 = prepare_sources(model1, model2)
-
-        # the two source forwards are independent chains of small kernels (one conv of a batch-16 ResNet fills a
-        # fraction of 256 CUs): the two models run on two side streams, joined before the taps are read
-        # Each source gets its own stream: their dependency chains of small kernels then also run NEXT TO the big grouped
-        # kernels of the previous update (step(x, next_x=...) enqueues the sources of the next batch before this update's
-        # own launches).  Equal priorities: favouring either side was slower (chain first 8.7 s, update first 11.5 s).
-        self._side_streams = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)) if overlap_sources else None
-        # The update's own launches go to a dedicated stream as well, not to the caller's: measured on the 401-update job,
+        # The update's own launches go to a dedicated stream, not to the caller's: measured on the 401-update job,
         # work on torch's default (null) stream overlaps the side streams markedly worse than work on a created stream
         # (8.24 s vs 7.73 s for the whole job).  step() orders that stream after the caller's and the caller's after it.
-        self._upd_stream = torch.cuda.Stream(self.device) if overlap_sources else None
-        self._src_events = None
-        self._slice_batch = True   # data parallel: every update splits its batch's samples over the ranks
-        # generations whose source forwards are enqueued, in update order:
-        # (batch as passed, its device copy, taps of model1, taps of model2, events)
-        self._queue: collections.deque = collections.deque()
+        self._upd_stream = torch.cuda.Stream(self.device) if self.sources._side_streams is not None else None
         self._cur_x = None
         self.t1_in = self.t1_out = self.t2_in = self.t2_out = None   # taps of the update being applied
 
@@ -328,17 +501,30 @@ class PleasFitter:
         self.merge = hip_ops.MergeBatch(dev)
         self._fwd_loss = None
         self._fwd_index = None
-        # graph_sources=True: from the second batch of a shape on, the two source forwards (~420 launches, ~35 us of host
-        # time per vendor convolution) are replayed from hipGraphs instead of being dispatched op by op: TWO graphs with
-        # their own static input and taps take turns, so that the sources of the next batch can be replayed while the
-        # update of the current one still reads the other generation.  Inside a graph the two models sit on parallel
-        # branches (captured from the two side streams).  Capture costs ~0.05 s per graph; a capture problem falls back
-        # to eager dispatch for the rest of the run.
-        self.graph_sources = graph_sources
-        self._graphs = [None, None]     # per generation: dict(graph, x, taps1, taps2, shape)
-        self._graph_turn = 0
-        self._graph_seen: Dict[tuple, int] = {}
-        self._graph_stream = torch.cuda.Stream(self.device, priority=-1) if graph_sources else None
+
+    # the source side lives in `self.sources`; these names are what the loop (and the tests) use
+    tap1 = property(lambda self: self.sources.tap1)
+    tap2 = property(lambda self: self.sources.tap2)
+    src1 = property(lambda self: self.sources.src1)
+    src2 = property(lambda self: self.sources.src2)
+    _queue = property(lambda self: self.sources.queue)
+    _side_streams = property(lambda self: self.sources._side_streams)
+    _graphs = property(lambda self: self.sources._graphs)
+    graph_sources = property(lambda self: self.sources.graph_sources)
+
+    @property
+    def _slice_batch(self):
+        return self.sources._slice_batch
+
+    @_slice_batch.setter
+    def _slice_batch(self, value):
+        self.sources._slice_batch = bool(value)
+
+    def _launch_sources(self, x: torch.Tensor, parts: int = 1):
+        return self.sources.launch(x, parts)
+
+    def _run_sources(self, x: torch.Tensor) -> None:
+        self.sources.run_eager(x)
 
     # -- one layer: merged input; queue forward(+target+residual+loss) and weight gradient for the grouped launches
     def _fit_layer(self, idx: int, plan: _LayerPlan) -> None:
@@ -396,75 +582,6 @@ class PleasFitter:
                 torch.mm(resid.reshape(-1, resid.shape[-1]).t(), ip.reshape(-1, ip.shape[-1]), out=plan.gw)
         for resid, plan in self._bias_grads:
             plan.gb.copy_(resid.sum((0, 2, 3)) if plan.is_conv else resid.reshape(-1, resid.shape[-1]).sum(0))
-
-    def _launch_sources(self, x: torch.Tensor, parts: int = 1):
-        """Enqueue both source forwards for ``x``; returns the generation (device batch, taps, events) the update will
-        consume.  ``parts`` > 1: ``x`` is that many batches back to back, each of which is sample-sliced on its own."""
-        x = x.to(self.device, non_blocking=True)
-        if self._slice_batch:
-            if parts > 1 and self.world > 1:
-                h = x.shape[0] // parts
-                x = torch.cat([dp_slice(x[i * h:(i + 1) * h], self.rank, self.world) for i in range(parts)], 0)
-            else:
-                x = dp_slice(x, self.rank, self.world)
-        if self.graph_sources:
-            gen = self._launch_graph(x)
-            if gen is not None:
-                return gen
-        self._run_sources_eager(x)
-        events = self._src_events
-        self._src_events = None
-        return (x, self.tap1.take(), self.tap2.take(), events)
-
-    def _capture_sources(self, x: torch.Tensor) -> dict:
-        self.tap1.take()
-        self.tap2.take()
-        x_static = x.clone()
-        graph = torch.cuda.CUDAGraph()
-        torch.cuda.current_stream(self.device).synchronize()
-        # thread_local: other threads (e.g. the collective watchdog of torch.distributed) may keep calling the runtime
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            cap = torch.cuda.current_stream(self.device)
-            side = self._side_streams or (cap, cap)
-            for stream, model in zip(side, (self.src1, self.src2)):
-                if stream is not cap:
-                    stream.wait_stream(cap)
-                with torch.cuda.stream(stream), self.ops.pin_stream():
-                    model(x_static)
-            for stream in side:
-                if stream is not cap:
-                    cap.wait_stream(stream)
-        return {"graph": graph, "x": x_static, "taps1": self.tap1.take(), "taps2": self.tap2.take(),
-                "shape": tuple(x.shape)}
-
-    def _launch_graph(self, x: torch.Tensor):
-        """Replay (capturing first if needed) this generation's source graph on the graph stream; None = run eagerly."""
-        key = tuple(x.shape)
-        seen = self._graph_seen[key] = self._graph_seen.get(key, 0) + 1
-        if seen <= 1:                    # the first batch of a shape runs eagerly: vendor plans, allocator
-            return None
-        slot = self._graph_turn = (self._graph_turn + 1) % 2
-        main, gs = torch.cuda.current_stream(self.device), self._graph_stream
-        try:
-            # everything below is ordered after the work already enqueued on `main`: in particular after the update that
-            # last read this generation's static taps (two updates back with one batch of look-ahead)
-            gs.wait_stream(main)
-            with torch.cuda.stream(gs):
-                g = self._graphs[slot]
-                if g is None or g["shape"] != key:
-                    g = self._graphs[slot] = self._capture_sources(x)
-                g["x"].copy_(x, non_blocking=True)
-                g["graph"].replay()
-                ev = torch.cuda.Event()
-                ev.record(gs)
-            return (x, g["taps1"], g["taps2"], [ev])
-        except Exception as exc:  # noqa: BLE001 -- capture is an optimisation; eager dispatch is always valid
-            print("pleas: source-forward graph capture unavailable (%s); running eagerly" % (exc,))
-            self.graph_sources = False
-            self._graphs = [None, None]
-            self.tap1.take()
-            self.tap2.take()
-            return None
 
     def _begin_update(self, x: torch.Tensor, next_x: Optional[torch.Tensor]) -> None:
         """Taps of ``x`` become current (running its sources now unless they were prefetched); the sources of
@@ -532,6 +649,9 @@ class PleasFitter:
         keep = group if lookahead else 0      # sources are launched whenever no more than `keep` generations are queued
         with self._session():
             it = iter(batches)
+            for gen in list(self._queue):         # forwards enqueued beforehand (FrozenSources.prefetch): same batches first
+                if next(it, None) is not gen[0]:
+                    raise RuntimeError("PleasFitter.steps: the prefetched batches must be the first ones, in order")
             ahead: List[torch.Tensor] = []        # fetched from `it`, sources not launched yet
             exhausted = False
             idx = 0
@@ -552,7 +672,7 @@ class PleasFitter:
                         else:
                             break
                     if group > 1 and len(run) == group:
-                        self._launch_group(run)      # one generation per batch of the run
+                        self.sources.launch_group(run)      # one generation per batch of the run
                         del ahead[:group]
                     else:
                         b = ahead.pop(0)
@@ -562,19 +682,6 @@ class PleasFitter:
                 self.step(self._queue[0][0])
                 yield idx
                 idx += 1
-
-    @torch.no_grad()
-    def _launch_group(self, run: List[torch.Tensor]) -> None:
-        """One source forward for several batches; their generations (views of its taps) join the queue."""
-        both = torch.cat([b.to(self.device, non_blocking=True) for b in run], 0)
-        xdev, (in1, out1), (in2, out2), events = self._launch_sources(both, parts=len(run))
-        n = xdev.shape[0] // len(run)
-        gens = []
-        for i, b in enumerate(run):
-            lo, hi = i * n, (i + 1) * n
-            cut = lambda d, lo=lo, hi=hi: {k: v[lo:hi] for k, v in d.items()}
-            gens.append((b, xdev, (cut(in1), cut(out1)), (cut(in2), cut(out2)), events))
-        self._queue.extend(gens)
 
     @torch.no_grad()
     def step(self, x: torch.Tensor, next_x: Optional[torch.Tensor] = None) -> None:
@@ -613,33 +720,6 @@ class PleasFitter:
         self.ops.masked_adam(self.p, self.g, self.mask, self.m, self.v, lr, self.step_count)
         self._end_update()
 
-    def _run_sources(self, x: torch.Tensor) -> None:
-        """Both source forwards, dispatched op by op; the hooks fill ``tap1`` / ``tap2`` (callers that read them right
-        away must synchronise: the models run on side streams)."""
-        self._run_sources_eager(x)
-
-    def _run_sources_eager(self, x: torch.Tensor) -> None:
-        side = self._side_streams
-        if side is None:
-            with self.ops.pin_stream():
-                self.src1(x)
-                self.src2(x)
-            return
-        main = torch.cuda.current_stream(self.device)
-        # The sources' tensors live in the side streams' allocator pools.  They are consumed on `main` (by the update
-        # that owns this generation) and released by the host once that update is enqueued; a side stream re-uses them
-        # only after a LATER wait_stream(main), i.e. after every consumer enqueued on `main` up to then -- with one
-        # batch of look-ahead that is the update two generations back.  No record_stream bookkeeping needed.
-        events = []
-        for stream, model in zip(side, (self.src1, self.src2)):
-            stream.wait_stream(main)
-            with torch.cuda.stream(stream), self.ops.pin_stream():
-                model(x)
-            ev = torch.cuda.Event()
-            ev.record(stream)
-            events.append(ev)
-        self._src_events = events
-
     def finish(self) -> nn.Module:
         """Write the fitted weights back into ``model3`` and drop the hooks (reference :392-403)."""
         sd = self.model3.state_dict()
@@ -648,8 +728,7 @@ class PleasFitter:
             if plan.b is not None:
                 sd["%s.bias" % plan.name] = plan.b.detach().clone()
         self.model3.load_state_dict(sd)
-        self.tap1.remove()
-        self.tap2.remove()
+        self.sources.close()
         return self.model3
 
 

@@ -517,7 +517,7 @@ def test_paired_source_forwards_equal_one_forward_per_batch(tiny_bottleneck):
     """steps() runs the frozen sources once per GROUP of batches (one forward of the concatenated batch, the updates read
     their slices of its taps): same updates in the same order as one forward per batch, also with ragged tails."""
     from pleas.methods.partial_matching import partial_merge
-    from pleas.methods.pleas_merging import PleasFitter
+    from pleas.methods.pleas_merging import FrozenSources, PleasFitter
 
     t = tiny_bottleneck
     m1, m2 = _cuda_pair(t)
@@ -526,9 +526,18 @@ def test_paired_source_forwards_equal_one_forward_per_batch(tiny_bottleneck):
     costs = {k: v.cuda() for k, v in t.per_key("am_cost").items()}
     outs = []
     for kw in ({"pair_sources": False}, {}, {"sources_per_forward": 4}, {"sources_per_forward": 3},   # default: pairs
-               {"lookahead": True}, {"sources_per_forward": 3, "lookahead": True}):   # next group enqueued beforehand
+               {"lookahead": True}, {"sources_per_forward": 3, "lookahead": True},    # next group enqueued beforehand
+               {"prefetch": 2}, {"prefetch": 1, "sources_per_forward": 3, "lookahead": True},
+               {"prefetch": 3, "sources_per_forward": 1}):
         m3 = partial_merge(t.spec, m1, m2, perm, costs, 0.5)
-        fit = PleasFitter(m1, m2, m3, t.spec, perm, costs, 0.5, len(xs) - 1, num_classes=10)
+        kw = dict(kw)
+        prefetch = kw.pop("prefetch", 0)
+        sources = None
+        if prefetch:      # the first groups' forwards are enqueued before the fitter exists (as during the LAP kernel)
+            sources = FrozenSources(m1, m2)
+            assert sources.prefetch(xs, group=kw.get("sources_per_forward"), max_groups=prefetch) == \
+                prefetch * kw.get("sources_per_forward", 2)
+        fit = PleasFitter(m1, m2, m3, t.spec, perm, costs, 0.5, len(xs) - 1, num_classes=10, sources=sources)
         assert list(fit.steps(xs, **kw)) == list(range(len(xs)))
         assert fit.step_count == len(xs) and not fit._queue
         outs.append({k: v.clone() for k, v in fit.finish().state_dict().items()})
