@@ -402,14 +402,18 @@ class MergeBatch:
         self._fresh = 1
 
     def add(self, w1: torch.Tensor, w2: torch.Tensor, row_axis: int, row1: torch.Tensor, row2: torch.Tensor,
-            n_merged_rows: int) -> torch.Tensor:
+            n_merged_rows: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if w1.shape != w2.shape or not w1.is_cuda or w1.dtype != torch.float32 or w2.dtype != torch.float32:
             raise PleasHipError("MergeBatch.add: fp32 CUDA sources of equal shape expected")
         w1, w2 = w1.contiguous(), w2.contiguous()
         shape = list(w1.shape)
         row_axis = row_axis % w1.dim()
         rows_out = int(row1.numel())
-        out = torch.empty(shape[:row_axis] + [rows_out] + shape[row_axis + 1:], dtype=torch.float32, device=w1.device)
+        want = shape[:row_axis] + [rows_out] + shape[row_axis + 1:]
+        if out is None:
+            out = torch.empty(want, dtype=torch.float32, device=w1.device)
+        elif list(out.shape) != want or out.dtype != torch.float32 or not out.is_contiguous() or out.device != w1.device:
+            raise PleasHipError("MergeBatch.add: out must be a contiguous fp32 tensor of shape %s" % (want,))
         self._keep.append((w1, w2, out, row1, row2))
         self._geo.append((math.prod(shape[:row_axis]), math.prod(shape[row_axis + 1:]), rows_out, shape[row_axis],
                           int(n_merged_rows)))
@@ -441,6 +445,22 @@ class MergeBatch:
         check(rc, "pleas_merge_batch")
         self._keep.clear()
         self._geo.clear()
+
+
+
+    def table(self):
+        """numpy view of the item table of the latest ``flush`` (shares its memory): pointer fields may be rewritten before
+        ``relaunch`` -- the per-update fast path of ``PleasFitter``, which keeps every other field as it is."""
+        import numpy as np
+
+        return None if self._arr is None else np.frombuffer(self._arr, dtype=np.dtype(type(self._arr[0])))
+
+    def relaunch(self) -> None:
+        """The launch of the latest ``flush`` again, with the table as it is now."""
+        if self._keep or self._arr is None or self._ws is None:
+            raise PleasHipError("MergeBatch.relaunch: nothing flushed yet, or tensors pending")
+        check(_lib.lib().pleas_merge_batch(self._arr, len(self._arr), self._ws.data_ptr(), self._ws.numel(), 0, _stream()),
+              "pleas_merge_batch")
 
 
 class FwdBatch:
@@ -501,6 +521,22 @@ class FwdBatch:
         self._geo.clear()
 
 
+
+    def table(self):
+        """numpy view of the item table of the latest ``flush`` (shares its memory): pointer fields may be rewritten before
+        ``relaunch`` -- the per-update fast path of ``PleasFitter``, which keeps every other field as it is."""
+        import numpy as np
+
+        return None if self._arr is None else np.frombuffer(self._arr, dtype=np.dtype(type(self._arr[0])))
+
+    def relaunch(self, loss: torch.Tensor) -> None:
+        """The launch of the latest ``flush`` again, with the table as it is now."""
+        if self._keep or self._arr is None or self._ws is None or loss.numel() != len(self._arr):
+            raise PleasHipError("FwdBatch.relaunch: nothing flushed yet, tensors pending, or loss of another length")
+        check(_lib.lib().pleas_fwd_batch(self._arr, len(self._arr), loss.data_ptr(), self._ws.data_ptr(), self._ws.numel(), 0,
+                                         _stream()), "pleas_fwd_batch")
+
+
 class WgradBatch:
     """Weight gradients of all merged layers of one update in ONE grouped launch (``pleas_wgrad_batch``).
     ``add`` per layer (operands must stay unmodified until ``flush``), ``flush`` once per update."""
@@ -549,6 +585,22 @@ class WgradBatch:
         check(rc, "pleas_wgrad_batch")
         self._keep.clear()
         self._geo.clear()
+
+
+
+    def table(self):
+        """numpy view of the item table of the latest ``flush`` (shares its memory): pointer fields may be rewritten before
+        ``relaunch`` -- the per-update fast path of ``PleasFitter``, which keeps every other field as it is."""
+        import numpy as np
+
+        return None if self._arr is None else np.frombuffer(self._arr, dtype=np.dtype(type(self._arr[0])))
+
+    def relaunch(self) -> None:
+        """The launch of the latest ``flush`` again, with the table as it is now."""
+        if self._keep or self._arr is None or self._ws is None:
+            raise PleasHipError("WgradBatch.relaunch: nothing flushed yet, or tensors pending")
+        check(_lib.lib().pleas_wgrad_batch(self._arr, len(self._arr), self._ws.data_ptr(), self._ws.numel(), 0, _stream()),
+              "pleas_wgrad_batch")
 
 
 class NormalEqBatch:

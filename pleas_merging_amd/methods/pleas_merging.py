@@ -89,6 +89,61 @@ def prepare_sources(model1: nn.Module, model2: nn.Module):
     return fuse_bn_act(model1) or model1, fuse_bn_act(model2) or model2
 
 
+class TapDict(dict):
+    """name -> tensor of one forward.  ``packs`` caches, per list of names, the device addresses and per-sample strides of
+    those tensors (``tap_pointers``)."""
+
+    __slots__ = ("packs",)
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.packs = {}
+
+
+class _TapView:
+    """The taps of ONE update inside a grouped source forward: samples ``lo:hi`` of every tensor of ``base``, sliced on
+    access (an update touches ~420 of them; slicing all of them ahead of time was 0.6 ms of host time per update)."""
+
+    __slots__ = ("base", "lo", "hi")
+
+    def __init__(self, base: TapDict, lo: int, hi: int):
+        self.base, self.lo, self.hi = base, lo, hi
+
+    def __getitem__(self, name):
+        return self.base[name][self.lo:self.hi]
+
+    def __contains__(self, name):
+        return name in self.base
+
+    def __len__(self):
+        return len(self.base)
+
+    def keys(self):
+        return self.base.keys()
+
+    def items(self):
+        return ((k, v[self.lo:self.hi]) for k, v in self.base.items())
+
+
+def tap_pointers(taps, names: tuple):
+    """Device addresses (numpy uint64) of ``taps[name]`` for ``name`` in ``names`` -- of the update's first sample when
+    ``taps`` is a view into a grouped forward.  The per-forward part is computed once per (forward, names)."""
+    import numpy as np
+
+    base, lo = (taps.base, taps.lo) if isinstance(taps, _TapView) else (taps, 0)
+    packs = getattr(base, "packs", None)
+    hit = packs.get(id(names)) if packs is not None else None
+    if hit is None or hit[0] is not names:
+        ts = [base[k] for k in names]
+        if not all(t.is_contiguous() and t.dtype == torch.float32 for t in ts):
+            return None
+        hit = (names, np.array([t.data_ptr() for t in ts], dtype=np.uint64),
+               np.array([t.stride(0) * 4 if t.dim() > 0 else 0 for t in ts], dtype=np.uint64))
+        if packs is not None:
+            packs[id(names)] = hit
+    return hit[1] + np.uint64(lo) * hit[2] if lo else hit[1]
+
+
 class ActivationTap:
     """Forward hooks on every Conv2d / Linear / LayerNorm of a model that keep the module's
     input and output of the latest forward (reference keeps inputs only, :197-231)."""
@@ -96,8 +151,8 @@ class ActivationTap:
     KINDS = (nn.Conv2d, nn.Linear, nn.LayerNorm)
 
     def __init__(self, model: nn.Module):
-        self.inputs: Dict[str, torch.Tensor] = {}
-        self.outputs: Dict[str, torch.Tensor] = {}
+        self.inputs: Dict[str, torch.Tensor] = TapDict()
+        self.outputs: Dict[str, torch.Tensor] = TapDict()
         self.handles = []
         for name, mod in model.named_modules():
             if isinstance(mod, self.KINDS):
@@ -121,7 +176,7 @@ class ActivationTap:
         """Hand over the tensors of the latest forward and start a new generation (the hooks look the dicts up on
         every call, so the next forward fills the fresh ones)."""
         got = (self.inputs, self.outputs)
-        self.inputs, self.outputs = {}, {}
+        self.inputs, self.outputs = TapDict(), TapDict()
         return got
 
     def remove(self):
@@ -336,8 +391,8 @@ class FrozenSources:
         n = xdev.shape[0] // len(run)
         for i, b in enumerate(run):
             lo, hi = i * n, (i + 1) * n
-            cut = lambda d, lo=lo, hi=hi: {k: v[lo:hi] for k, v in d.items()}
-            self.queue.append((b, xdev, (cut(in1), cut(out1)), (cut(in2), cut(out2)), events))
+            self.queue.append((b, xdev, (_TapView(in1, lo, hi), _TapView(out1, lo, hi)),
+                               (_TapView(in2, lo, hi), _TapView(out2, lo, hi)), events))
 
     @torch.no_grad()
     def prefetch(self, batches, group: Optional[int] = None, max_groups: int = 1, memory_fraction: float = 0.5) -> int:
@@ -430,6 +485,13 @@ class PleasFitter:
         self._upd_stream = torch.cuda.Stream(self.device) if self.sources._side_streams is not None else None
         self._cur_x = None
         self.t1_in = self.t1_out = self.t2_in = self.t2_out = None   # taps of the update being applied
+        # Per input shape: the merged inputs and residuals of every layer live in buffers that are kept between updates
+        # (written and read on the update stream only), so the item tables of the three grouped launches change between
+        # two updates of that shape in the tap addresses alone -- see _step.
+        self._buffers: Dict[tuple, Dict[int, Tuple[torch.Tensor, torch.Tensor]]] = {}
+        self._bufs: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self._replay = None      # (shape key, names, merge table, forward table, vendor / bias work) of the latest full update
+        self.fast_updates = 0    # updates applied by patching the tables (the rest took the layer-by-layer path)
 
         layers = {n: m for n, m in model3.named_modules() if isinstance(m, (nn.Conv2d, nn.Linear))}
         self.layer_modules = layers
@@ -543,9 +605,14 @@ class PleasFitter:
         hip_forward = self.forward == "hip" and (square or linear)
         # merged input: queued for the ONE grouped merge launch that precedes the grouped forward (merge.flush); the
         # vendor-forward path consumes it right here and takes the single-tensor launch
-        ip = self.merge.add(ip1, ip2, 1, *plan.in_maps) if hip_forward else ops.merge_blocks(ip1, ip2, 1, *plan.in_maps)
+        kept = self._bufs.get(idx) if hip_forward else None
+        ip = self.merge.add(ip1, ip2, 1, *plan.in_maps, out=kept[0] if kept else None) if hip_forward \
+            else ops.merge_blocks(ip1, ip2, 1, *plan.in_maps)
         if hip_forward:
-            resid = torch.empty((ip.shape[0], cout) + tuple(o1.shape[2:]), dtype=torch.float32, device=ip.device)
+            resid = kept[1] if kept else torch.empty((ip.shape[0], cout) + tuple(o1.shape[2:]), dtype=torch.float32,
+                                                     device=ip.device)
+            if kept is None:
+                self._bufs[idx] = (ip, resid)
             n = resid.numel() * self.world           # the mean runs over the full (global) batch
             self.fwd.add(ip, plan.w, plan.b, o1, o2, r1, r2, nm, resid, 2.0 / n, 1.0 / n, *geo,
                          flags=ops.FwdBatch.KPOS_MAJOR if plan.kpos else 0)
@@ -691,28 +758,71 @@ class PleasFitter:
         with self._session():
             self._step(x, next_x)
 
+    def _update_key(self) -> tuple:
+        first = self.plans[0].name
+        if first not in self.t1_in:
+            return ()
+        taps = self.t1_in
+        n = (taps.hi - taps.lo) if isinstance(taps, _TapView) else taps[first].shape[0]
+        return (n,) + tuple(self._cur_x.shape[1:])
+
     def _step(self, x: torch.Tensor, next_x: Optional[torch.Tensor]) -> None:
+        """One update.  The first update of an input shape goes layer by layer (_fit_layer: checks, buffers, item tables of
+        the three grouped launches).  Every further update of that shape differs from it in the addresses of the source
+        taps alone, so it rewrites those four pointer columns (numpy, from one address table per source forward) and
+        launches again: ~2.3 ms -> ~0.5 ms of host time per update, which is what bounds a rank once its share of an update
+        is a few samples."""
         self._begin_update(x, next_x)
-        self._fwd_rows, self._vendor_wgrad, self._bias_grads = [], [], []
-        with self.ops.pin_stream():
-            for idx, plan in enumerate(self.plans):
-                if plan.name not in self.t1_in or plan.name not in self.t2_in:
-                    print("Key error on %s" % plan.name)
-                    continue
-                self._fit_layer(idx, plan)
-        self.merge.flush()   # ONE grouped launch: the merged inputs of every layer
-        if self._fwd_rows:   # ONE grouped MFMA launch: forward + target + residual + loss of every merged layer
-            if self._fwd_loss is None or self._fwd_loss.numel() != len(self._fwd_rows):
-                self._fwd_loss = torch.zeros(len(self._fwd_rows), dtype=torch.float32, device=self.device)
-                self._fwd_index = torch.tensor(self._fwd_rows, dtype=torch.long, device=self.device)
-            self.fwd.flush(self._fwd_loss)
+        key = self._update_key()
+        replay = self._replay if (self._replay is not None and key and self._replay[0] == key) else None
+        ptrs = None
+        if replay is not None:
+            names = replay[1]
+            ptrs = [tap_pointers(t, names) for t in (self.t1_in, self.t2_in, self.t1_out, self.t2_out)]
+            if any(p is None for p in ptrs):
+                replay = None
+        if replay is not None:
+            _, names, merge_tab, fwd_tab, self._vendor_wgrad, self._bias_grads = replay
+            merge_tab["w1"][:], merge_tab["w2"][:], fwd_tab["o1"][:], fwd_tab["o2"][:] = ptrs
+            with self.ops.pin_stream():
+                self.merge.relaunch()
+                self.fwd.relaunch(self._fwd_loss)
+            self.fast_updates += 1
+        else:
+            self._replay = None
+            self._bufs = self._buffers.setdefault(key, {}) if key else {}
+            self._fwd_rows, self._vendor_wgrad, self._bias_grads = [], [], []
+            complete = bool(key)
+            with self.ops.pin_stream():
+                for idx, plan in enumerate(self.plans):
+                    if plan.name not in self.t1_in or plan.name not in self.t2_in:
+                        print("Key error on %s" % plan.name)
+                        complete = False
+                        continue
+                    self._fit_layer(idx, plan)
+            self.merge.flush()   # ONE grouped launch: the merged inputs of every layer
+            if self._fwd_rows:   # ONE grouped MFMA launch: forward + target + residual + loss of every merged layer
+                if self._fwd_loss is None or self._fwd_loss.numel() != len(self._fwd_rows):
+                    self._fwd_loss = torch.zeros(len(self._fwd_rows), dtype=torch.float32, device=self.device)
+                    self._fwd_index = torch.tensor(self._fwd_rows, dtype=torch.long, device=self.device)
+                self.fwd.flush(self._fwd_loss)
         vendor_rows = len(self._fwd_rows) < len(self.plans)
         if vendor_rows:
             self.ops.loss_final(self.loss_parts, self.loss_nparts, self.loss_scale, self.loss_now)
         if self._fwd_rows:
             self.loss_now.index_copy_(0, self._fwd_index, self._fwd_loss)
         self._finish_vendor_parts()
-        self.wgrad.flush()  # ONE grouped MFMA launch: weight gradients of every merged layer
+        if replay is not None:
+            with self.ops.pin_stream():
+                self.wgrad.relaunch()
+        else:
+            n_wgrad = len(self.wgrad._keep)
+            self.wgrad.flush()  # ONE grouped MFMA launch: weight gradients of every merged layer
+            if complete and not vendor_rows and n_wgrad > 0:
+                names = tuple(self.plans[i].name for i in self._fwd_rows)
+                merge_tab, fwd_tab = self.merge.table(), self.fwd.table()
+                if merge_tab is not None and fwd_tab is not None and len(merge_tab) == len(fwd_tab) == len(names):
+                    self._replay = (key, names, merge_tab, fwd_tab, self._vendor_wgrad, self._bias_grads)
         dp_sum_(self._g_ext, self.world)     # gradients + losses
         self.loss_sum.add_(self.loss_now)
         lr = self.lrs[min(self.step_count, len(self.lrs) - 1)]

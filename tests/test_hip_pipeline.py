@@ -549,6 +549,43 @@ def test_paired_source_forwards_equal_one_forward_per_batch(tiny_bottleneck):
                 assert _rel(outs[0][k], other[k]) < 1e-5, k
 
 
+def test_replayed_updates_equal_layer_by_layer_updates(tiny_bottleneck):
+    """From the second update of an input shape on, PleasFitter rewrites the tap addresses in the item tables of the
+    grouped launches and launches again.  Same fitted weights as when every update goes layer by layer -- one by one,
+    in groups, with a change of batch size in between (which falls back and records again)."""
+    from pleas.methods.partial_matching import partial_merge
+    from pleas.methods.pleas_merging import PleasFitter
+
+    t = tiny_bottleneck
+    m1, m2 = _cuda_pair(t)
+    xs = [x for x, _ in t.batches() + t.batches() + t.batches()][:10]
+    xs = xs[:5] + [xs[5][:2]] + xs[6:]            # update 5 has 2 samples instead of 4
+    perm = t.per_key("am_perm")
+    costs = {k: v.cuda() for k, v in t.per_key("am_cost").items()}
+    outs, fast = [], []
+    for mode in ("layers", "singles", "groups"):
+        m3 = partial_merge(t.spec, m1, m2, perm, costs, 0.5)
+        fit = PleasFitter(m1, m2, m3, t.spec, perm, costs, 0.5, len(xs) - 1, num_classes=10)
+        if mode == "layers":
+            for x in xs:
+                fit._replay = None                # never replay
+                fit.step(x)
+        elif mode == "singles":
+            for x in xs:
+                fit.step(x)
+        else:
+            assert list(fit.steps(xs, sources_per_forward=2)) == list(range(len(xs)))
+        fast.append(fit.fast_updates)
+        outs.append({k: v.clone() for k, v in fit.finish().state_dict().items()})
+    assert fast[0] == 0 and fast[1] == len(xs) - 3 and fast[2] == len(xs) - 3   # three shape changes: 4 -> 2 -> 4
+    for other in outs[1:]:
+        for k in outs[0]:
+            if k == DEGENERATE:
+                assert torch.allclose(outs[0][k], other[k], atol=2 * 5e-4 * len(xs))
+            elif outs[0][k].dtype.is_floating_point:
+                assert _rel(outs[0][k], other[k]) < 1e-5, k
+
+
 def test_config4_zip_budget_partial_merge_and_train_vs_oracle():
     """configs[4]-style partial merge at ResNet-18 scale: zip ratios (budget 1.55: stages 3-4 stay separate, which makes
     ODD merged widths 2n-1 = 511 / 1023), gradient masks with frozen blocks, two PLeaS updates.  HIP path vs CPU oracle."""
