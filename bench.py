@@ -68,6 +68,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--ratio", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--phase-log", action="store_true", help="debug: synchronise and log the duration of each job phase")
     ap.add_argument("--prefetch-groups", type=int, default=8,
                     help="groups of source forwards enqueued while the LAP kernel runs (0: none); also bounded by memory")
     ap.add_argument("--emulate-allreduce-us", type=float, default=0.0,
@@ -144,16 +145,38 @@ def run_job(spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, ratio, dp, 
         early["sources"] = src = FrozenSources(m1, m2, data_parallel=dp)
         src.prefetch(inputs, max_groups=prefetch_groups)
 
-    perm, costs = activation_matching(spec, m1, m2, match_loader, len(match_loader), output_costs=True,
-                                      while_solving=while_solving)
+    def logged(loader):        # --phase-log: time of every 10 matching batches (synchronising)
+        for i, item in enumerate(loader):
+            if i % 10 == 0:
+                phase("matching: batches up to %d" % i)
+            yield item
+
+    perm, costs = activation_matching(spec, m1, m2, logged(match_loader) if PHASE_LOG else match_loader, len(match_loader),
+                                      output_costs=True, while_solving=while_solving)
+    phase("matching (rest) + LAP")
     m3 = partial_merge(spec, m1, m2, perm, costs, ratio, device=next(m1.parameters()).device)   # stays on the GPU
     # Data parallel: each rank's share of an update is small (batch / world samples); the frozen sources therefore forward
     # 2 * world updates' samples at once (steps() default), which keeps their host dispatch off the per-update path.
     # (Replaying them from a hipGraph costs the host MORE than dispatching them: 9.6 ms per replay of ~600 nodes.)
     fit = PleasFitter(m1, m2, m3, spec, perm, costs, ratio, n_pleas_sched, data_parallel=dp, sources=early.get("sources"))
+    phase("partial merge + fitter set-up")
     for _ in fit.steps(inputs, lookahead=lookahead):
         pass
+    phase("%d updates" % len(inputs))
     return fit.finish(), perm, costs
+
+
+PHASE_LOG = False
+_phase_t = [0.0]
+
+
+def phase(name):
+    """--phase-log: synchronise and log the time since the previous phase boundary (perturbs the pipeline slightly)."""
+    if PHASE_LOG:
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        log("phase %-32s %.3f s" % (name, now - _phase_t[0]))
+        _phase_t[0] = now
 
 
 def time_normal_eq(spec, m1, m2, perm, costs, loader, ratio):
@@ -314,6 +337,9 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    global PHASE_LOG
+    PHASE_LOG = bool(args.phase_log)
+    _phase_t[0] = time.perf_counter()
     t0 = time.perf_counter()
     m3, perm, costs = run_job(spec, m1, m2, pool.loader(0, n_match), pool.loader(0, n_pleas), max(1, n_sched), args.ratio, dp,
                               None if args.lookahead < 0 else bool(args.lookahead), args.prefetch_groups)
@@ -322,7 +348,8 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     hip_ops.profile_enable(False)
-    log("timed region: %.3fs" % elapsed)
+    log("timed region: %.3fs  (HBM reserved by the caching allocator: peak %.1f GB)"
+        % (elapsed, torch.cuda.max_memory_reserved(device) / 1e9))
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -50,6 +50,22 @@ def _need_gpu(*tensors: torch.Tensor) -> None:
             raise PleasHipError("HIP path computes in fp32 (got %s)" % t.dtype)
 
 
+_ROLE_STREAMS = {}
+
+
+def role_stream(device: torch.device, role: str, priority: int = 0) -> torch.cuda.Stream:
+    """ONE HIP stream per (device, role) for the life of the process.  torch's caching allocator keeps freed blocks per
+    allocation stream, so a job that created fresh streams could not reuse anything an earlier job (or a warm-up) had
+    left behind: it went back to hipMalloc for its ~15 GB of taps per source forward, and the pools of the abandoned
+    streams stayed reserved until an out-of-memory retry released them."""
+    device = torch.device(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), role)
+    st = _ROLE_STREAMS.get(key)
+    if st is None:
+        st = _ROLE_STREAMS[key] = torch.cuda.Stream(device, priority=priority)
+    return st
+
+
 class Workspace:
     """Grow-only device scratch buffer, one per device; callers never see hidden allocations
     inside the C library."""

@@ -26,6 +26,7 @@ from torch import nn
 
 from ..core.solvers import hip_solve_lsa
 from ..core.utils import Axis, Permutation, PermutationSpec
+from .. import hip_ops
 from ..hip_ops import cross_features_cdist, cross_features_inner_product  # noqa: F401  (public plug-ins)
 
 _FUSED_EPILOGUE = {}  # callable -> epilogue id, filled below
@@ -75,7 +76,7 @@ class _SideStream:
     next ``fork`` (which waits for everything enqueued on the caller's stream) -- no record_stream needed."""
 
     def __init__(self, device: torch.device):
-        self.side = torch.cuda.Stream(device)
+        self.side = hip_ops.role_stream(device, "model2")
         self.main = None
 
         def fork(x):
@@ -476,7 +477,7 @@ def accumulate_costs_fused(spec: PermutationSpec, model1: nn.Module, model2: nn.
     # The batches run on a created stream, not on the caller's: work on torch's default (null) stream overlaps the side
     # stream of the split twin graph markedly worse than work on a created stream (see PleasFitter).
     caller = torch.cuda.current_stream(device)
-    work = torch.cuda.Stream(device) if sinks.streams is not None else caller
+    work = hip_ops.role_stream(device, "model1") if sinks.streams is not None else caller
     work.wait_stream(caller)
     with torch.inference_mode(), torch.cuda.stream(work):
         for x, _ in shard_batches(dataloader, num_batches, rank, world):
@@ -532,7 +533,7 @@ def solve_all(costs: Dict[Axis, torch.Tensor], lsa_solver: Callable, while_solvi
         else:
             # the kernel gets a stream of its own: what `while_solving` enqueues elsewhere (source forwards on side
             # streams) then runs beside it also when the caller is on torch's default stream
-            caller, solver = torch.cuda.current_stream(dev), torch.cuda.Stream(dev)
+            caller, solver = torch.cuda.current_stream(dev), hip_ops.role_stream(dev, "lap")
             solver.wait_stream(caller)
             with torch.cuda.stream(solver):
                 outs = hip_ops.solve_lsa_batched(mats, maximize=True)

@@ -295,7 +295,8 @@ class FrozenSources:
         # fraction of 256 CUs).  Each source gets its own stream: their chains then also run NEXT TO the big grouped
         # kernels of an update when they are enqueued ahead of it.  Equal priorities: favouring either side was slower
         # (chain first 8.7 s, update first 11.5 s).
-        self._side_streams = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)) if overlap else None
+        self._side_streams = (hip_ops.role_stream(self.device, "model1"),
+                              hip_ops.role_stream(self.device, "model2")) if overlap else None
         self._src_events = None
         self._slice_batch = True   # data parallel: every update splits its batch's samples over the ranks
         self.queue: collections.deque = collections.deque()
@@ -310,7 +311,7 @@ class FrozenSources:
         self._graphs = [None, None]     # per generation: dict(graph, x, taps1, taps2, shape)
         self._graph_turn = 0
         self._graph_seen: Dict[tuple, int] = {}
-        self._graph_stream = torch.cuda.Stream(self.device, priority=-1) if graph else None
+        self._graph_stream = hip_ops.role_stream(self.device, "sources.graph", priority=-1) if graph else None
 
     def launch(self, x: torch.Tensor, parts: int = 1, after_current: bool = True):
         """Enqueue both source forwards for ``x``; returns the generation (device batch, taps, events) the update will
@@ -482,7 +483,7 @@ class PleasFitter:
         # The update's own launches go to a dedicated stream, not to the caller's: measured on the 401-update job,
         # work on torch's default (null) stream overlaps the side streams markedly worse than work on a created stream
         # (8.24 s vs 7.73 s for the whole job).  step() orders that stream after the caller's and the caller's after it.
-        self._upd_stream = torch.cuda.Stream(self.device) if self.sources._side_streams is not None else None
+        self._upd_stream = hip_ops.role_stream(self.device, "updates") if self.sources._side_streams is not None else None
         self._cur_x = None
         self.t1_in = self.t1_out = self.t2_in = self.t2_out = None   # taps of the update being applied
         # Per input shape: the merged inputs and residuals of every layer live in buffers that are kept between updates
