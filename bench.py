@@ -69,7 +69,7 @@ def parse():
     ap.add_argument("--ratio", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--phase-log", action="store_true", help="debug: synchronise and log the duration of each job phase")
-    ap.add_argument("--prefetch-groups", type=int, default=8,
+    ap.add_argument("--prefetch-groups", type=int, default=16,
                     help="groups of source forwards enqueued while the LAP kernel runs (0: none); also bounded by memory")
     ap.add_argument("--emulate-allreduce-us", type=float, default=0.0,
                     help="with --emulate-world: hold the update stream this long where the gradient all-reduce would run")
@@ -129,7 +129,7 @@ def build_models(arch, device, batch):
     return models
 
 
-def run_job(spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, ratio, dp, lookahead=None, prefetch_groups=8):
+def run_job(spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, ratio, dp, lookahead=None, prefetch_groups=16):
     """The timed hot path.  Returns (merged model, perm, costs)."""
     from pleas_merging_amd.methods.activation_matching import activation_matching
     from pleas_merging_amd.methods.partial_matching import partial_merge
