@@ -71,6 +71,7 @@ def parse():
     ap.add_argument("--phase-log", action="store_true", help="debug: synchronise and log the duration of each job phase")
     ap.add_argument("--prefetch-groups", type=int, default=16,
                     help="groups of source forwards enqueued while the LAP kernel runs (0: none); also bounded by memory")
+    ap.add_argument("--prefetch-memory", type=float, default=0.5, help="share of the free HBM the prefetched taps may take")
     ap.add_argument("--emulate-allreduce-us", type=float, default=0.0,
                     help="with --emulate-world: hold the update stream this long where the gradient all-reduce would run")
     ap.add_argument("--lookahead", type=int, default=-1, help="1: the next group's source forwards are enqueued before the "
@@ -143,7 +144,7 @@ def run_job(spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, ratio, dp, 
 
     def while_solving():
         early["sources"] = src = FrozenSources(m1, m2, data_parallel=dp)
-        src.prefetch(inputs, max_groups=prefetch_groups)
+        src.prefetch(inputs, max_groups=prefetch_groups, memory_fraction=PREFETCH_MEMORY)
 
     def logged(loader):        # --phase-log: time of every 10 matching batches (synchronising)
         for i, item in enumerate(loader):
@@ -167,6 +168,7 @@ def run_job(spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, ratio, dp, 
 
 
 PHASE_LOG = False
+PREFETCH_MEMORY = 0.5
 _phase_t = [0.0]
 
 
@@ -304,6 +306,8 @@ def main():
     if world > 1:
         dist.barrier()
 
+    global PREFETCH_MEMORY
+    PREFETCH_MEMORY = args.prefetch_memory
     n_match, n_pleas = split_steps(args.steps)
     full = (n_match, n_pleas) == (FULL_MATCH, FULL_PLEAS)
     n_sched = n_pleas - 1  # CosineAnnealingLR(T_max=MAX_STEPS) with MAX_STEPS + 1 updates
