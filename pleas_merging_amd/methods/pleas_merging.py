@@ -402,14 +402,16 @@ class FrozenSources:
         they run beside the LAP kernel (one workgroup per problem, 71 of 256 CUs, 0.28 s).  ``batches`` must be tensors
         whose values are already in place (resident inputs, or host tensors); ``PleasFitter.steps`` must later be given
         the same tensor objects first, in the same order.  Takes whole groups of ``group`` (default ``2 * world``) equal
-        batches, at most ``max_groups`` of them and as long as less than ``memory_fraction`` of the free HBM is used
-        (measured from the first group).  Returns the number of batches taken."""
+        batches, at most ``max_groups`` of them and as long as their taps (sized from the first group) fit into
+        ``memory_fraction`` of the HBM that is free or idle in the allocator's pools.  Returns the number of batches taken."""
         if self._side_streams is None or self.graph_sources:
             return 0
         group = max(1, int(group or 2 * self.world))
         batches = list(batches)
-        free0 = torch.cuda.mem_get_info(self.device)[0]
-        budget, per_group, taken = free0 * memory_fraction, None, 0
+        # what the taps may take: a share of the HBM that is free or sits unused in the caching allocator's pools
+        idle = torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
+        budget = (torch.cuda.mem_get_info(self.device)[0] + idle) * memory_fraction
+        per_group, taken = None, 0
         for g in range(max_groups):
             run = batches[g * group:(g + 1) * group]
             if len(run) < group or any(not torch.is_tensor(b) or b.shape != run[0].shape or b.shape[0] == 0 for b in run):
@@ -421,8 +423,12 @@ class FrozenSources:
             else:
                 self.queue.append((run[0],) + self.launch(run[0], after_current=False))
             taken += group
-            if per_group is None:
-                per_group = max(free0 - torch.cuda.mem_get_info(self.device)[0], 1)
+            if per_group is None:      # bytes one group's taps hold (inputs and outputs of every hooked layer, both models)
+                gen = self.queue[-1]
+                per_group = 0
+                for taps in (gen[2][0], gen[2][1], gen[3][0], gen[3][1]):
+                    base = taps.base if isinstance(taps, _TapView) else taps
+                    per_group += sum(t.numel() * t.element_size() for t in base.values())
         return taken
 
     def run_eager(self, x: torch.Tensor, after_current: bool = True) -> None:
