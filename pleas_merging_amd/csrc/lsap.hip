@@ -40,12 +40,9 @@ struct LsapBatch {
 
 struct Cand {
     double val;
-    int key;  // (tie key << 11) | column ; smaller wins
+    int key;    // (tie key << 11) | column ; smaller wins
+    int owner;  // row assigned to that column (-1: free), filled in for the per-wave candidates only
 };
-
-__device__ __forceinline__ bool better(const Cand& a, const Cand& b) {  // a strictly better than b
-    return a.val < b.val || (a.val == b.val && a.key < b.key);
-}
 
 // DPP move: lanes without a source keep their own value (harmless for a min reduction).
 template <int CTRL, int ROW_MASK>
@@ -53,28 +50,42 @@ __device__ __forceinline__ int dpp_mov(int x) {
     return __builtin_amdgcn_update_dpp(x, x, CTRL, ROW_MASK, 0xF, false);
 }
 
+// Wave-wide lexicographic min of (val, key), returned in every lane: first the minimum of val (six DPP steps on the two
+// halves of the double + one v_min_f64 each; lane 63 ends up with the wave's minimum), then the minimum of the keys of
+// the lanes that attain it (six DPP steps on one int).  Comparing (val, key) pairs in every step instead cost three
+// compares and three selects per step.
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ void dpp_min_step(Cand& c) {
-    Cand o;
-    const int lo = dpp_mov<CTRL, ROW_MASK>(__double2loint(c.val));
-    const int hi = dpp_mov<CTRL, ROW_MASK>(__double2hiint(c.val));
-    o.val = __hiloint2double(hi, lo);
-    o.key = dpp_mov<CTRL, ROW_MASK>(c.key);
-    if (better(o, c)) c = o;
+__device__ __forceinline__ double dpp_min_f64(double x) {
+    const int lo = dpp_mov<CTRL, ROW_MASK>(__double2loint(x));
+    const int hi = dpp_mov<CTRL, ROW_MASK>(__double2hiint(x));
+    return __builtin_fmin(x, __hiloint2double(hi, lo));
 }
 
-// Wave-wide lexicographic min; the result is valid in lane 63 and broadcast from there.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_min_i32(int x) {
+    const int o = dpp_mov<CTRL, ROW_MASK>(x);
+    return o < x ? o : x;
+}
+
 __device__ __forceinline__ Cand wave_min(Cand c) {
-    dpp_min_step<0x111, 0xF>(c);  // row_shr:1
-    dpp_min_step<0x112, 0xF>(c);  // row_shr:2
-    dpp_min_step<0x114, 0xF>(c);  // row_shr:4
-    dpp_min_step<0x118, 0xF>(c);  // row_shr:8  -> lane 15 of every row holds the row's min
-    dpp_min_step<0x142, 0xA>(c);  // row_bcast:15 into rows 1 and 3
-    dpp_min_step<0x143, 0xC>(c);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's min
+    double m = c.val;
+    m = dpp_min_f64<0x111, 0xF>(m);  // row_shr:1
+    m = dpp_min_f64<0x112, 0xF>(m);  // row_shr:2
+    m = dpp_min_f64<0x114, 0xF>(m);  // row_shr:4
+    m = dpp_min_f64<0x118, 0xF>(m);  // row_shr:8  -> lane 15 of every row holds the row's min
+    m = dpp_min_f64<0x142, 0xA>(m);  // row_bcast:15 into rows 1 and 3
+    m = dpp_min_f64<0x143, 0xC>(m);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's min
     Cand r;
-    r.val = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(c.val), 63),
-                             __builtin_amdgcn_readlane(__double2loint(c.val), 63));
-    r.key = __builtin_amdgcn_readlane(c.key, 63);
+    r.val = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(m), 63), __builtin_amdgcn_readlane(__double2loint(m), 63));
+    int k = c.val == r.val ? c.key : 0x7fffffff;
+    k = dpp_min_i32<0x111, 0xF>(k);
+    k = dpp_min_i32<0x112, 0xF>(k);
+    k = dpp_min_i32<0x114, 0xF>(k);
+    k = dpp_min_i32<0x118, 0xF>(k);
+    k = dpp_min_i32<0x142, 0xA>(k);
+    k = dpp_min_i32<0x143, 0xC>(k);
+    r.key = __builtin_amdgcn_readlane(k, 63);
+    r.owner = -1;
     return r;
 }
 
@@ -95,14 +106,26 @@ __device__ __forceinline__ int col_of(int tid, int k) {
     return ((k / VEC) * kLsapThreads + tid) * VEC + (k % VEC);
 }
 
+constexpr int kDeadKey = 0x7fffffff;
+
+// Tie key of a live column: (rank in scipy's scan order << 11) | column; smaller wins among equal path lengths.
+__device__ __forceinline__ int tie_key(int n, int pos, int r4c, int j) {
+    const int tie = r4c < 0 ? (n - 1 - pos) : (n + pos);
+    return (tie << 11) | j;
+}
+
 template <int COLS>
 __device__ void lsap_solve(const LsapShared sh, const float* __restrict__ cost, const int n, const float sign,
                            int64_t* __restrict__ out, Cand (*wave_best)[kLsapWaves]) {
     constexpr int VEC = COLS < 4 ? COLS : 4;
     const int tid = threadIdx.x;
     const bool vec_ok = (n % VEC == 0) && ((reinterpret_cast<uintptr_t>(cost) & 15) == 0);
+    // Per owned column, in registers: dual v, tentative length sj, predecessor row, position in `remaining`, assigned
+    // row at the start of the search, and the tie key (kDeadKey once the column is scanned, or beyond n).  The step
+    // loop below is written with selects only: as branches (one exec-mask region per column and comparison) it ran to
+    // ~850 instructions per step for 8 columns and WAS the step time (1.7 us).
     double v[COLS], sj[COLS];
-    int pos[COLS], r4c[COLS];
+    int pos[COLS], r4c[COLS], pathk[COLS], keyk[COLS];
 #pragma unroll
     for (int k = 0; k < COLS; ++k) v[k] = 0.0;
     for (int t = tid; t < n; t += kLsapThreads) {
@@ -119,19 +142,18 @@ __device__ void lsap_solve(const LsapShared sh, const float* __restrict__ cost, 
             const int j = col_of<COLS>(tid, k);
             pos[k] = j < n ? n - 1 - j : -1;  // reversed fill: column j sits at position n-1-j
             sj[k] = INFINITY;
+            pathk[k] = -1;
             r4c[k] = j < n ? sh.row4col[j] : 0;
+            keyk[k] = j < n ? tie_key(n, pos[k], r4c[k], j) : kDeadKey;
         }
         for (int t = tid; t < n; t += kLsapThreads) sh.remaining[t] = n - 1 - t;
         __syncthreads();
 
         double dist = 0.0;
         int i = cur, sink = -1, live = n, nrows = 0, parity = 0;
-        while (sink < 0) {
-            if (tid == 0) sh.rowlist[nrows] = i;
-            ++nrows;
-            const double ui = sh.u[i];
-            const float* __restrict__ crow = cost + (size_t)i * n;
-            float c[COLS];
+        float c[COLS];
+        auto load_row = [&](int row) {   // this thread's columns of one cost row, all loads issued back to back
+            const float* __restrict__ crow = cost + (size_t)row * n;
             if (vec_ok) {
 #pragma unroll
                 for (int g = 0; g < COLS / VEC; ++g) {
@@ -155,32 +177,57 @@ __device__ void lsap_solve(const LsapShared sh, const float* __restrict__ cost, 
                     c[k] = j < n ? crow[j] : 0.f;
                 }
             }
+        };
+        load_row(i);
+        while (sink < 0) {
+            if (tid == 0) sh.rowlist[nrows] = i;
+            ++nrows;
+            const double ui = sh.u[i];
+            // pass 1: relax the live columns, thread-local minimum of their tentative lengths
+            double cv[COLS];
             Cand best;
             best.val = INFINITY;
-            best.key = 0x7fffffff;
+            best.owner = -1;
 #pragma unroll
             for (int k = 0; k < COLS; ++k) {
-                const int j = col_of<COLS>(tid, k);
-                const bool livecol = pos[k] >= 0;
+                const bool livecol = keyk[k] != kDeadKey;
                 const double r = ((dist + (double)(sign * c[k])) - ui) - v[k];
-                if (livecol && r < sj[k]) {
-                    sj[k] = r;
-                    sh.path[j] = i;
-                }
-                Cand cand;
-                cand.val = livecol ? sj[k] : INFINITY;
-                const int tie = r4c[k] < 0 ? (n - 1 - pos[k]) : (n + pos[k]);
-                cand.key = livecol ? ((tie << 11) | j) : 0x7fffffff;
-                if (better(cand, best)) best = cand;
+                const bool upd = livecol & (r < sj[k]);
+                sj[k] = upd ? r : sj[k];
+                pathk[k] = upd ? i : pathk[k];
+                cv[k] = livecol ? sj[k] : (double)INFINITY;
+                best.val = __builtin_fmin(best.val, cv[k]);   // no NaNs here; the sign of a zero does not matter below
+            }
+            // pass 2: smallest tie key among the columns that attain it (dead columns carry kDeadKey)
+            best.key = kDeadKey;
+#pragma unroll
+            for (int k = 0; k < COLS; ++k) {
+                const int key = cv[k] == best.val ? keyk[k] : kDeadKey;
+                best.key = key < best.key ? key : best.key;
             }
             best = wave_min(best);
+            {   // the row this wave's candidate leads to: read now, beside the barrier wait, not after it
+                const int jw = best.key & 2047;
+                best.owner = (best.key != kDeadKey && jw < n) ? sh.row4col[jw] : -1;
+            }
             if ((tid & 63) == 0) wave_best[parity][tid >> 6] = best;
             __syncthreads();  // the only barrier of a step
-            best = wave_best[parity][0];
+            {
+                Cand wb[kLsapWaves];
 #pragma unroll
-            for (int w = 1; w < kLsapWaves; ++w) {
-                const Cand o = wave_best[parity][w];
-                if (better(o, best)) best = o;
+                for (int w = 0; w < kLsapWaves; ++w) wb[w] = wave_best[parity][w];
+                best.val = wb[0].val;
+#pragma unroll
+                for (int w = 1; w < kLsapWaves; ++w) best.val = __builtin_fmin(best.val, wb[w].val);
+                best.key = kDeadKey;
+                best.owner = -1;
+#pragma unroll
+                for (int w = 0; w < kLsapWaves; ++w) {
+                    const int key = wb[w].val == best.val ? wb[w].key : kDeadKey;
+                    const bool take = key < best.key;
+                    best.key = take ? key : best.key;
+                    best.owner = take ? wb[w].owner : best.owner;
+                }
             }
             parity ^= 1;
             // Every thread holds the same winner and replays the same bookkeeping; each LDS word
@@ -189,27 +236,39 @@ __device__ void lsap_solve(const LsapShared sh, const float* __restrict__ cost, 
             const int j = best.key & 2047;
             const int tie = best.key >> 11;
             const int pj = tie < n ? (n - 1 - tie) : (tie - n);
-            const int owner = sh.row4col[j];
+            const int owner = best.owner;
+            if (owner >= 0) load_row(owner);   // the next row's loads fly while the bookkeeping below runs
             --live;
             const int moved = sh.remaining[live];
+            const bool swap = pj != live;
+            // only the threads that own column j (now scanned) or the column moved into its slot have anything to do
+            const int my_run = col_of<COLS>(tid, 0) / VEC;   // == tid: a thread's columns are runs tid, tid + T, ...
+            const bool mine = (my_run == (j / VEC) % kLsapThreads) | (swap & (my_run == (moved / VEC) % kLsapThreads));
+            if (mine) {
 #pragma unroll
-            for (int k = 0; k < COLS; ++k) {
-                const int jj = col_of<COLS>(tid, k);
-                if (jj == j) pos[k] = -1;
-                else if (jj == moved && pj != live) pos[k] = pj;
+                for (int k = 0; k < COLS; ++k) {
+                    const int jj = col_of<COLS>(tid, k);
+                    const bool hit = jj == j;
+                    const bool mv = swap & (jj == moved);
+                    pos[k] = hit ? -1 : (mv ? pj : pos[k]);
+                    keyk[k] = hit ? kDeadKey : (mv ? tie_key(n, pj, r4c[k], jj) : keyk[k]);
+                }
             }
-            if (tid == 0 && pj != live) sh.remaining[pj] = moved;
+            if (tid == 0 && swap) sh.remaining[pj] = moved;
             if (owner < 0)
                 sink = j;
             else
                 i = owner;
         }
 
-        // publish tentative lengths, then dual update (rows in LDS, columns in registers)
+        // publish tentative lengths and predecessors, then dual update (rows in LDS, columns in registers)
 #pragma unroll
         for (int k = 0; k < COLS; ++k) {
             const int j = col_of<COLS>(tid, k);
-            if (j < n) sh.shortest[j] = sj[k];
+            if (j < n) {
+                sh.shortest[j] = sj[k];
+                sh.path[j] = pathk[k];
+            }
             if (j < n && pos[k] < 0) v[k] -= dist - sj[k];
         }
         __syncthreads();
