@@ -143,8 +143,26 @@ def run_job(spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, ratio, dp, 
     inputs = [x for x, _ in pleas_loader]
 
     def while_solving():
+        t0 = time.perf_counter()
         early["sources"] = src = FrozenSources(m1, m2, data_parallel=dp)
-        src.prefetch(inputs, max_groups=prefetch_groups, memory_fraction=PREFETCH_MEMORY)
+        t1 = time.perf_counter()
+        st0 = torch.cuda.memory_stats() if PHASE_LOG else None
+        if PHASE_LOG and os.environ.get("PLEAS_BENCH_PROFILE_PREFETCH"):
+            import cProfile, pstats
+            pr = cProfile.Profile()
+            pr.enable()
+            n = src.prefetch(inputs, max_groups=prefetch_groups, memory_fraction=PREFETCH_MEMORY)
+            pr.disable()
+            pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(12)
+        else:
+            n = src.prefetch(inputs, max_groups=prefetch_groups, memory_fraction=PREFETCH_MEMORY)
+        if PHASE_LOG:
+            st1 = torch.cuda.memory_stats()
+            log("host, while the LAP kernel runs: source set-up %.3f s, %d batches' source forwards enqueued in %.3f s "
+                "(allocator: %d new segments, reserved %+.1f GB, %d retries)"
+                % (t1 - t0, n, time.perf_counter() - t1, st1["segment.all.allocated"] - st0["segment.all.allocated"],
+                   (st1["reserved_bytes.all.current"] - st0["reserved_bytes.all.current"]) / 1e9,
+                   st1["num_alloc_retries"] - st0["num_alloc_retries"]))
 
     def logged(loader):        # --phase-log: time of every 10 matching batches (synchronising)
         for i, item in enumerate(loader):
@@ -330,7 +348,19 @@ def main():
 
     # ---- warm-up: W matching batches + W updates on throw-away state (MIOpen find, allocator, graph build)
     if args.warmup > 0:
-        run_job(spec, m1, m2, pool.loader(0, args.warmup * max(world, args.emulate_world)), pool.loader(0, warm_updates), max(1, warm_updates - 1),
+        if dp:
+            # torch's MIOpen binding empties the caching allocator whenever it meets a convolution configuration for the
+            # first time.  The only source-forward size the warm-up job meets LATE is the one left-over update at its end
+            # (batch / ranks samples): met there, it would release the pools the job has just filled, and the timed job
+            # would go back to hipMalloc for 120 GB of taps (1.3 s at 8 ranks).  So that size goes first.
+            from pleas_merging_amd.methods.pleas_merging import FrozenSources
+
+            early = FrozenSources(m1, m2, data_parallel=True)
+            early.launch(pool.items[0])
+            torch.cuda.synchronize()
+            early.close()
+            del early
+        run_job(spec, m1, m2, pool.loader(0, args.warmup * ranks), pool.loader(0, warm_updates), max(1, warm_updates - 1),
                 args.ratio, dp, None if args.lookahead < 0 else bool(args.lookahead), args.prefetch_groups)
 
     log("warm-up done")
