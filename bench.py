@@ -71,6 +71,8 @@ def parse():
     ap.add_argument("--phase-log", action="store_true", help="debug: synchronise and log the duration of each job phase")
     ap.add_argument("--prefetch-groups", type=int, default=16,
                     help="groups of source forwards enqueued while the LAP kernel runs (0: none); also bounded by memory")
+    ap.add_argument("--grad-buckets", type=int, default=1, help="data parallel: 1 (default) = one all-reduce per update; "
+                    "2 = the gradient arena is all-reduced in two halves, each beside the other half's kernels")
     ap.add_argument("--prefetch-memory", type=float, default=0.5, help="share of the free HBM the prefetched taps may take")
     ap.add_argument("--emulate-allreduce-us", type=float, default=0.0,
                     help="with --emulate-world: hold the update stream this long where the gradient all-reduce would run")
@@ -177,7 +179,8 @@ def run_job(spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, ratio, dp, 
     # Data parallel: each rank's share of an update is small (batch / world samples); the frozen sources therefore forward
     # 2 * world updates' samples at once (steps() default), which keeps their host dispatch off the per-update path.
     # (Replaying them from a hipGraph costs the host MORE than dispatching them: 9.6 ms per replay of ~600 nodes.)
-    fit = PleasFitter(m1, m2, m3, spec, perm, costs, ratio, n_pleas_sched, data_parallel=dp, sources=early.get("sources"))
+    fit = PleasFitter(m1, m2, m3, spec, perm, costs, ratio, n_pleas_sched, data_parallel=dp, sources=early.get("sources"),
+                      grad_buckets=GRAD_BUCKETS)
     phase("partial merge + fitter set-up")
     for _ in fit.steps(inputs, lookahead=lookahead):
         pass
@@ -187,6 +190,7 @@ def run_job(spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, ratio, dp, 
 
 PHASE_LOG = False
 PREFETCH_MEMORY = 0.5
+GRAD_BUCKETS = 1
 _phase_t = [0.0]
 
 
@@ -324,8 +328,9 @@ def main():
     if world > 1:
         dist.barrier()
 
-    global PREFETCH_MEMORY
+    global PREFETCH_MEMORY, GRAD_BUCKETS
     PREFETCH_MEMORY = args.prefetch_memory
+    GRAD_BUCKETS = args.grad_buckets
     n_match, n_pleas = split_steps(args.steps)
     full = (n_match, n_pleas) == (FULL_MATCH, FULL_PLEAS)
     n_sched = n_pleas - 1  # CosineAnnealingLR(T_max=MAX_STEPS) with MAX_STEPS + 1 updates

@@ -372,7 +372,11 @@ struct WgradPlan {
     double flops = 0, bytes = 0;
     bool uploaded = false;
 };
-static WgradPlan g_wplan;
+// A few plans are kept (keyed by layer geometry + workspace address): a caller may alternate between grouped launches,
+// e.g. the two gradient buckets of a data-parallel update, without rebuilding and re-uploading the tables each time.
+constexpr int kWgradPlans = 4;
+static WgradPlan g_wplans[kWgradPlans];
+static unsigned g_wplan_turn = 0;
 static std::mutex g_wplan_mu;
 
 static size_t walign(size_t v) { return (v + 255) / 256 * 256; }
@@ -492,13 +496,18 @@ extern "C" int pleas_wgrad_batch(const pleas_wgrad_layer* layers, int n_layers, 
     }
     hipStream_t stream = (hipStream_t)stream_;
     std::lock_guard<std::mutex> lk(g_wplan_mu);
-    WgradPlan& P = g_wplan;
     std::vector<int64_t> key = wgrad_key(layers, n_layers, ws);
-    if (key != P.key) {
-        const int rc = build_wgrad_plan(P, layers, n_layers);
+    WgradPlan* hit = nullptr;
+    for (auto& cand : g_wplans)
+        if (cand.key == key) hit = &cand;
+    if (!hit) {
+        hit = &g_wplans[g_wplan_turn++ % kWgradPlans];
+        hit->key.clear();
+        const int rc = build_wgrad_plan(*hit, layers, n_layers);
         if (rc != PLEAS_OK) return rc;
-        P.key.swap(key);
+        hit->key.swap(key);
     }
+    WgradPlan& P = *hit;
     if (ws_fresh) P.uploaded = false;  // caller says the tables inside ws are not (or no longer) there
     if (!ws || ws_bytes < P.total) {
         std::snprintf(g_last_error, sizeof(g_last_error), "wgrad workspace too small: need %zu bytes", P.total);
@@ -507,6 +516,8 @@ extern "C" int pleas_wgrad_batch(const pleas_wgrad_layer* layers, int n_layers, 
     }
     char* base = (char*)ws;
     if (!P.uploaded) {
+        for (auto& other : g_wplans)   // its tables go into `ws`: whatever another plan had there is gone
+            if (&other != &P && other.key.size() > 1 && other.key[1] == (int64_t)(uintptr_t)ws) other.uploaded = false;
         float* slab0 = reinterpret_cast<float*>(base + P.off_slabs);
         std::vector<WgradLayerDev> abs_layers = P.layers;
         for (auto& d : abs_layers) d.slab = slab0 + reinterpret_cast<size_t>(d.slab);

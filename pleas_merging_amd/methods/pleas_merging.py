@@ -202,7 +202,7 @@ def cosine_lrs(base_lr: float, t_max: int, n: int) -> List[float]:
 
 # ------------------------------------------------------------------------------------------ per-layer plan
 class _LayerPlan:
-    __slots__ = ("name", "mod", "is_conv", "w", "b", "gw", "gb", "in_maps", "out_maps", "w_shape", "off_w", "kpos")
+    __slots__ = ("name", "mod", "is_conv", "w", "b", "gw", "gb", "in_maps", "out_maps", "w_shape", "off_w", "kpos", "bucket")
 
 
 def _identity_block(n: int):
@@ -228,7 +228,7 @@ def dp_slice(x: torch.Tensor, rank: int, world: int) -> torch.Tensor:
     return x.chunk(world)[rank]
 
 
-def dp_sum_(flat: torch.Tensor, world: int) -> torch.Tensor:
+def dp_sum_(flat: torch.Tensor, world: int, share: float = 1.0) -> torch.Tensor:
     """Sum of the flat gradient arena over ranks (ONE collective per update).  Each rank scales its
     residual by 2 / (local numel * world), so the sum IS the gradient of the full-batch mean."""
     if world > 1:
@@ -237,19 +237,53 @@ def dp_sum_(flat: torch.Tensor, world: int) -> torch.Tensor:
         if dist.is_initialized():
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         else:                           # PLEAS_EMULATE_WORLD (activation_matching._dist_info): no peers
-            _emulated_collective(flat)
+            _emulated_collective(flat, share)
     return flat
+
+
+class _Pending:
+    """An all-reduce in flight (``dist.all_reduce(..., async_op=True)``, or its emulation on a stream of its own);
+    ``wait()`` orders the current stream after it."""
+
+    def __init__(self, work=None, stream=None):
+        self.work, self.stream = work, stream
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+
+
+def dp_sum_async_(flat: torch.Tensor, world: int, share: float = 1.0) -> Optional[_Pending]:
+    """Start the sum of ``flat`` over ranks and return at once; the caller keeps enqueuing work that does not need the
+    result (the other gradient bucket's kernels) and calls ``wait()`` before the first reader."""
+    if world <= 1:
+        return None
+    import torch.distributed as dist
+
+    if dist.is_initialized():
+        return _Pending(work=dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
+    if not flat.is_cuda:
+        return None
+    from .. import hip_ops                       # PLEAS_EMULATE_WORLD: the stall sits on a stream of its own
+    comm = hip_ops.role_stream(flat.device, "emulated-collective")
+    comm.wait_stream(torch.cuda.current_stream(flat.device))
+    with torch.cuda.stream(comm):
+        _emulated_collective(flat, share)
+    return _Pending(stream=comm)
 
 
 _SPIN = {}
 
 
-def _emulated_collective(flat: torch.Tensor) -> None:
-    """Profiling aid: with PLEAS_EMULATE_ALLREDUCE_US=T the stream is held for T microseconds where the all-reduce
-    would run (a spin kernel on one CU), so that what overlaps a collective can be studied on one GPU."""
+def _emulated_collective(flat: torch.Tensor, share: float = 1.0) -> None:
+    """Profiling aid: with PLEAS_EMULATE_ALLREDUCE_US=T the stream is held for ``share`` * T microseconds where the
+    all-reduce would run (a spin kernel on one CU; T = the whole gradient arena), so that what overlaps a collective
+    can be studied on one GPU."""
     import os
 
-    us = float(os.environ.get("PLEAS_EMULATE_ALLREDUCE_US", "0") or 0)
+    us = float(os.environ.get("PLEAS_EMULATE_ALLREDUCE_US", "0") or 0) * share
     if us <= 0 or not flat.is_cuda:
         return
     if "per_us" not in _SPIN:           # calibrate the spin kernel's cycle unit once
@@ -473,7 +507,8 @@ class PleasFitter:
     def __init__(self, model1, model2, model3, spec, perm, costs, budget_ratios, max_steps: int, lr: float = 5e-4,
                  separate_classifier=False, num_classes=1000, model_type="rn50", data_parallel: bool = False,
                  forward: str = "hip", graph_sources: bool = False, fuse_sources: bool = True,
-                 overlap_sources: bool = True, fused_sources=None, sources: Optional[FrozenSources] = None):
+                 overlap_sources: bool = True, fused_sources=None, sources: Optional[FrozenSources] = None,
+                 grad_buckets: int = 1):
         from .. import hip_ops
 
         self.ops = hip_ops
@@ -563,6 +598,20 @@ class PleasFitter:
         self.loss_scale = torch.zeros(len(self.plans), dtype=torch.float32, device=dev)
         self.loss_meta_host = [None] * len(self.plans)
         self.wgrad = hip_ops.WgradBatch(dev)
+        # Data parallel, grad_buckets=2 (option): the gradient arena is summed in TWO buckets (first / second half of its
+        # bytes, layers in plan order).  Bucket 0's all-reduce is started as soon as its grouped weight-gradient launch is
+        # enqueued and runs beside bucket 1's launch; bucket 1's runs beside bucket 0's Adam; the losses ride at the end
+        # of bucket 1.  Off by default: with the collective modelled as a stall of a stream of its own
+        # (PLEAS_EMULATE_ALLREDUCE_US) the split cost more than it hid -- 1.69 vs 1.64 s per rank at 8 ranks, 4.33 vs
+        # 3.76 s at 2 -- and RCCL itself cannot be timed on a one-GPU box; same results either way (two-rank test).
+        self.wgrad_b = hip_ops.WgradBatch(dev) if (self.world > 1 and grad_buckets >= 2) else None
+        self._bucket_cut = 0
+        if self.wgrad_b is not None:
+            half = total // 2
+            cut_plan = next((pl for pl in self.plans if pl.off_w >= half), None)
+            self._bucket_cut = cut_plan.off_w if cut_plan is not None else 0
+        for pl in self.plans:
+            pl.bucket = 1 if (self.wgrad_b is not None and self._bucket_cut > 0 and pl.off_w >= self._bucket_cut) else 0
         if forward not in ("hip", "vendor"):
             raise ValueError("forward must be 'hip' (fused MFMA kernel) or 'vendor' (MIOpen + pleas_target_residual)")
         self.forward = forward
@@ -637,7 +686,8 @@ class PleasFitter:
                 self.loss_scale[idx] = 1.0 / n
             resid = out
         if (square and ip.shape[1] >= 16) or linear:
-            self.wgrad.add(resid, ip, plan.gw, *geo, flags=ops.WgradBatch.KPOS_MAJOR if plan.kpos else 0)
+            (self.wgrad_b if plan.bucket else self.wgrad).add(resid, ip, plan.gw, *geo,
+                                                             flags=ops.WgradBatch.KPOS_MAJOR if plan.kpos else 0)
         elif plan.is_conv:  # stem (3 input channels) and exotic geometries: vendor weight gradient
             self._vendor_wgrad.append((resid, ip, plan))
         else:
@@ -819,22 +869,40 @@ class PleasFitter:
         if self._fwd_rows:
             self.loss_now.index_copy_(0, self._fwd_index, self._fwd_loss)
         self._finish_vendor_parts()
+        two = self.wgrad_b is not None and self._bucket_cut > 0
+        cut = self._bucket_cut
+        pending = [None, None]
         if replay is not None:
             with self.ops.pin_stream():
                 self.wgrad.relaunch()
+                if two:
+                    pending[0] = dp_sum_async_(self._g_ext[:cut], self.world, cut / self._g_ext.numel())
+                    self.wgrad_b.relaunch()
         else:
-            n_wgrad = len(self.wgrad._keep)
-            self.wgrad.flush()  # ONE grouped MFMA launch: weight gradients of every merged layer
-            if complete and not vendor_rows and n_wgrad > 0:
+            n_wgrad = len(self.wgrad._keep) + (len(self.wgrad_b._keep) if two else 0)
+            n_b = len(self.wgrad_b._keep) if two else 0
+            self.wgrad.flush()  # ONE grouped MFMA launch: weight gradients of every merged layer (of bucket 0)
+            if two:
+                pending[0] = dp_sum_async_(self._g_ext[:cut], self.world, cut / self._g_ext.numel())
+                self.wgrad_b.flush()
+            if complete and not vendor_rows and n_wgrad > 0 and (not two or n_b > 0):
                 names = tuple(self.plans[i].name for i in self._fwd_rows)
                 merge_tab, fwd_tab = self.merge.table(), self.fwd.table()
                 if merge_tab is not None and fwd_tab is not None and len(merge_tab) == len(fwd_tab) == len(names):
                     self._replay = (key, names, merge_tab, fwd_tab, self._vendor_wgrad, self._bias_grads)
-        dp_sum_(self._g_ext, self.world)     # gradients + losses
-        self.loss_sum.add_(self.loss_now)
         lr = self.lrs[min(self.step_count, len(self.lrs) - 1)]
         self.step_count += 1
-        self.ops.masked_adam(self.p, self.g, self.mask, self.m, self.v, lr, self.step_count)
+        if two:
+            pending[1] = dp_sum_async_(self._g_ext[cut:], self.world, 1.0 - cut / self._g_ext.numel())   # + the losses
+            for half, sl in enumerate((slice(0, cut), slice(cut, None))):
+                if pending[half] is not None:
+                    pending[half].wait()
+                self.ops.masked_adam(self.p[sl], self.g[sl], self.mask[sl], self.m[sl], self.v[sl], lr, self.step_count)
+            self.loss_sum.add_(self.loss_now)
+        else:
+            dp_sum_(self._g_ext, self.world)     # gradients + losses
+            self.loss_sum.add_(self.loss_now)
+            self.ops.masked_adam(self.p, self.g, self.mask, self.m, self.v, lr, self.step_count)
         self._end_update()
 
     def finish(self) -> nn.Module:

@@ -22,7 +22,7 @@ def _batches(t):
     return [x + 0.01 * i for i, x in enumerate(xs)][:N_UPDATES]
 
 
-def _job(t, data_parallel):
+def _job(t, data_parallel, buckets=1):
     from pleas.methods.activation_matching import activation_matching
     from pleas.methods.partial_matching import partial_merge
     from pleas.methods.pleas_merging import PleasFitter
@@ -30,7 +30,8 @@ def _job(t, data_parallel):
     m1, m2 = copy.deepcopy(t.m1).cuda(), copy.deepcopy(t.m2).cuda()
     perm, costs = activation_matching(t.spec, m1, m2, t.batches(), N_MATCH, output_costs=True)
     m3 = partial_merge(t.spec, m1, m2, perm, costs, 0.5)
-    fit = PleasFitter(m1, m2, m3, t.spec, perm, costs, 0.5, N_UPDATES - 1, num_classes=10, data_parallel=data_parallel)
+    fit = PleasFitter(m1, m2, m3, t.spec, perm, costs, 0.5, N_UPDATES - 1, num_classes=10, data_parallel=data_parallel,
+                      grad_buckets=buckets)
     assert list(fit.steps(_batches(t))) == list(range(N_UPDATES))
     loss = fit.loss_sum.clone()
     torch.cuda.synchronize()
@@ -38,7 +39,7 @@ def _job(t, data_parallel):
             {k: v.cpu() for k, v in fit.finish().state_dict().items()}, loss.cpu(), fit.world)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, buckets):
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
@@ -50,7 +51,7 @@ def _worker(rank, world, port, q):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        perm, costs, sd, loss, world = _job(Tiny("tiny_bottleneck.npz"), data_parallel=True)
+        perm, costs, sd, loss, world = _job(Tiny("tiny_bottleneck.npz"), data_parallel=True, buckets=buckets)
         as_np = lambda d: {k: v.numpy() for k, v in d.items()}   # plain arrays: nothing shared with a process that exits
         q.put((rank, (as_np(perm), as_np(costs), as_np(sd), loss.numpy(), world)))
     finally:
@@ -62,12 +63,13 @@ def _rel(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
 
 
-def test_two_rank_job_equals_single_process_job(tiny_bottleneck):
+@pytest.mark.parametrize("buckets", [1, 2])     # one all-reduce per update / two halves, each started early
+def test_two_rank_job_equals_single_process_job(tiny_bottleneck, buckets):
     want_perm, want_costs, want_sd, want_loss, world1 = _job(tiny_bottleneck, data_parallel=False)
     assert world1 == 1
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, 29641, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, 29641 + buckets, q, buckets)) for r in range(2)]
     for p in procs:
         p.start()
     results = dict(q.get(timeout=300) for _ in procs)
