@@ -69,11 +69,11 @@ def parse():
     ap.add_argument("--ratio", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--phase-log", action="store_true", help="debug: synchronise and log the duration of each job phase")
-    ap.add_argument("--prefetch-groups", type=int, default=16,
+    ap.add_argument("--prefetch-groups", type=int, default=24,
                     help="groups of source forwards enqueued while the LAP kernel runs (0: none); also bounded by memory")
     ap.add_argument("--grad-buckets", type=int, default=1, help="data parallel: 1 (default) = one all-reduce per update; "
                     "2 = the gradient arena is all-reduced in two halves, each beside the other half's kernels")
-    ap.add_argument("--prefetch-memory", type=float, default=0.5, help="share of the free HBM the prefetched taps may take")
+    ap.add_argument("--prefetch-memory", type=float, default=0.7, help="share of the free HBM the prefetched taps may take")
     ap.add_argument("--emulate-allreduce-us", type=float, default=0.0,
                     help="with --emulate-world: hold the update stream this long where the gradient all-reduce would run")
     ap.add_argument("--lookahead", type=int, default=-1, help="1: the next group's source forwards are enqueued before the "
@@ -132,7 +132,7 @@ def build_models(arch, device, batch):
     return models
 
 
-def run_job(spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, ratio, dp, lookahead=None, prefetch_groups=16):
+def run_job(spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, ratio, dp, lookahead=None, prefetch_groups=24):
     """The timed hot path.  Returns (merged model, perm, costs)."""
     from pleas_merging_amd.methods.activation_matching import activation_matching
     from pleas_merging_amd.methods.partial_matching import partial_merge
@@ -189,7 +189,7 @@ def run_job(spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, ratio, dp, 
 
 
 PHASE_LOG = False
-PREFETCH_MEMORY = 0.5
+PREFETCH_MEMORY = 0.7
 GRAD_BUCKETS = 1
 _phase_t = [0.0]
 
