@@ -69,6 +69,18 @@ def _node(graph: torch.fx.Graph, op: str, target, args=(), name: str = "n") -> t
     return graph.create_node(op, target, tuple(args), {}, name=name)
 
 
+class _Trace:
+    """fx graph of a model without the GraphModule around it (``symbolic_trace`` also generates and compiles Python code
+    for a module nobody calls: a third of the twin graph's build time, spent while the GPU waits for its first batch)."""
+
+    def __init__(self, model: nn.Module):
+        self.graph = torch.fx.Tracer().trace(model)
+        self._model = model
+
+    def named_modules(self):
+        return self._model.named_modules()
+
+
 class _SideStream:
     """Stream fork/join calls placed in a split twin graph: model2's chain is enqueued on a second HIP
     stream, model1's on the caller's stream, and the caller's stream waits for both before the sinks run.
@@ -115,7 +127,7 @@ def _build_twin(model1: nn.Module, model2: nn.Module, axes: Iterable[Axis], emit
         if not keep_inputs:
             raise ValueError("a split twin graph defers its sinks: it needs keep_inputs=True")
         return _build_split_twin(model1, model2, axes, emit, side_stream, fuse_bn, emit_derived)
-    traced = torch.fx.symbolic_trace(model1)
+    traced = _Trace(model1)
     submods = dict(traced.named_modules())
     want: Dict[str, List[int]] = {}
     for ax in axes:
@@ -155,7 +167,7 @@ def _build_twin(model1: nn.Module, model2: nn.Module, axes: Iterable[Axis], emit
     return gm
 
 
-def _bn_chains(traced: torch.fx.GraphModule, model1: nn.Module, model2: nn.Module):
+def _bn_chains(traced: _Trace, model1: nn.Module, model2: nn.Module):
     """Eval-mode ``BatchNorm2d -> [+ other] -> [ReLU]`` chains of the traced graph whose links have no other consumer:
     ``{last node of the chain: (bn, add or None, relu or None, residual operand or None)}`` and the set of nodes that are
     produced by the chain's single fused launch instead of their own."""
@@ -193,7 +205,7 @@ def _build_split_twin(model1: nn.Module, model2: nn.Module, axes: Iterable[Axis]
     from .. import hip_ops
     from .source_forward import fold_bn
 
-    traced = torch.fx.symbolic_trace(model1)
+    traced = _Trace(model1)
     submods = dict(traced.named_modules())
     root = nn.ModuleList([model1, model2])
     chains, absorbed = _bn_chains(traced, model1, model2) if fuse_bn else ({}, set())

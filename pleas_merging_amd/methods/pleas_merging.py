@@ -442,6 +442,11 @@ class FrozenSources:
             return 0
         group = max(1, int(group or 2 * self.world))
         batches = list(batches)
+        # The side streams skip the current stream's queue (the LAP kernel), but the memory they are about to take from
+        # their allocator pools may have been released by the host while its last readers are still queued: updates of an
+        # earlier fitter on the update stream (waited for here), matching kernels on model1's stream (in order with it;
+        # model2's stream follows model1's in run_eager).
+        self._side_streams[0].wait_stream(self.ops.role_stream(self.device, "updates"))
         # what the taps may take: a share of the HBM that is free or sits unused in the caching allocator's pools
         idle = torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
         budget = (torch.cuda.mem_get_info(self.device)[0] + idle) * memory_fraction
@@ -482,11 +487,13 @@ class FrozenSources:
         # only after a LATER wait_stream(main), i.e. after every consumer enqueued on `main` up to then -- with one
         # batch of look-ahead that is the update two generations back.  No record_stream bookkeeping needed.
         events = []
+        if not after_current:          # model2's stream follows model1's up to HERE (the batch is in place), not its forward
+            here = torch.cuda.Event()
+            here.record(side[0])
+            side[1].wait_event(here)
         for stream, model in zip(side, (self.src1, self.src2)):
             if after_current:
                 stream.wait_stream(main)
-            elif stream is not side[0]:
-                stream.wait_stream(side[0])
             with torch.cuda.stream(stream), self.ops.pin_stream():
                 model(x)
             ev = torch.cuda.Event()
