@@ -464,3 +464,22 @@ def test_eval_helpers_route_features_to_the_right_head(tiny_basic):
     whole = torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(4, 3))
     x = torch.randn(6, 4, generator=g)
     assert float(eval_whole_model(whole, [(x, whole(x).argmax(1))], 3)) == 1.0
+
+
+def test_tap_views_and_pointer_tables():
+    """Grouped source forwards hand every update a lazily sliced view of the group's taps; the per-update fast path of
+    PleasFitter needs only the addresses of those slices, computed from one table per forward."""
+    from pleas_merging_amd.methods.pleas_merging import TapDict, _TapView, tap_pointers
+
+    base = TapDict(a=torch.arange(6 * 3 * 4, dtype=torch.float32).reshape(6, 3, 4),
+                   b=torch.arange(6 * 5, dtype=torch.float32).reshape(6, 5))
+    view = _TapView(base, 2, 4)
+    assert "a" in view and "zz" not in view and len(view) == 2 and list(view.keys()) == ["a", "b"]
+    assert torch.equal(view["a"], base["a"][2:4]) and dict(view.items())["b"].shape == (2, 5)
+    names = ("b", "a")
+    got = tap_pointers(view, names)
+    assert [int(p) for p in got] == [base["b"][2:4].data_ptr(), base["a"][2:4].data_ptr()]
+    assert [int(p) for p in tap_pointers(base, names)] == [base["b"].data_ptr(), base["a"].data_ptr()]
+    assert base.packs and tap_pointers(_TapView(base, 4, 6), names)[1] == base["a"][4:].data_ptr()   # table reused
+    # a tensor the grouped kernels could not read in place -> no table (the caller falls back to the layer-by-layer path)
+    assert tap_pointers(TapDict(a=torch.zeros(4, 6).t()), ("a",)) is None
