@@ -20,6 +20,9 @@ Ratios = Union[float, Dict[Axis, float]]
 Blocks = Dict[Axis, Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]]
 
 
+_BLOCKS_MEMO: list = []
+
+
 def expand_ratios(spec: PermutationSpec, ratios: Ratios) -> Dict[Axis, float]:
     """Reference: partial_matching.py:30-44."""
     return ratios if isinstance(ratios, dict) else {ax: ratios for ax in spec}
@@ -37,6 +40,12 @@ def get_blocks(spec: PermutationSpec, perm: Permutation, costs: Dict[Axis, torch
     hard-codes ``.cuda()`` at :86).
     """
     ratios = expand_ratios(spec, ratios)
+    # partial_merge and then PleasFitter ask for the same blocks (as the reference's drivers do): 71 quantiles and 284
+    # boolean-index syncs, 23 ms on the ResNet-101 pair.  The latest answer is kept, keyed by the identity AND version
+    # counter of every tensor involved, so an in-place change of a permutation or cost matrix is seen.
+    memo_key = tuple((key, id(p), p._version, id(costs[key]), costs[key]._version, float(ratios[key])) for key, p in perm.items())
+    if _BLOCKS_MEMO and _BLOCKS_MEMO[0] == memo_key:
+        return dict(_BLOCKS_MEMO[1])
     out: Blocks = {}
     for key, p in perm.items():
         r = float(ratios[key])
@@ -47,6 +56,7 @@ def get_blocks(spec: PermutationSpec, perm: Permutation, costs: Dict[Axis, torch
         matched = cost[rows, cols]
         keep = matched >= torch.quantile(matched, r)
         out[key] = (rows[keep], cols[keep], rows[~keep], cols[~keep])
+    _BLOCKS_MEMO[:] = [memo_key, dict(out), list(perm.values()), [costs[k] for k in perm]]   # keeps the ids alive
     return out
 
 

@@ -483,3 +483,23 @@ def test_tap_views_and_pointer_tables():
     assert base.packs and tap_pointers(_TapView(base, 4, 6), names)[1] == base["a"][4:].data_ptr()   # table reused
     # a tensor the grouped kernels could not read in place -> no table (the caller falls back to the layer-by-layer path)
     assert tap_pointers(TapDict(a=torch.zeros(4, 6).t()), ("a",)) is None
+
+
+def test_get_blocks_memo_sees_in_place_changes():
+    """get_blocks keeps its latest answer (partial_merge and PleasFitter ask for the same blocks back to back); the key
+    holds every tensor's version counter, so a changed cost matrix or permutation is recomputed."""
+    from pleas_merging_amd.core.utils import Axis, PermutationGroup
+    from pleas_merging_amd.methods.partial_matching import get_blocks
+
+    ax = Axis("w", 0)
+    spec = {ax: PermutationGroup(size=4, state=[ax], node=[])}
+    perm = {ax: torch.tensor([1, 0, 3, 2])}
+    costs = {ax: torch.tensor([[0., 9., 0., 0.], [8., 0., 0., 0.], [0., 0., 0., 1.], [0., 0., 2., 0.]])}
+    first = get_blocks(spec, perm, costs, 0.5)
+    again = get_blocks(spec, perm, costs, 0.5)
+    assert all(a is b for a, b in zip(first[ax], again[ax]))                    # served from the memo
+    assert first[ax][0].tolist() == [0, 1] and first[ax][2].tolist() == [2, 3]
+    costs[ax][2, 3] = 20.0                                                      # in place: version counter moves
+    changed = get_blocks(spec, perm, costs, 0.5)
+    assert changed[ax][0].tolist() == [0, 2] and changed[ax][2].tolist() == [1, 3]
+    assert get_blocks(spec, perm, costs, 0.25)[ax][0].tolist() == [0, 1, 2]     # another ratio is another key

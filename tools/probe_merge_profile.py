@@ -1,0 +1,23 @@
+"""cProfile of partial_merge(device=cuda) and PleasFitter.__init__ on the ResNet-101 pair (host-bound one-off parts)."""
+import sys, os, time, cProfile, pstats
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pleas_merging_amd import resnet as zoo
+from pleas_merging_amd.core.compiler import get_permutation_spec
+from pleas_merging_amd.core.utils import make_identity_perm
+from pleas_merging_amd.methods.partial_matching import partial_merge
+from pleas_merging_amd.methods.pleas_merging import FrozenSources, PleasFitter
+dev = torch.device("cuda")
+torch.manual_seed(0); m1 = zoo.resnet101().to(dev).eval()
+torch.manual_seed(1); m2 = zoo.resnet101().to(dev).eval()
+spec = get_permutation_spec(m1, ((1, 3, 224, 224),))
+perm = make_identity_perm(spec); costs = {k: torch.rand(g.size, g.size, device=dev) for k, g in spec.items()}
+src = FrozenSources(m1, m2)
+for rep in range(2):
+    torch.cuda.synchronize(); t0 = time.time(); m3 = partial_merge(spec, m1, m2, perm, costs, 0.0, device=dev); torch.cuda.synchronize(); t1 = time.time()
+    fit = PleasFitter(m1, m2, m3, spec, perm, costs, 0.0, 400, sources=src); torch.cuda.synchronize(); t2 = time.time()
+    print("partial_merge %.3f s, PleasFitter init %.3f s" % (t1 - t0, t2 - t1))
+for name, fn in (("partial_merge", lambda: partial_merge(spec, m1, m2, perm, costs, 0.0, device=dev)),
+                 ("fitter", lambda: PleasFitter(m1, m2, m3, spec, perm, costs, 0.0, 400, sources=src))):
+    pr = cProfile.Profile(); pr.enable(); fn(); pr.disable()
+    print("=====", name); pstats.Stats(pr).sort_stats("tottime").print_stats(14)
