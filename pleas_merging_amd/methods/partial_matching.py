@@ -43,8 +43,11 @@ def get_blocks(spec: PermutationSpec, perm: Permutation, costs: Dict[Axis, torch
     # partial_merge and then PleasFitter ask for the same blocks (as the reference's drivers do): 71 quantiles and 284
     # boolean-index syncs, 23 ms on the ResNet-101 pair.  The latest answer is kept, keyed by the identity AND version
     # counter of every tensor involved, so an in-place change of a permutation or cost matrix is seen.
-    memo_key = tuple((key, id(p), p._version, id(costs[key]), costs[key]._version, float(ratios[key])) for key, p in perm.items())
-    if _BLOCKS_MEMO and _BLOCKS_MEMO[0] == memo_key:
+    memo_key = tuple((key, id(p), getattr(p, "_version", None), id(costs[key]), getattr(costs[key], "_version", None),
+                      float(ratios[key])) for key, p in perm.items())
+    if any(k[2] is None or k[4] is None for k in memo_key):
+        memo_key = None                      # not tensors: nothing to tell a change by, never served from the memo
+    if memo_key is not None and _BLOCKS_MEMO and _BLOCKS_MEMO[0] == memo_key:
         return dict(_BLOCKS_MEMO[1])
     out: Blocks = {}
     for key, p in perm.items():
