@@ -73,11 +73,11 @@ def fuse_bn_act(model: nn.Module, op: Callable = _bn_act) -> Optional[torch.fx.G
     passes its own.  Returns None when the model cannot be traced or holds nothing to fold; the caller
     then runs the model as it is (vendor kernels)."""
     try:
-        gm = torch.fx.symbolic_trace(model)
+        graph = torch.fx.Tracer().trace(model)      # the graph alone: one code generation at the end, not two
     except Exception:  # noqa: BLE001 -- untraceable control flow: nothing to rewrite
         return None
-    mods = dict(gm.named_modules())
-    graph = gm.graph
+    mods = dict(model.named_modules())
+    constants = {}                                    # get_attr targets of the folded scale / shift vectors
     folded = 0
     for node in list(graph.nodes):
         if node.op != "call_module" or not _foldable(mods.get(node.target)):
@@ -87,8 +87,8 @@ def fuse_bn_act(model: nn.Module, op: Callable = _bn_act) -> Optional[torch.fx.G
         bn = mods[node.target]
         scale, shift = fold_bn(bn)
         tag = node.name
-        gm.register_buffer("_pleas_scale_%s" % tag, scale, persistent=False)
-        gm.register_buffer("_pleas_shift_%s" % tag, shift, persistent=False)
+        constants["_pleas_scale_%s" % tag] = scale
+        constants["_pleas_shift_%s" % tag] = shift
 
         chain, res, relu = [node], None, False
         users = list(node.users)
@@ -115,6 +115,17 @@ def fuse_bn_act(model: nn.Module, op: Callable = _bn_act) -> Optional[torch.fx.G
     if folded == 0:
         return None
     graph.lint()
-    gm.recompile()
+    # the GraphModule's attributes: every submodule the graph calls (the SAME objects, so hooks on them keep firing),
+    # every other attribute it reads, and the folded constants
+    root = dict(constants)
+    for node in graph.nodes:
+        if node.op == "call_module":
+            root[node.target] = mods[node.target]
+        elif node.op == "get_attr" and node.target not in root:
+            obj = model
+            for part in node.target.split("."):
+                obj = getattr(obj, part)
+            root[node.target] = obj
+    gm = torch.fx.GraphModule(root, graph, class_name=type(model).__name__)
     gm.train(model.training)
     return gm
