@@ -1,46 +1,96 @@
 #!/usr/bin/env python3
 """Headline benchmark (BASELINE.json): wall-clock seconds to merge a ResNet-101 pair --
-100-batch activation matching + LAP + partial merge + 400-step PLeaS (401 updates) -- on
-synthetic 224x224 inputs, on N MI355X GPUs of one node.
+100-batch activation matching + LAP (71 groups) + partial merge + 400-step PLeaS (401 Adam updates) --
+on synthetic 224x224 inputs, on N MI355X GPUs of one node.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--arch resnet101] [--batch 16]
-  N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one batch through the hot path.  The default K = 501 is the whole job (100 matching
-batches + 401 PLeaS updates); a smaller K runs a proportionally shortened job and says so in
-``config.workload``.  W warm-up steps (untimed) run the same code on throw-away state first.
-Inputs and both models are resident in HBM before the timed region starts.
+A STEP is ONE WHOLE JOB (100 matching batches + 71 LAPs + merge + 401 updates on one set of synthetic batches that is
+resident in HBM).  ``--steps K`` times exactly K jobs back to back, bracketed by barrier + synchronize on both sides
+(max over ranks); ``value`` = that time / K = seconds per job = BASELINE.json's metric; ``ms_per_step`` = 1000 * value.
+``--warmup W`` runs W untimed jobs first.  ``--match-batches`` / ``--updates`` shorten the job for debugging only (the
+line then says SHORTENED and is not a benchmark result).
 
-Multi-GPU (strong scaling, total work fixed): matching shards whole batches over ranks and
-all-reduces the flat cost arena once (RCCL); each PLeaS update shards the batch's samples over
-ranks and all-reduces the flat gradient arena, so every rank applies the identical update.
+N > 1: the driver starts one rank per GPU with ``python -m torch.distributed.run ... bench.py --gpus N``; when started
+WITHOUT that launcher (``python bench.py --gpus N``) this script starts it itself, before anything touches the GPU, and
+exits with its status.  Strong scaling, total work fixed: matching shards whole batches over ranks and all-reduces the
+flat cost arena once (RCCL); each PLeaS update shards the batch's samples over ranks and all-reduces the flat gradient
+arena, so every rank applies the identical update.
 
-The JSON line also carries
-  roofline     -- the dominant kernel (fp32-MFMA gram contraction): algorithmic FLOP / HIP-event time
-                  of its launches inside the timed region, against the 157.3 TFLOP/s fp32 matrix peak;
-  cpu_baseline -- the CPU oracle (restatement of the reference) timed on this box's host cores on a
-                  bounded sample, extrapolated to the job, N = 1 only.
+Besides the contract's keys the JSON line carries
+  roofline      the own kernel with the most time in the timed jobs: algorithmic flop per launch / HIP-event time of
+                its launches inside the timed region, against the 157.3 TFLOP/s fp32 matrix peak (+ roofline_other);
+  cpu_baseline  the CPU oracle (restatement of the reference) on this box's host cores, bounded sample, N = 1 only;
+  phases_s      one more (untimed, synchronised) job split into spec / matching / LAP / merge + set-up / updates;
+  alt_solver    the closed-form PLeaS phase (solver="normal_eq": MFMA normal equations + batched Cholesky), N = 1;
+  vendor        the frozen source forwards of the PLeaS phase (vendor convolutions + pleas_bn_act) timed alone;
+  checks        invariants of the last timed job's result (permutations valid, losses fell, weights finite).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
 FULL_MATCH, FULL_PLEAS = 100, 401
 T_START = time.time()
 
 
-def log(msg):
-    if int(os.environ.get("RANK", "0")) == 0:
-        print("[bench %7.1fs] %s" % (time.time() - T_START, msg), file=sys.stderr, flush=True)
+def parse(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3, help="timed jobs (a step is one whole matching + PLeaS job)")
+    ap.add_argument("--warmup", type=int, default=1, help="untimed jobs before the timed ones")
+    ap.add_argument("--arch", default="resnet101")
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--ratio", type=float, default=0.0)
+    ap.add_argument("--match-batches", type=int, default=FULL_MATCH, help="debug: matching batches per job (default 100)")
+    ap.add_argument("--updates", type=int, default=FULL_PLEAS, help="debug: PLeaS updates per job (default 401)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt-solver", action="store_true", help="skip the closed-form (normal equations) leg")
+    ap.add_argument("--no-phases", action="store_true", help="skip the extra synchronised job that fills phases_s")
+    ap.add_argument("--phase-log", action="store_true", help="debug: log the phases of that job as they finish")
+    ap.add_argument("--prefetch-groups", type=int, default=24,
+                    help="groups of source forwards enqueued while the LAP kernel runs (0: none); also bounded by memory")
+    ap.add_argument("--grad-buckets", type=int, default=1, help="data parallel: 1 (default) = one all-reduce per update; "
+                    "2 = the gradient arena is all-reduced in two halves, each beside the other half's kernels")
+    ap.add_argument("--prefetch-memory", type=float, default=0.7, help="share of the free HBM the prefetched taps may take")
+    ap.add_argument("--emulate-allreduce-us", type=float, default=0.0,
+                    help="with --emulate-world: hold the update stream this long where the gradient all-reduce would run")
+    ap.add_argument("--lookahead", type=int, default=-1, help="1: the next group's source forwards are enqueued before the "
+                    "current group's PLeaS updates and share the GPU with them; 0: one group at a time; -1 (default): 0 on "
+                    "one GPU, 1 under data parallelism (fills the all-reduce gaps)")
+    ap.add_argument("--profile-all", action="store_true", help="also bracket the many-launch elementwise kernel "
+                    "(bn_act) with events: complete kernels_ms, slightly slower timed region")
+    ap.add_argument("--cpu-sample-batch", type=int, default=4)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
+                                                      "the multi-rank logic on a single GPU)")
+    ap.add_argument("--all-ranks-on-gpu0", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="profiling aid, single process: time rank 0's share of an N-rank job with the collectives "
+                         "skipped (PLEAS_EMULATE_WORLD); the line is tagged emulated and is NOT a benchmark result")
+    return ap.parse_args(argv)
+
+
+def self_launch(args) -> int:
+    """``python bench.py --gpus N`` without a launcher: start ``torch.distributed.run`` with N ranks as a CHILD process
+    (this process has not touched the GPU and never will) and return its exit status.  Rank 0 prints the JSON line."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] --gpus %d without a launcher: starting %s" % (args.gpus, " ".join(cmd[1:8])), file=sys.stderr, flush=True)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // max(1, args.gpus))))
+    return subprocess.call(cmd, env=env)
 
 
 def usable_cores():
@@ -59,46 +109,18 @@ def usable_cores():
     return n
 
 
-def parse():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=FULL_MATCH + FULL_PLEAS)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--arch", default="resnet101")
-    ap.add_argument("--batch", type=int, default=16)
-    ap.add_argument("--ratio", type=float, default=0.0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--phase-log", action="store_true", help="debug: synchronise and log the duration of each job phase")
-    ap.add_argument("--prefetch-groups", type=int, default=24,
-                    help="groups of source forwards enqueued while the LAP kernel runs (0: none); also bounded by memory")
-    ap.add_argument("--grad-buckets", type=int, default=1, help="data parallel: 1 (default) = one all-reduce per update; "
-                    "2 = the gradient arena is all-reduced in two halves, each beside the other half's kernels")
-    ap.add_argument("--prefetch-memory", type=float, default=0.7, help="share of the free HBM the prefetched taps may take")
-    ap.add_argument("--emulate-allreduce-us", type=float, default=0.0,
-                    help="with --emulate-world: hold the update stream this long where the gradient all-reduce would run")
-    ap.add_argument("--lookahead", type=int, default=-1, help="1: the next group's source forwards are enqueued before the "
-                    "current group's PLeaS updates and share the GPU with them (PleasFitter.steps(lookahead=True): about "
-                    "-3 %% wall-clock on one GPU, but per-kernel durations then include the contention); 0: one group at a "
-                    "time; -1 (default): 0 on one GPU, 1 under data parallelism (fills the all-reduce gaps)")
-    ap.add_argument("--profile-all", action="store_true", help="also bracket the many-launch elementwise kernel "
-                    "(bn_act) with events: complete phases_ms, slightly slower timed region")
-    ap.add_argument("--cpu-sample-batch", type=int, default=2)
-    ap.add_argument("--alt-solver", action="store_true", help="also time the closed-form PLeaS phase "
-                                                              "(solver=normal_eq) after the headline run")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
-                                                      "the multi-rank logic on a single GPU)")
-    ap.add_argument("--all-ranks-on-gpu0", action="store_true", help="rehearsal only: every rank uses cuda:0")
-    ap.add_argument("--emulate-world", type=int, default=0,
-                    help="profiling aid, single process: time rank 0's share of an N-rank job with the collectives "
-                         "skipped (PLEAS_EMULATE_WORLD); the line is tagged emulated and is NOT a benchmark result")
-    return ap.parse_args()
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
+    _early = parse()
+    if _early.gpus > 1:          # before `import torch`: the parent stays free of any GPU state
+        sys.exit(self_launch(_early))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 
-def split_steps(k):
-    if k >= FULL_MATCH + FULL_PLEAS:
-        return FULL_MATCH, k - FULL_MATCH
-    n_match = max(1, round(k * FULL_MATCH / (FULL_MATCH + FULL_PLEAS)))
-    return n_match, max(1, k - n_match)
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %7.1fs] %s" % (time.time() - T_START, msg), file=sys.stderr, flush=True)
 
 
 class Pool:
@@ -132,75 +154,89 @@ def build_models(arch, device, batch):
     return models
 
 
-def run_job(spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, ratio, dp, lookahead=None, prefetch_groups=24):
-    """The timed hot path.  Returns (merged model, perm, costs)."""
-    from pleas_merging_amd.methods.activation_matching import activation_matching
+class Phases:
+    """Wall-clock of the job's phases.  Only the extra job after the timed ones uses it: every boundary synchronises the
+    device, which removes the overlap between phases (LAP beside prefetched source forwards), so the phases add up to
+    slightly more than a timed job."""
+
+    def __init__(self, on=False, verbose=False):
+        self.on, self.verbose, self.t, self.out = on, verbose, time.perf_counter(), {}
+
+    def mark(self, name):
+        if not self.on:
+            return
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        self.out[name] = round(self.out.get(name, 0.0) + now - self.t, 4)
+        if self.verbose:
+            log("phase %-28s %.3f s" % (name, now - self.t))
+        self.t = now
+
+
+def run_job(cfg, spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, phases=None):
+    """The timed hot path: activation matching (+ LAP) -> partial merge -> PLeaS updates.  Returns a dict with the merged
+    model, the permutation, the costs and the per-layer losses of the first and last update (device tensors)."""
+    from pleas_merging_amd.core.solvers import hip_solve_lsa
+    from pleas_merging_amd import hip_ops
+    from pleas_merging_amd.methods.activation_matching import accumulate_costs_fused, activation_matching, solve_all
     from pleas_merging_amd.methods.partial_matching import partial_merge
     from pleas_merging_amd.methods.pleas_merging import FrozenSources, PleasFitter
 
-    # The frozen sources of the PLeaS phase do not depend on the permutation: while the batched LAP kernel runs (0.28 s, one
+    phases = phases or Phases()
+    dp = cfg["dp"]
+    # The frozen sources of the PLeaS phase do not depend on the permutation: while the batched LAP kernel runs (one
     # workgroup per problem), the host builds their fused forwards and enqueues the first groups of source forwards on
     # the side streams, where they also fill the GPU's idle time during partial merge and fitter set-up.
     early = {}
     inputs = [x for x, _ in pleas_loader]
 
     def while_solving():
-        t0 = time.perf_counter()
         early["sources"] = src = FrozenSources(m1, m2, data_parallel=dp)
-        t1 = time.perf_counter()
-        st0 = torch.cuda.memory_stats() if PHASE_LOG else None
-        if PHASE_LOG and os.environ.get("PLEAS_BENCH_PROFILE_PREFETCH"):
-            import cProfile, pstats
-            pr = cProfile.Profile()
-            pr.enable()
-            n = src.prefetch(inputs, max_groups=prefetch_groups, memory_fraction=PREFETCH_MEMORY)
-            pr.disable()
-            pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(12)
-        else:
-            n = src.prefetch(inputs, max_groups=prefetch_groups, memory_fraction=PREFETCH_MEMORY)
-        if PHASE_LOG:
-            st1 = torch.cuda.memory_stats()
-            log("host, while the LAP kernel runs: source set-up %.3f s, %d batches' source forwards enqueued in %.3f s "
-                "(allocator: %d new segments, reserved %+.1f GB, %d retries)"
-                % (t1 - t0, n, time.perf_counter() - t1, st1["segment.all.allocated"] - st0["segment.all.allocated"],
-                   (st1["reserved_bytes.all.current"] - st0["reserved_bytes.all.current"]) / 1e9,
-                   st1["num_alloc_retries"] - st0["num_alloc_retries"]))
+        src.prefetch(inputs, max_groups=cfg["prefetch_groups"], memory_fraction=cfg["prefetch_memory"])
 
-    def logged(loader):        # --phase-log: time of every 10 matching batches (synchronising)
-        for i, item in enumerate(loader):
-            if i % 10 == 0:
-                phase("matching: batches up to %d" % i)
-            yield item
-
-    perm, costs = activation_matching(spec, m1, m2, logged(match_loader) if PHASE_LOG else match_loader, len(match_loader),
-                                      output_costs=True, while_solving=while_solving)
-    phase("matching (rest) + LAP")
-    m3 = partial_merge(spec, m1, m2, perm, costs, ratio, device=next(m1.parameters()).device)   # stays on the GPU
+    if phases.on:      # the same two calls activation_matching() makes, with a synchronising boundary between them
+        costs = accumulate_costs_fused(spec, m1, m2, match_loader, len(match_loader), hip_ops.EPI_NEG_CDIST)
+        phases.mark("matching")
+        perm = solve_all(costs, hip_solve_lsa, while_solving)
+        phases.mark("lap")
+    else:
+        perm, costs = activation_matching(spec, m1, m2, match_loader, len(match_loader), output_costs=True,
+                                          while_solving=while_solving)
+    m3 = partial_merge(spec, m1, m2, perm, costs, cfg["ratio"], device=next(m1.parameters()).device)   # stays on the GPU
     # Data parallel: each rank's share of an update is small (batch / world samples); the frozen sources therefore forward
     # 2 * world updates' samples at once (steps() default), which keeps their host dispatch off the per-update path.
-    # (Replaying them from a hipGraph costs the host MORE than dispatching them: 9.6 ms per replay of ~600 nodes.)
-    fit = PleasFitter(m1, m2, m3, spec, perm, costs, ratio, n_pleas_sched, data_parallel=dp, sources=early.get("sources"),
-                      grad_buckets=GRAD_BUCKETS)
-    phase("partial merge + fitter set-up")
-    for _ in fit.steps(inputs, lookahead=lookahead):
-        pass
-    phase("%d updates" % len(inputs))
-    return fit.finish(), perm, costs
+    fit = PleasFitter(m1, m2, m3, spec, perm, costs, cfg["ratio"], n_pleas_sched, data_parallel=dp,
+                      sources=early.get("sources"), grad_buckets=cfg["grad_buckets"])
+    phases.mark("merge_and_setup")
+    first = None
+    for i in fit.steps(inputs, lookahead=cfg["lookahead"]):
+        if i == 0:
+            first = fit.loss_now.clone()
+    last = fit.loss_now.clone()
+    phases.mark("updates")
+    m3 = fit.finish()
+    phases.mark("finish")
+    return {"m3": m3, "perm": perm, "costs": costs, "first_loss": first, "last_loss": last, "layers": len(fit.plans)}
 
 
-PHASE_LOG = False
-PREFETCH_MEMORY = 0.7
-GRAD_BUCKETS = 1
-_phase_t = [0.0]
-
-
-def phase(name):
-    """--phase-log: synchronise and log the time since the previous phase boundary (perturbs the pipeline slightly)."""
-    if PHASE_LOG:
-        torch.cuda.synchronize()
-        now = time.perf_counter()
-        log("phase %-32s %.3f s" % (name, now - _phase_t[0]))
-        _phase_t[0] = now
+def check_result(spec, res):
+    """Cheap invariants of a job's result (no oracle at this size inside the bench; tests/test_hip_fullsize.py compares
+    the same calls with the CPU oracle at batch 2)."""
+    out = {}
+    perms_ok = all(sorted(res["perm"][k].tolist()) == list(range(spec[k].size)) for k in spec)
+    out["perms_are_permutations"] = bool(perms_ok and len(res["perm"]) == len(spec))
+    out["costs_finite"] = bool(all(torch.isfinite(v).all().item() for v in res["costs"].values()))
+    first, last = res["first_loss"].double().cpu(), res["last_loss"].double().cpu()
+    out["loss_first_update"] = float(first.sum())
+    out["loss_last_update"] = float(last.sum())
+    # the stem's loss is rounding noise (DESIGN.md section 1); every other layer must have come down
+    fell = int((last[1:] < first[1:]).sum())
+    out["layers_whose_loss_fell"] = "%d / %d" % (fell, first.numel() - 1)
+    out["weights_finite"] = bool(all(torch.isfinite(v).all().item() for v in res["m3"].state_dict().values()
+                                     if v.dtype.is_floating_point))
+    out["ok"] = bool(out["perms_are_permutations"] and out["costs_finite"] and out["weights_finite"]
+                     and out["loss_last_update"] < out["loss_first_update"] and fell >= 0.9 * (first.numel() - 1))
+    return out
 
 
 def time_normal_eq(spec, m1, m2, perm, costs, loader, ratio):
@@ -234,12 +270,78 @@ def time_normal_eq(spec, m1, m2, perm, costs, loader, ratio):
     rec = p.get("normal_eq", (0, 0.0, 0.0, 0.0))
     ach = rec[2] / (rec[1] * 1e-3) / 1e12 if rec[1] > 0 else 0.0
     return {"solver": "normal_eq", "batches": len(loader), "accumulate_s": round(t1 - t0, 3), "solve_s": round(t2 - t1, 3),
-            "neq_batch_kernel": {"launches": rec[0], "avg_launch_us": round(rec[1] * 1e3 / max(rec[0], 1), 1),
-                                 "achieved_tflops": round(ach, 1), "frac_of_fp32_mfma_peak": round(ach / FP32_MATRIX_PEAK_TFLOPS, 3),
-                                 "note": "flops counted for the lower block triangle only (K^2 * N*HWo per layer)"}}
+            "neq_batch_kernel": {"bound": "mfma", "launches": rec[0], "avg_launch_us": round(rec[1] * 1e3 / max(rec[0], 1), 1),
+                                 "achieved": round(ach, 1), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": round(ach / FP32_MATRIX_PEAK_TFLOPS, 3),
+                                 "note": "MFMA utilisation of the normal-equations GEMMs; flops counted for the lower "
+                                         "block triangle only (K^2 * N*HWo per layer)"}}
 
 
-def gram_flops_per_sample(spec, m1, device):
+def time_sources_alone(m1, m2, pool, n_updates, groups=6):
+    """The frozen source forwards of the PLeaS phase (vendor convolutions + pleas_bn_act, both models on two streams,
+    32 samples per forward) with nothing else on the GPU, scaled to the job's updates."""
+    from pleas_merging_amd.methods.pleas_merging import FrozenSources
+
+    src = FrozenSources(m1, m2)
+    per = 2
+    for timed in (False, True):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for g in range(groups):
+            src.launch_group([pool.items[(per * g + i) % len(pool.items)] for i in range(per)])
+            src.queue.clear()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    src.close()
+    per_update = dt / (groups * per)
+    return per_update * n_updates, per_update
+
+
+def cpu_baseline(spec, arch, batch_full, sample_batch, n_match, n_pleas, ratio):
+    """Oracle (CPU restatement of the reference path) on this box's host cores, bounded sample:
+    2 matching batches + 2 PLeaS updates at a reduced batch size, all LAPs, the merge; extrapolated linearly
+    in samples to the job that the GPU ran."""
+    from oracle import pleas_oracle as orc
+    from pleas_merging_amd import resnet as zoo
+
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    log("cpu baseline on %d cores" % cores)
+    models = []
+    for seed in (0, 1):
+        torch.manual_seed(seed)
+        m = zoo.MODELS[arch](num_classes=1000)
+        g = torch.Generator().manual_seed(900)
+        zoo.calibrate_bn(m, [torch.randn(sample_batch, 3, 224, 224, generator=g)])
+        models.append(m)
+    m1, m2 = models
+    g = torch.Generator().manual_seed(1000)
+    data = [(torch.randn(sample_batch, 3, 224, 224, generator=g), None) for _ in range(4)]
+    t0 = time.time()
+    costs = orc.matching_costs(spec, m1, m2, data[:2], 2, accumulate=True)
+    t_match = (time.time() - t0) / 2
+    log("cpu: matching batch %.1fs" % t_match)
+    t0 = time.time()
+    perm = {k: orc.solve_lsa(v) for k, v in costs.items()}
+    t_lap = time.time() - t0
+    t0 = time.time()
+    m3 = orc.partial_merge(spec, m1, m2, perm, costs, ratio)
+    t_merge = time.time() - t0
+    t0 = time.time()
+    orc.train(data[2:4], m1, m2, m3, spec, perm, costs, ratio, 1)
+    t_step = (time.time() - t0) / 2
+    log("cpu: PLeaS update %.1fs" % t_step)
+    scale = batch_full / sample_batch
+    total = n_match * t_match * scale + t_lap + t_merge + n_pleas * t_step * scale
+    return {
+        "value": round(total, 1), "unit": "s", "cores": cores, "kind": "port",
+        "sample": "oracle on %s pair: 2 matching batches (%.1fs each) + 2 PLeaS updates (%.1fs each) at batch %d, all %d "
+                  "LAPs (%.2fs), merge (%.2fs); batches scaled x%.0f to batch %d, then x%d matching + x%d updates"
+                  % (arch, t_match, t_step, sample_batch, len(perm), t_lap, t_merge, scale, batch_full, n_match, n_pleas),
+    }
+
+
+def gram_flops_per_sample(spec, m1):
     """Sum over tracked nodes of 2*C^2*HW; shapes from a meta trace."""
     from pleas_merging_amd.core.compiler import trace_with_shapes
 
@@ -258,55 +360,14 @@ def gram_flops_per_sample(spec, m1, device):
     return flops, byts
 
 
-def cpu_baseline(spec, arch, batch_full, sample_batch, n_match, n_pleas, ratio):
-    """Oracle (CPU restatement of the reference path) on this box's host cores, bounded sample:
-    1 matching batch + 1 PLeaS update at a reduced batch size, all LAPs; extrapolated linearly
-    in samples to the job that the GPU ran."""
-    from oracle import pleas_oracle as orc
-    from pleas_merging_amd import resnet as zoo
-
-    cores = usable_cores()
-    torch.set_num_threads(cores)
-    log("cpu baseline on %d cores" % cores)
-    models = []
-    for seed in (0, 1):
-        torch.manual_seed(seed)
-        m = zoo.MODELS[arch](num_classes=1000)
-        g = torch.Generator().manual_seed(900)
-        zoo.calibrate_bn(m, [torch.randn(sample_batch, 3, 224, 224, generator=g)])
-        models.append(m)
-    m1, m2 = models
-    g = torch.Generator().manual_seed(1000)
-    data = [(torch.randn(sample_batch, 3, 224, 224, generator=g), None) for _ in range(2)]
-    t0 = time.time()
-    costs = orc.matching_costs(spec, m1, m2, data[:1], 1, accumulate=True)
-    t_match = time.time() - t0
-    log("cpu: matching batch %.1fs" % t_match)
-    t0 = time.time()
-    perm = {k: orc.solve_lsa(v) for k, v in costs.items()}
-    t_lap = time.time() - t0
-    t0 = time.time()
-    m3 = orc.partial_merge(spec, m1, m2, perm, costs, ratio)
-    t_merge = time.time() - t0
-    t0 = time.time()
-    orc.train(data[1:2], m1, m2, m3, spec, perm, costs, ratio, 1)
-    t_step = time.time() - t0
-    log("cpu: PLeaS update %.1fs" % t_step)
-    scale = batch_full / sample_batch
-    total = n_match * t_match * scale + t_lap + t_merge + n_pleas * t_step * scale
-    return {
-        "value": round(total, 1), "unit": "s", "cores": cores, "kind": "port",
-        "sample": "oracle on %s pair: 1 matching batch (%.1fs) + 1 PLeaS update (%.1fs) at batch %d, all %d LAPs "
-                  "(%.2fs), merge (%.2fs); batches scaled x%.0f to batch %d, then x%d matching + x%d updates"
-                  % (arch, t_match, t_step, sample_batch, len(perm), t_lap, t_merge, scale, batch_full, n_match, n_pleas),
-    }
-
-
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d (start N ranks with torch.distributed.run, or run "
+                         "`python bench.py --gpus N` without a launcher and it starts them itself)" % (world, args.gpus))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.all_ranks_on_gpu0:
@@ -315,7 +376,6 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(args.backend)
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
@@ -328,78 +388,91 @@ def main():
     if world > 1:
         dist.barrier()
 
-    global PREFETCH_MEMORY, GRAD_BUCKETS
-    PREFETCH_MEMORY = args.prefetch_memory
-    GRAD_BUCKETS = args.grad_buckets
-    n_match, n_pleas = split_steps(args.steps)
+    n_match, n_pleas = max(1, args.match_batches), max(1, args.updates)
     full = (n_match, n_pleas) == (FULL_MATCH, FULL_PLEAS)
-    n_sched = n_pleas - 1  # CosineAnnealingLR(T_max=MAX_STEPS) with MAX_STEPS + 1 updates
+    n_sched = max(1, n_pleas - 1)  # CosineAnnealingLR(T_max=MAX_STEPS) with MAX_STEPS + 1 updates
     m1, m2 = build_models(args.arch, device, args.batch)
     log("models built + BN calibrated")
+    t0 = time.perf_counter()
     spec = get_permutation_spec(m1, ((1, 3, 224, 224),))
-    # the PLeaS loop runs the frozen sources on groups of 2 * ranks updates and enqueues up to --prefetch-groups of them
-    # while the LAP kernel runs: a warm-up of one more update than that meets both forward sizes (a group and a single)
-    # and leaves the caching allocator with the blocks those prefetched generations need, so the vendor library's first-use set-up for a shape never lands in the timed region
+    spec_s = time.perf_counter() - t0
     ranks = max(world, args.emulate_world)
-    warm_updates = max(args.warmup, 2 * ranks * max(1, args.prefetch_groups) + 1) if args.warmup > 0 else 0
-    pool = Pool(max(n_match, n_pleas, args.warmup + 1, warm_updates), args.batch, device)
+    pool = Pool(max(n_match, n_pleas), args.batch, device)
     dp = world > 1
     if args.emulate_world > 1:
         assert world == 1, "--emulate-world is a single-process aid"
         os.environ["PLEAS_EMULATE_WORLD"] = str(args.emulate_world)
         os.environ["PLEAS_EMULATE_ALLREDUCE_US"] = str(args.emulate_allreduce_us)
         dp = True
-    log("spec (%d groups) + %d synthetic batches resident" % (len(spec), len(pool.items)))
+    cfg = {"dp": dp, "ratio": args.ratio, "prefetch_groups": args.prefetch_groups, "prefetch_memory": args.prefetch_memory,
+           "grad_buckets": args.grad_buckets, "lookahead": None if args.lookahead < 0 else bool(args.lookahead)}
+    log("spec (%d groups, %.2f s on the host, outside `value`) + %d synthetic batches resident" % (len(spec), spec_s, len(pool.items)))
 
-    # ---- warm-up: W matching batches + W updates on throw-away state (MIOpen find, allocator, graph build)
-    if args.warmup > 0:
-        if dp:
-            # torch's MIOpen binding empties the caching allocator whenever it meets a convolution configuration for the
-            # first time.  The only source-forward size the warm-up job meets LATE is the one left-over update at its end
-            # (batch / ranks samples): met there, it would release the pools the job has just filled, and the timed job
-            # would go back to hipMalloc for 120 GB of taps (1.3 s at 8 ranks).  So that size goes first.
-            from pleas_merging_amd.methods.pleas_merging import FrozenSources
+    def job(phases=None):
+        return run_job(cfg, spec, m1, m2, pool.loader(0, n_match), pool.loader(0, n_pleas), n_sched, phases)
 
-            early = FrozenSources(m1, m2, data_parallel=True)
-            early.launch(pool.items[0])
-            torch.cuda.synchronize()
-            early.close()
-            del early
-        run_job(spec, m1, m2, pool.loader(0, args.warmup * ranks), pool.loader(0, warm_updates), max(1, warm_updates - 1),
-                args.ratio, dp, None if args.lookahead < 0 else bool(args.lookahead), args.prefetch_groups)
+    # ---- warm-up: W whole jobs on throw-away state (MIOpen find, allocator pools, twin-graph build paths)
+    if args.warmup > 0 and dp:
+        # torch's MIOpen binding empties the caching allocator whenever it meets a convolution configuration for the
+        # first time.  The only source-forward size a job meets LATE is the one left-over update at its end
+        # (batch / ranks samples): met there, it would release the pools the job has just filled.  So that size goes first.
+        from pleas_merging_amd.methods.pleas_merging import FrozenSources
 
-    log("warm-up done")
-    # ---- timed region.  Events bracket the few-launches-per-step kernels only: bn_act runs ~200 times per step and would
-    # pay two event records per launch inside the timed region.
+        early = FrozenSources(m1, m2, data_parallel=True)
+        early.launch(pool.items[0])
+        torch.cuda.synchronize()
+        early.close()
+        del early
+    for w in range(args.warmup):
+        job()
+        torch.cuda.synchronize()
+        log("warm-up job %d done" % (w + 1))
+
+    # ---- timed region: exactly K jobs.  Events bracket the few-launches-per-step kernels only: bn_act runs ~200 times per
+    # update and would pay two event records per launch inside the timed region.
     hip_ops.profile_reset()
     hip_ops.profile_enable(True, skip=() if args.profile_all else ("bn_act",))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    global PHASE_LOG
-    PHASE_LOG = bool(args.phase_log)
-    _phase_t[0] = time.perf_counter()
+    per_job, res = [], None
     t0 = time.perf_counter()
-    m3, perm, costs = run_job(spec, m1, m2, pool.loader(0, n_match), pool.loader(0, n_pleas), max(1, n_sched), args.ratio, dp,
-                              None if args.lookahead < 0 else bool(args.lookahead), args.prefetch_groups)
-    torch.cuda.synchronize()
+    for k in range(args.steps):
+        tj = time.perf_counter()
+        res = job()
+        torch.cuda.synchronize()
+        per_job.append(time.perf_counter() - tj)
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     hip_ops.profile_enable(False)
-    log("timed region: %.3fs  (HBM reserved by the caching allocator: peak %.1f GB)"
-        % (elapsed, torch.cuda.max_memory_reserved(device) / 1e9))
+    log("timed region: %d jobs in %.3fs (per job: %s; HBM reserved by the caching allocator: peak %.1f GB)"
+        % (args.steps, elapsed, " ".join("%.3f" % t for t in per_job), torch.cuda.max_memory_reserved(device) / 1e9))
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    value = elapsed / max(1, args.steps)
+    prof = hip_ops.profile_collect() if rank == 0 else {}  # the timed jobs' kernels, before anything else is timed
+    checks = check_result(spec, res) if rank == 0 else None
 
-    prof = hip_ops.profile_collect() if rank == 0 else {}  # headline run's kernels, before anything else is timed
-    alt = None
-    if args.alt_solver and world == 1:
-        alt = time_normal_eq(spec, m1, m2, perm, costs, pool.loader(0, n_pleas), args.ratio)
+    # ---- untimed extras (every rank takes part in the phases job: it contains collectives)
+    phases = None
+    if not args.no_phases:
+        ph = Phases(on=True, verbose=args.phase_log)
+        job(ph)
+        phases = dict(ph.out)
+    alt = vendor = None
+    if world == 1 and args.emulate_world <= 1:
+        if not args.no_alt_solver:
+            alt = time_normal_eq(spec, m1, m2, res["perm"], res["costs"], pool.loader(0, n_pleas), args.ratio)
+            log("closed form: accumulate %.2fs, solve %.2fs" % (alt["accumulate_s"], alt["solve_s"]))
+        src_s, src_per = time_sources_alone(m1, m2, pool, n_pleas)
+        vendor = {"source_forwards_alone_s_per_job": round(src_s, 3), "ms_per_update": round(src_per * 1e3, 3),
+                  "share_of_value": round(src_s / value, 3),
+                  "note": "frozen source forwards of the PLeaS phase (MIOpen / Tensile convolutions + pleas_bn_act, both "
+                          "models, 32 samples per forward) with nothing else on the GPU; rocprofv3 kernel shares: profiles/"}
     if rank == 0:  # {kernel: (launches, total_ms, flops, bytes)}
-        log("profile events collected")
         labels = {
             "gram_partial": "gram_batch_kernel (grouped fp32 MFMA 32x32x2 contraction, one launch per matching batch)",
             "conv_wgrad": "wgrad_batch_kernel (grouped fp32 MFMA 32x32x2 weight gradients, one launch per PLeaS update)",
@@ -424,29 +497,34 @@ def main():
             roofs["gram_partial"]["path_equivalent"] = {
                 "flop_per_launch": per_launch, "tflops": round(per_launch / (us * 1e-6) / 1e12, 2) if us else 0.0,
                 "note": "all 344 tracked nodes as the reference contracts them; 240 are contracted here, 104 derived"}
-        # HBM-side bytes per launch from rocprofv3 PMC passes on standalone replays of the same grids (profiles/)
+        # HBM-side bytes per launch: rocprofv3 PMC passes on standalone replays of the same grids (profiles/*_traffic.json,
+        # FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); a counter pass cannot run inside this process
         for key, fname in (("gram_partial", "gram_traffic.json"), ("conv_fwd", "fwd_traffic.json"),
                            ("conv_wgrad", "wgrad_traffic.json")):
             tpath = os.path.join(ROOT, "profiles", fname)
-            if os.path.exists(tpath) and args.arch == "resnet101" and args.batch == 16:
+            if os.path.exists(tpath) and args.arch == "resnet101" and args.batch == 16 and world == 1:
                 roofs[key]["traffic"] = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                roofs[key]["traffic_source"] = "profiles/" + fname
         dominant = max(roofs, key=lambda k: roofs[k]["total_ms"])   # own kernel with the most time in the timed region
         roofline = roofs[dominant]
         other = {k: v for k, v in roofs.items() if k != dominant}
-        steps = n_match + n_pleas
+        srt = sorted(per_job)
         out = {
             "metric": "wall-clock (s): ResNet-101 pair, 100-batch act-match + 400-step PLeaS, 1/8 GPU"
             if args.arch == "resnet101" else "wall-clock (s): %s pair, act-match + PLeaS" % args.arch,
-            "value": round(elapsed, 3), "unit": "s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed * 1e3 / steps, 3), "higher_is_better": False, "scaling": "strong",
+            "value": round(value, 4), "unit": "s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(value * 1e3, 2), "higher_is_better": False, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "%s pair (random init, BN calibrated), %d matching batches + LAP (%d groups) + partial merge "
-                            "(ratio %.2f) + %d PLeaS Adam updates, batch %d x 3x224x224%s"
+                "workload": "%s pair (random init, BN calibrated), ONE JOB per step: %d matching batches + LAP (%d groups) + "
+                            "partial merge (ratio %.2f) + %d PLeaS Adam updates, batch %d x 3x224x224%s"
                             % (args.arch, n_match, len(spec), args.ratio, n_pleas, args.batch,
-                               "" if full else " (SHORTENED job: --steps %d)" % args.steps),
+                               "" if full else " (SHORTENED job: not a benchmark result)"),
                 "solver": "adam", "parallelism": "dp%d" % world,
+                "not_in_value": "get_permutation_spec %.2f s (host, once per model)" % spec_s,
             },
+            "job_s": {"mean": round(value, 4), "median": round(srt[len(srt) // 2], 4), "min": round(srt[0], 4),
+                      "max": round(srt[-1], 4), "note": "rank 0's per-job times; value = bracketed total / steps"},
             "roofline": roofline,
             "roofline_other": other,
         }
@@ -458,13 +536,25 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.emulate_world <= 1:
             out["cpu_baseline"] = cpu_baseline(spec, args.arch, args.batch, args.cpu_sample_batch, n_match, n_pleas,
                                                args.ratio)
-        if args.alt_solver and world == 1:
+        if phases is not None:
+            phases = {"spec": round(spec_s, 4), **phases,
+                      "note": "one extra job with a device synchronisation at every boundary (phases cannot overlap "
+                              "there, so they add up to a little more than `value`); spec is outside `value`"}
+            out["phases_s"] = phases
+        if alt is not None:
             out["alt_solver"] = alt
-        out["phases_ms"] = {k: {"launches": v[0], "total_ms": round(v[1], 2)} for k, v in sorted(prof.items())}
-        print(json.dumps(out))
+        if vendor is not None:
+            out["vendor"] = vendor
+        out["checks"] = checks
+        out["kernels_ms"] = {k: {"launches": v[0], "total_ms": round(v[1], 2)} for k, v in sorted(prof.items())}
+        print(json.dumps(out), flush=True)
+        if not checks["ok"]:
+            log("RESULT CHECK FAILED: %r" % (checks,))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and not checks["ok"]:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

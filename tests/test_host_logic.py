@@ -503,3 +503,31 @@ def test_get_blocks_memo_sees_in_place_changes():
     changed = get_blocks(spec, perm, costs, 0.5)
     assert changed[ax][0].tolist() == [0, 2] and changed[ax][2].tolist() == [1, 3]
     assert get_blocks(spec, perm, costs, 0.25)[ax][0].tolist() == [0, 1, 2]     # another ratio is another key
+
+
+def test_bench_starts_its_own_ranks_without_touching_the_gpu(monkeypatch):
+    """`python bench.py --gpus N` without a launcher: the parent builds a torch.distributed.run command for N ranks on
+    127.0.0.1 and hands over its own arguments; with WORLD_SIZE set (the driver's launch) nothing is re-launched."""
+    import importlib
+    import subprocess
+    import sys
+
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2", "--warmup", "1"])
+    rc = bench.self_launch(bench.parse(["--gpus", "4", "--steps", "2", "--warmup", "1"]))
+    assert rc == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # defaults finish within minutes: a step is one whole job (~6.5 s), 1 warm-up + 3 timed
+    d = bench.parse([])
+    assert (d.gpus, d.steps, d.warmup, d.match_batches, d.updates) == (1, 3, 1, 100, 401)

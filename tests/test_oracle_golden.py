@@ -133,3 +133,34 @@ def test_train_adam(tiny_basic, ratio, steps):
     for k in want:
         rel = (got[k].float() - want[k].float()).norm() / (want[k].float().norm() + 1e-12)
         assert rel < 1e-5, (k, float(rel))
+
+
+# ------------------------------------------------------------------ degenerate stem: the reference against itself
+@pytest.mark.parametrize("ratio,steps", [(0.0, 5), (0.0, 20), (0.5, 5), (0.5, 20)])
+def test_reference_disagrees_with_itself_on_the_stem_only(tiny_basic, ratio, steps):
+    """tests/golden/stem_spread.npz (make_golden_stem.py: the reference's train() under 1 / 4 / 8 threads and with
+    oneDNN convolutions off).  Its trained ``conv1.weight`` differs between variants by more than its whole travel
+    from the merged initial value, while every other tensor agrees to < 1e-6 rel-fro -- which is why the HIP path's
+    stem is gated by tests/stem_gate.py and not weight for weight.  Every variant passes that gate against the others."""
+    import numpy as np
+    from stem_gate import GOLDEN, gate_stem, reference_stems, stem_objective
+
+    t = tiny_basic
+    z = np.load(os.path.join(GOLDEN, "stem_spread.npz"))
+    tag = "r%03d_s%d" % (int(ratio * 100), steps)
+    init, refs = reference_stems(ratio, steps)
+    assert torch.equal(refs[0], t.state("trained_" + tag)["conv1.weight"])       # variant 0 is the fixture's run
+    spread = max(float((a - b).abs().max()) for i, a in enumerate(refs) for b in refs[i + 1:])
+    travel = max(float((r - init).abs().max()) for r in refs)
+    assert spread > 0.5 * travel > 5e-5, (spread, travel)
+    assert spread <= 2 * 5e-4 * (steps + 1)
+    for name in z["variants"]:
+        assert float(z["others_worst_rel_%s/%s" % (tag, name)]) < 1e-6
+    perm, costs = t.per_key("am_perm"), t.per_key("am_cost")
+    obj = lambda w: stem_objective(t.m1, t.m2, w, t.spec, perm, costs, ratio, t.batches("xt")[:steps + 1], 10)
+    for i, r in enumerate(refs):
+        gate_stem(r, init, refs[:i] + refs[i + 1:], obj, what="variant %d" % i)
+    # the oracle (same CPU kernels as variant 0) lands on variant 0
+    m3 = orc.partial_merge(t.spec, t.m1, t.m2, perm, costs, ratio)
+    m3, _ = orc.train(t.batches("xt"), t.m1, t.m2, m3, t.spec, perm, costs, ratio, steps, num_classes=10)
+    gate_stem(m3.state_dict()["conv1.weight"], init, refs, obj, what="oracle")
