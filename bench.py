@@ -219,7 +219,7 @@ def run_job(cfg, spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, phases
     return {"m3": m3, "perm": perm, "costs": costs, "first_loss": first, "last_loss": last, "layers": len(fit.plans)}
 
 
-def check_result(spec, res):
+def check_result(spec, res, full=True):
     """Cheap invariants of a job's result (no oracle at this size inside the bench; tests/test_hip_fullsize.py compares
     the same calls with the CPU oracle at batch 2)."""
     out = {}
@@ -234,8 +234,9 @@ def check_result(spec, res):
     out["layers_whose_loss_fell"] = "%d / %d" % (fell, first.numel() - 1)
     out["weights_finite"] = bool(all(torch.isfinite(v).all().item() for v in res["m3"].state_dict().values()
                                      if v.dtype.is_floating_point))
-    out["ok"] = bool(out["perms_are_permutations"] and out["costs_finite"] and out["weights_finite"]
-                     and out["loss_last_update"] < out["loss_first_update"] and fell >= 0.9 * (first.numel() - 1))
+    out["ok"] = bool(out["perms_are_permutations"] and out["costs_finite"] and out["weights_finite"])
+    if full:   # a handful of updates of a shortened debug job need not bring every layer's loss down
+        out["ok"] = bool(out["ok"] and out["loss_last_update"] < out["loss_first_update"] and fell >= 0.9 * (first.numel() - 1))
     return out
 
 
@@ -454,7 +455,7 @@ def main():
         elapsed = float(t.item())
     value = elapsed / max(1, args.steps)
     prof = hip_ops.profile_collect() if rank == 0 else {}  # the timed jobs' kernels, before anything else is timed
-    checks = check_result(spec, res) if rank == 0 else None
+    checks = check_result(spec, res, full) if rank == 0 else None
 
     # ---- untimed extras (every rank takes part in the phases job: it contains collectives)
     phases = None

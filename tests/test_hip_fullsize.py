@@ -30,7 +30,7 @@ def _rel(a, b):
 class Pair:
     """Two calibrated random-init ResNets on the CPU (oracle side), their spec, data and the oracle's matching."""
 
-    def __init__(self, arch: str, batch: int = 2, n_batches: int = 4):
+    def __init__(self, arch: str, batch: int = 2, n_batches: int = 5):
         from pleas_merging_amd import resnet as zoo
         from pleas_merging_amd.core.compiler import get_permutation_spec
 
@@ -47,6 +47,16 @@ class Pair:
         self.want_perm, self.want_costs = orc.activation_matching(self.spec, self.m1, self.m2, self.data, 2,
                                                                   accumulate=True)
         self._gpu = None
+        self._variant = None
+
+    def variant_matching(self):
+        """The oracle against ITSELF: the same restatement with oneDNN convolutions switched off (another summation order
+        in every convolution of the 101-layer forwards).  Its disagreement with the default run is the yardstick for what
+        any second implementation of the path can be held to at this depth."""
+        if self._variant is None:
+            with torch.backends.mkldnn.flags(enabled=False):
+                self._variant = orc.activation_matching(self.spec, self.m1, self.m2, self.data, 2, accumulate=True)
+        return self._variant
 
     def gpu(self):
         if self._gpu is None:
@@ -67,15 +77,30 @@ def rn50():
     return Pair("resnet50")
 
 
-def _check_matching(p, perm, costs):
+def _value(cost, perm):
+    return float(cost.double().cpu()[torch.arange(len(perm)), perm].sum())
+
+
+def _check_matching(p, perm, costs, max_flipped_groups=4):
+    """Costs within 1e-4 rel-fro of the oracle's in every group.  Assignments: IDENTICAL to the oracle's, except in
+    groups where the optimum is a near-tie that fp32 rounding of the cost matrix decides -- there (i) the HIP assignment
+    is exactly what the oracle's LAP (scipy's algorithm) returns on the HIP cost matrix, i.e. the integer path is exact,
+    and (ii) under the ORACLE's cost matrix its value is within 1e-6 relative of the oracle's optimum.  The oracle flips
+    in the same way against itself (oneDNN off: 9 units of layer4.1.conv2, gap 1e-7; test_oracle_fullsize_spread.py)."""
     assert len(p.spec) == len(perm) == len(costs)
     flips = {}
     for k in p.spec:
         assert _rel(costs[k], p.want_costs[k]) < TOL, (k, _rel(costs[k], p.want_costs[k]))
+        assert sorted(perm[k].tolist()) == list(range(p.spec[k].size)), k
         n = int((perm[k] != p.want_perm[k]).sum())
         if n:
-            flips[str(k)] = n
-    assert not flips, "groups whose assignment differs from the oracle's: %r" % flips
+            assert (orc.solve_lsa(costs[k].cpu()) == perm[k]).all(), k
+            best, mine = _value(p.want_costs[k], p.want_perm[k]), _value(p.want_costs[k], perm[k])
+            gap = (best - mine) / abs(best)
+            assert 0 <= gap < 1e-6, (k, n, gap)
+            flips[str(k)] = (n, gap)
+    assert len(flips) <= max_flipped_groups, flips
+    return flips
 
 
 @pytest.mark.parametrize("derive_bn", [True, False])
@@ -105,59 +130,88 @@ def test_rn101_api_default_equals_oracle(rn101):
         assert sorted(perm[k].tolist()) == list(range(rn101.spec[k].size))
 
 
+LR = 5e-4
+SHARE = 3e-3     # share of coordinates with a visibly different Adam step: the oracle's own worst tensors reach 1.2e-3
+
+
+def _oracle_train(p, ratios, data, updates, num_classes, onednn=True):
+    with torch.backends.mkldnn.flags(enabled=onednn):
+        o3 = orc.partial_merge(p.spec, p.m1, p.m2, p.want_perm, p.want_costs, ratios)
+        merged = {k: v.clone() for k, v in o3.state_dict().items()}
+        o3, losses = orc.train(data, p.m1, p.m2, o3, p.spec, p.want_perm, p.want_costs, ratios, updates - 1,
+                               num_classes=num_classes)
+    assert len(losses) == updates
+    return merged, {k: v.clone() for k, v in o3.state_dict().items()}
+
+
 def _merge_and_train(p, ratios, updates, num_classes=1000):
     """HIP partial_merge + train vs the oracle's, from the ORACLE's perm / costs (so both sides merge the same blocks).
-    Returns (worst rel-fro over non-stem float tensors, its key, merged widths)."""
+
+    Merged state dicts: bit-equal.  Trained tensors: Adam's first updates are sign-like (m / sqrt(v) = +-1), so a
+    coordinate whose gradient is a near-cancellation lands 2 * lr away when rounding flips its sign, and at 101 layers
+    the two source forwards of ANY two convolution implementations differ by 1e-5..1e-4 at the top.  The oracle against
+    itself (oneDNN off) therefore disagrees by up to 1e-3 rel-fro (fc.weight: 306 of 2M entries flipped; measured in
+    test_oracle_fullsize_spread.py).  Gate per tensor:
+      * rel-fro(HIP, oracle) <= max(1e-4, 3 x rel-fro(oracle variant, oracle));
+      * the share of coordinates that took a visibly different step (|delta| > lr / 10) is at most 3e-3 (the oracle's
+        own worst tensors: 1.2e-3) or 3 x the oracle's own share, and all other coordinates together agree to < 1e-4.
+    The kernels themselves are held to fp64 on identical inputs in test_rn101_gradients_vs_fp64_on_identical_taps."""
     from pleas.methods.partial_matching import partial_merge
     from pleas.methods.pleas_merging import train
 
     m1, m2 = p.gpu()
     costs = p.gpu_costs()
-    m3 = partial_merge(p.spec, m1, m2, p.want_perm, costs, ratios)
-    o3 = orc.partial_merge(p.spec, p.m1, p.m2, p.want_perm, p.want_costs, ratios)
-    got, want = m3.state_dict(), o3.state_dict()
-    assert list(got) == list(want)
-    for k in want:
-        assert got[k].shape == want[k].shape, k
-        if want[k].dtype.is_floating_point:
-            assert torch.equal(got[k].cpu(), want[k]), k     # gather / average / halve are exact in fp32
-    widths = {k: v.shape[0] for k, v in got.items() if v.dim() == 4}
-    init = want[DEGENERATE].clone()
     data = p.data[2:2 + updates]
+    m3 = partial_merge(p.spec, m1, m2, p.want_perm, costs, ratios)
+    merged, want = _oracle_train(p, ratios, data, updates, num_classes)
+    _, variant = _oracle_train(p, ratios, data, updates, num_classes, onednn=False)
+    got = m3.state_dict()
+    assert list(got) == list(merged)
+    for k in merged:
+        assert got[k].shape == merged[k].shape, k
+        if merged[k].dtype.is_floating_point:
+            assert torch.equal(got[k].cpu(), merged[k]), k     # gather / average / halve are exact in fp32
+    widths = {k: v.shape[0] for k, v in got.items() if v.dim() == 4}
     m3 = train(data, m1, m2, m3, p.spec, p.want_perm, costs, ratios, False, updates - 1, None, num_classes=num_classes)
-    o3, losses = orc.train(data, p.m1, p.m2, o3, p.spec, p.want_perm, p.want_costs, ratios, updates - 1,
-                           num_classes=num_classes)
-    assert len(losses) == updates
-    got, want = m3.state_dict(), o3.state_dict()
-    worst, at = 0.0, None
+    got = {k: v.cpu() for k, v in m3.state_dict().items()}
+    report = {}
     for k in want:
-        if k != DEGENERATE and want[k].dtype.is_floating_point:
-            r = _rel(got[k], want[k])
-            if r > worst:
-                worst, at = r, k
+        if k == DEGENERATE or not want[k].dtype.is_floating_point:
+            continue
+        r, yard = _rel(got[k], want[k]), _rel(variant[k], want[k])
+        assert r <= max(TOL, 3 * yard), (k, r, yard)
+        stats = []
+        for other in (got[k], variant[k]):
+            d = (other.double() - want[k].double()).abs()
+            affected = d > LR / 10
+            stats.append((float(affected.double().mean()), float((d * ~affected).norm() / (want[k].double().norm() + 1e-30))))
+        (frac, rest), (yfrac, yrest) = stats
+        assert frac <= max(3 * yfrac, SHARE) and rest <= max(TOL, 2 * yrest), (k, stats)
+        if r > TOL:
+            report[k] = (r, yard, frac, yfrac)
     # the stem's residual is rounding noise in the reference itself: layer objective and travel vs the oracle's
     # (tests/stem_gate.py), not weight for weight
-    gate_stem(got[DEGENERATE], init, [want[DEGENERATE]],
+    gate_stem(got[DEGENERATE], merged[DEGENERATE], [want[DEGENERATE], variant[DEGENERATE]],
               lambda w: stem_objective(p.m1, p.m2, w, p.spec, p.want_perm, p.want_costs, ratios, data, num_classes),
               what="stem")
-    return worst, at, widths, got, want
+    print("tensors above 1e-4 (rel-fro, oracle's own spread, affected share, oracle's own share):", report)
+    return widths, got, want
 
 
 @pytest.mark.parametrize("budget", BUDGETS)
 def test_rn101_budget_sweep_partial_merge_and_pleas_vs_oracle(rn101, budget):
     """(b) configs[4]: the five budgets through zip_ratios -> partial_merge -> 2 PLeaS updates.  Merged state dicts are
-    bit-equal to the oracle's; every trained tensor (105 layers, K up to 4608 / 9216 at doubled width) < 1e-4 rel-fro."""
+    bit-equal to the oracle's; every trained tensor (105 layers, K up to 4608 / 9216 at doubled width) within the gate of _merge_and_train."""
     from pleas.methods.extras import zip_ratios
 
     ratios = zip_ratios(rn101.spec, budget, BUDGETS)
     separate = sum(1 for v in ratios.values() if v == 1.0)
     assert (separate == 0) == (budget == 1.0)
-    worst, at, widths, got, want = _merge_and_train(rn101, ratios, 2)
+    widths, got, want = _merge_and_train(rn101, ratios, 2)
     if budget == 2.0:        # every stage separate: widths 2n-1 (the max-cost unit always stays merged)
         assert widths["layer4.2.conv2.weight"] == 1023 and widths["layer3.0.conv3.weight"] == 2047
     if budget == 1.0:
         assert widths["layer4.2.conv2.weight"] == 512 and got["layer4.0.conv2.weight"].shape[1] * 9 == 4608
-    assert worst < TOL, (budget, at, worst)
 
 
 def test_rn50_full_merge_pleas_vs_oracle(rn50):
@@ -168,17 +222,72 @@ def test_rn50_full_merge_pleas_vs_oracle(rn50):
     assert len(rn50.spec) == 37
     perm, costs = activation_matching(rn50.spec, m1, m2, rn50.data, 2, output_costs=True)
     _check_matching(rn50, perm, costs)
-    worst, at, widths, _, _ = _merge_and_train(rn50, 0.0, 2)
-    assert worst < TOL, (at, worst)
+    widths, _, _ = _merge_and_train(rn50, 0.0, 2)
     assert widths["layer4.2.conv3.weight"] == 2048
 
 
 def test_rn101_mixed_ratio_masks_and_frozen_blocks(rn101):
     """Ratio 0.5 in every group: every layer has merged AND separate units (n_merged < Cout), so the transposed
     gradient-mask blocks (reference pleas_merging.py:57-58) are exercised at full size.  3 updates vs the oracle."""
-    worst, at, widths, got, want = _merge_and_train(rn101, 0.5, 3)
+    widths, got, want = _merge_and_train(rn101, 0.5, 3)
     assert widths["layer3.5.conv2.weight"] == 384
-    assert worst < TOL, (at, worst)
+
+
+def test_rn101_gradients_vs_fp64_on_identical_taps(rn101):
+    """The update's own kernels at ResNet-101 size, isolated from the sources' forward rounding: ONE update of the HIP path
+    (grouped merge -> fused MFMA forward + target + residual + loss -> grouped MFMA weight gradient; 105 layers, K up to
+    6912, ratio 0.5 so that every layer has merged and separate units) against fp64 autograd of the reference objective
+    (pleas_merging.py:281-287) evaluated on the SAME source activations, copied from the GPU taps: rel-fro < 2e-5, or
+    within 3x of what fp32 autograd on the CPU reaches against fp64 on that layer."""
+    from copy import deepcopy
+
+    from pleas.methods.partial_matching import partial_merge
+    from pleas.methods.pleas_merging import PleasFitter
+    from pleas_merging_amd.core.utils import get_attr
+
+    p, ratio = rn101, 0.5
+    m1, m2 = p.gpu()
+    m3 = partial_merge(p.spec, m1, m2, p.want_perm, p.gpu_costs(), ratio)
+    fit = PleasFitter(m1, m2, m3, p.spec, p.want_perm, p.gpu_costs(), ratio, 3, num_classes=1000)
+    x = p.data[2][0]
+    fit._run_sources(x.cuda())
+    torch.cuda.synchronize()
+    taps = {n: tuple(t[n].detach().double().cpu() for t in (fit.tap1.inputs, fit.tap2.inputs, fit.tap1.outputs, fit.tap2.outputs))
+            for n in fit.tap1.inputs}
+    fit.tap1.clear()
+    fit.tap2.clear()
+    fit.step(x)
+    torch.cuda.synchronize()
+    blocks = orc.spread_blocks(p.spec, orc.get_blocks(p.spec, p.want_perm, p.want_costs, ratio))
+    worst_g = worst_l = worst_cpu = 0.0
+    kmax = 0
+    for idx, plan in enumerate(fit.plans):
+        ip1, ip2, o1, o2 = taps[plan.name]
+        ip, op = orc.layer_targets(lambda _t, o=o1: o, lambda _t, o=o2: o, blocks, plan.name, ip1, ip2, num_classes=1000)
+        layer = deepcopy(get_attr(m3, plan.name.split("."))).double()
+        for prm in layer.parameters():
+            prm.requires_grad_(True)
+        loss = ((layer(ip) - op) ** 2).mean()
+        grads = torch.autograd.grad(loss, list(layer.parameters()))
+        layer32 = deepcopy(get_attr(m3, plan.name.split("."))).float()       # the same objective in fp32 on the CPU
+        for prm in layer32.parameters():
+            prm.requires_grad_(True)
+        g32 = torch.autograd.grad(((layer32(ip.float()) - op.float()) ** 2).mean(), [layer32.weight])[0]
+        gw = plan.gw.permute(0, 3, 1, 2) if plan.kpos else plan.gw
+        if plan.name != "conv1":        # stem: residual and gradient are rounding noise (DESIGN.md section 1)
+            rg, rg_cpu = _rel(gw, grads[0]), _rel(g32, grads[0])
+            assert rg < max(2e-5, 3 * rg_cpu), (plan.name, tuple(gw.shape), rg, rg_cpu)
+            worst_g, worst_cpu = max(worst_g, rg), max(worst_cpu, rg_cpu)
+            rl = abs(float(fit.loss_now[idx]) - float(loss.detach())) / float(loss.detach())
+            assert rl < 1e-5, (plan.name, rl)
+            worst_l = max(worst_l, rl)
+        if plan.gb is not None:
+            assert _rel(plan.gb, grads[1]) < 2e-5, plan.name
+        kmax = max(kmax, grads[0][0].numel())
+    fit.finish()
+    assert kmax >= 4608
+    print("worst gradient rel-fro vs fp64: HIP %.2e, fp32 CPU autograd %.2e; worst loss rel %.2e, largest K %d"
+          % (worst_g, worst_cpu, worst_l, kmax))
 
 
 def test_rn101_planted_permutation_batch16():
