@@ -165,6 +165,28 @@ int pleas_bn_act(const float* x, const float* scale, const float* shift, const f
 int pleas_bn_act_tracked(const float* x, const float* scale, const float* shift, const float* res, float* y_bn,
                          float* y_sum, float* y, int64_t n, int channels, int64_t inner, int relu, void* stream);
 
+/* Train-mode BatchNorm of the matching forward, folded to the same per-channel affine map.
+ *
+ * Replaces: the BatchNorm2d modules inside the cross module's forward when the caller's models are in train mode --
+ *   which is what both reference drivers do: no .eval() before activation_matching
+ *   (experiments/shared_label_space/run_domainnet.py:172-186, :257-264; pleas/methods/activation_matching.py:119-122
+ *   never touches the mode) -- i.e. torch.nn.functional.batch_norm(training=True): batch statistics for the
+ *   normalisation, running statistics updated as a side effect.
+ *
+ * One streaming pass over x [n][channels][inner] (fp64 accumulation, deterministic two-stage reduce) gives, per channel,
+ *   mean, var_b (biased);  scale = gamma / sqrt(var_b + eps);  shift = beta - mean * scale     (gamma / beta NULL = 1 / 0)
+ * and, when running_mean / running_var are non-NULL,
+ *   running <- (1 - f) running + f {mean, var_b * count / (count - 1)},   f = momentum, or 1 / (batches so far + 1) when
+ *   momentum < 0 (torch's momentum=None);   *num_batches_tracked += 1 when non-NULL.
+ * The chain's values then come from pleas_bn_act_tracked(x, scale, shift, ...) exactly as in eval mode.
+ * ws: >= pleas_bn_train_ws_bytes(n, channels) bytes, 8-byte aligned, caller-owned.
+ */
+size_t pleas_bn_train_ws_bytes(int64_t n, int channels);
+int pleas_bn_train_fold(const float* x, int64_t n, int channels, int64_t inner, const float* gamma, const float* beta,
+                        double eps, double momentum, float* running_mean, float* running_var,
+                        int64_t* num_batches_tracked, float* scale, float* shift, void* ws, size_t ws_bytes,
+                        void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Fused masked Adam step over a flat parameter arena.
  *

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import threading
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -16,29 +17,38 @@ from . import _lib
 from ._lib import EPI_INNER, EPI_NEG_CDIST, PleasHipError, check
 
 
-_STREAM_CACHE = {"epoch": -1, "handle": 0}
-_STREAM_EPOCH = [0]
+class _Pinned(threading.local):
+    """Per THREAD: torch's current stream is thread-local, so a handle pinned by one thread must never be seen by
+    another (a DataLoader / collate thread, the autograd thread, a second fitter)."""
+
+    depth = 0
+    handle = 0
+
+
+_PINNED = _Pinned()
 
 
 def _stream() -> int:
     """Raw hipStream_t of torch's current stream.  ``torch.cuda.current_stream()`` costs ~8 us; inside a
-    ``pin_stream()`` block (one PLeaS update / matching batch) the handle is looked up once."""
-    if _STREAM_CACHE["epoch"] == _STREAM_EPOCH[0] and _STREAM_EPOCH[0] > 0:
-        return _STREAM_CACHE["handle"]
+    ``pin_stream()`` block (one PLeaS update / matching batch) the handle is looked up once -- by the thread that
+    entered the block, for that thread only."""
+    if _PINNED.depth > 0:
+        return _PINNED.handle
     return torch.cuda.current_stream().cuda_stream
 
 
 class pin_stream:
-    """Context manager: all wrappers inside reuse the stream handle that is current at entry."""
+    """Context manager: all wrappers called by THIS thread inside reuse the stream handle that is current at entry
+    (nested blocks re-pin and restore)."""
 
     def __enter__(self):
-        _STREAM_EPOCH[0] = abs(_STREAM_EPOCH[0]) + 1
-        _STREAM_CACHE["epoch"] = _STREAM_EPOCH[0]
-        _STREAM_CACHE["handle"] = torch.cuda.current_stream().cuda_stream
+        self._saved = (_PINNED.depth, _PINNED.handle)
+        _PINNED.depth += 1
+        _PINNED.handle = torch.cuda.current_stream().cuda_stream
         return self
 
     def __exit__(self, *exc):
-        _STREAM_EPOCH[0] = -abs(_STREAM_EPOCH[0])
+        _PINNED.depth, _PINNED.handle = self._saved
         return False
 
 
@@ -67,10 +77,10 @@ def role_stream(device: torch.device, role: str, priority: int = 0) -> torch.cud
 
 
 class Workspace:
-    """Grow-only device scratch buffer, one per device; callers never see hidden allocations
-    inside the C library."""
+    """Grow-only device scratch buffer, one per (device, stream): two streams that run ``gram_accum`` / ``sqerr`` side
+    by side must not share scratch.  Callers never see hidden allocations inside the C library."""
 
-    _per_device: dict = {}
+    _per_stream: dict = {}
 
     def __init__(self, device: torch.device):
         self.device = device
@@ -78,10 +88,11 @@ class Workspace:
 
     @classmethod
     def get(cls, device: torch.device) -> "Workspace":
-        key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
-        if key not in cls._per_device:
-            cls._per_device[key] = cls(device)
-        return cls._per_device[key]
+        key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), _stream())
+        ws = cls._per_stream.get(key)
+        if ws is None:
+            ws = cls._per_stream[key] = cls(device)
+        return ws
 
     def reserve(self, nbytes: int) -> torch.Tensor:
         if self.buf.numel() < nbytes:
@@ -303,6 +314,37 @@ def bn_act_tracked(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, re
     if res is None:
         return (y_bn, None, y) if relu else (y, None, None)
     return (y_bn, y_sum, y) if relu else (y_bn, y, None)
+
+
+def bn_train_fold(bn: "torch.nn.BatchNorm2d", x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Train-mode ``bn`` on ``x`` as a per-channel affine map: returns fp32 device vectors ``(scale, shift)`` with
+    ``F.batch_norm(x, ..., training=True) == x * scale[c] + shift[c]`` and updates ``bn``'s running statistics and
+    ``num_batches_tracked`` exactly as the module's forward would (``pleas_bn_train_fold``).  The caller applies the map
+    with ``bn_act`` / ``bn_act_tracked``."""
+    _need_gpu(x)
+    if x.dim() < 2:
+        raise PleasHipError("bn_train_fold needs an [N, C, ...] tensor")
+    x = x.contiguous()
+    n, C = x.shape[0], x.shape[1]
+    inner = math.prod(x.shape[2:])
+    if n * inner <= 1:
+        raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(x.shape),))
+    lib = _lib.lib()
+    need = int(lib.pleas_bn_train_ws_bytes(n, C))
+    ws = torch.empty(need // 8, dtype=torch.float64, device=x.device)
+    out = torch.empty(2, C, dtype=torch.float32, device=x.device)
+    track = bn.track_running_stats and bn.running_mean is not None
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    for t in (bn.weight, bn.bias, bn.running_mean if track else None, bn.running_var if track else None):
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.device != x.device):
+            raise PleasHipError("bn_train_fold: BatchNorm parameters / buffers must be contiguous fp32 on x's device")
+    rc = lib.pleas_bn_train_fold(x.data_ptr(), n, C, inner, ptr(bn.weight), ptr(bn.bias), float(bn.eps),
+                                 -1.0 if bn.momentum is None else float(bn.momentum),
+                                 ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
+                                 ptr(bn.num_batches_tracked) if (track and bn.num_batches_tracked is not None) else None,
+                                 out[0].data_ptr(), out[1].data_ptr(), ws.data_ptr(), need, _stream())
+    check(rc, "pleas_bn_train_fold")
+    return out[0], out[1]
 
 
 # ---------------------------------------------------------------------------------------- merge blocks

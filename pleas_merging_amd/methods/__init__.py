@@ -11,4 +11,5 @@ from .partial_matching import expand_ratios, get_blocks, partial_merge, build_pa
 from .pleas_merging import train, get_gradient_mask
 from .extras import reset_bn_stats, zip_ratios, save_matching, load_matching, load_checkpoint
 from .budget import count_linear_flops, partial_merge_flops, qp_ratios
-from .evaluation import get_fc_perm, permute_final_features, eval_perm_model, eval_whole_model
+from .evaluation import (get_fc_perm, permute_final_features, eval_perm_model, eval_whole_model,
+                         train_eval_linear_probe)

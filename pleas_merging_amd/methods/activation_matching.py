@@ -168,10 +168,11 @@ def _build_twin(model1: nn.Module, model2: nn.Module, axes: Iterable[Axis], emit
 
 
 def _bn_chains(traced: _Trace, model1: nn.Module, model2: nn.Module):
-    """Eval-mode ``BatchNorm2d -> [+ other] -> [ReLU]`` chains of the traced graph whose links have no other consumer:
+    """``BatchNorm2d -> [+ other] -> [ReLU]`` chains of the traced graph whose links have no other consumer:
     ``{last node of the chain: (bn, add or None, relu or None, residual operand or None)}`` and the set of nodes that are
-    produced by the chain's single fused launch instead of their own."""
-    from .source_forward import _foldable, _is_add, _is_relu
+    produced by the chain's single fused launch instead of their own.  The BatchNorm may be in eval mode (constants
+    folded once) or in train mode (batch statistics folded per batch, ``hip_ops.bn_train_fold``), per model."""
+    from .source_forward import _foldable, _foldable_train, _is_add, _is_relu
 
     mods1, mods2 = dict(model1.named_modules()), dict(model2.named_modules())
     fx_mods = dict(traced.named_modules())
@@ -179,7 +180,7 @@ def _bn_chains(traced: _Trace, model1: nn.Module, model2: nn.Module):
     for node in traced.graph.nodes:
         if node.op != "call_module" or len(node.args) != 1 or node.kwargs:
             continue
-        if not (_foldable(mods1.get(node.target)) and _foldable(mods2.get(node.target))):
+        if not all(_foldable(m) or _foldable_train(m) for m in (mods1.get(node.target), mods2.get(node.target))):
             continue
         add = relu = res = None
         users = list(node.users)
@@ -198,12 +199,22 @@ def _bn_chains(traced: _Trace, model1: nn.Module, model2: nn.Module):
     return at, absorbed
 
 
+def _train_fold(mod: nn.BatchNorm2d, side: int, name: str) -> Callable:
+    """Graph callable of a train-mode BatchNorm: ``x -> (scale, shift)`` of THIS batch (and the module's running
+    statistics move on, as in the module's own forward)."""
+    def fold(x):
+        return hip_ops.bn_train_fold(mod, x)
+
+    fold.__name__ = fold.__qualname__ = "bn_train_fold_%d_%s" % (side, name)
+    return fold
+
+
 def _build_split_twin(model1: nn.Module, model2: nn.Module, axes: Iterable[Axis], emit: Callable, streams: _SideStream,
                       fuse_bn: bool = False, emit_derived: Optional[Callable] = None):
     import operator
 
     from .. import hip_ops
-    from .source_forward import fold_bn
+    from .source_forward import _foldable, fold_bn
 
     traced = _Trace(model1)
     submods = dict(traced.named_modules())
@@ -250,10 +261,15 @@ def _build_split_twin(model1: nn.Module, model2: nn.Module, axes: Iterable[Axis]
                 # node of the chain (activation matching measures all of them), reading x and the residual once
                 bn, add, relu, res = chains[node]
                 mod = (model1, model2)[side].get_submodule(bn.target)
-                names = ["_pleas_%s_%d_%s" % (kind, side, bn.name) for kind in ("scale", "shift")]
-                for nm_, buf in zip(names, fold_bn(mod)):
-                    root.register_buffer(nm_, buf, persistent=False)
-                attrs = (_node(twin, "get_attr", names[0], (), "bn_scale"), _node(twin, "get_attr", names[1], (), "bn_shift"))
+                if _foldable(mod):          # eval mode: scale / shift are constants of the run
+                    names = ["_pleas_%s_%d_%s" % (kind, side, bn.name) for kind in ("scale", "shift")]
+                    for nm_, buf in zip(names, fold_bn(mod)):
+                        root.register_buffer(nm_, buf, persistent=False)
+                    attrs = (_node(twin, "get_attr", names[0], (), "bn_scale"), _node(twin, "get_attr", names[1], (), "bn_shift"))
+                else:                       # train mode (the reference drivers' mode): this batch's statistics, one pass
+                    fold = _node(twin, "call_function", _train_fold(mod, side, bn.name), (env[side][bn.args[0]],), "bn_stats")
+                    attrs = (_node(twin, "call_function", operator.getitem, (fold, 0), "bn_scale"),
+                             _node(twin, "call_function", operator.getitem, (fold, 1), "bn_shift"))
                 fold_attrs[side][bn] = attrs
                 fused = _node(twin, "call_function", hip_ops.bn_act_tracked,
                               (env[side][bn.args[0]], attrs[0], attrs[1], env[side][res] if res is not None else None,

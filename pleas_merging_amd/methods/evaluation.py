@@ -67,3 +67,56 @@ def eval_whole_model(model: nn.Module, dataloader: Iterable, num_classes: int) -
     acc = torch.tensor(hit / max(seen, 1))
     print(acc)
     return acc
+
+
+def train_eval_linear_probe(model: nn.Module, train_dataloader, test_dataloader, num_classes: int, wandb_run, dataset_name: str,
+                            lr: float = 1e-3, epochs: int = 10, device=None) -> nn.Module:
+    """Linear probe on a frozen (merged) backbone, as the different-label-space driver evaluates merged models
+    (reference :499-570; run_torchvision.py:276-290).  Same recipe: Adam(``lr``) on a fresh ``Linear`` head, cosine
+    schedule over ``epochs * len(train_dataloader)`` steps down to ``lr / 10``, cross entropy, backbone in eval mode
+    under ``no_grad``; per-epoch train accuracy / loss and the final test accuracy go to ``wandb_run.log`` under the
+    reference's keys (``wandb_run=None`` skips logging).  Returns the trained head.  The backbone stays where it is
+    (``device`` defaults to its device) -- the reference hard-codes ``.cuda()`` and a 224x224 probe input; here the
+    feature width is read from the first training batch."""
+    if device is None:
+        device = next(iter(model.parameters())).device
+    model.eval()
+    n_batches = len(train_dataloader)
+    fc = opt = sched = None
+    loss_fn = nn.CrossEntropyLoss()
+    log = wandb_run.log if wandb_run is not None else (lambda _metrics: None)
+    for epoch in range(epochs):
+        hit = torch.zeros((), dtype=torch.long, device=device)
+        seen, total, loss = 0, 0.0, None
+        for x, y in train_dataloader:
+            x, y = x.to(device), y.to(device)
+            with torch.no_grad():
+                feats = model(x)
+            if fc is None:
+                fc = nn.Linear(feats.shape[-1], num_classes).to(device)
+                opt = torch.optim.Adam(fc.parameters(), lr=lr)
+                sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, epochs * n_batches, eta_min=lr / 10)
+            fc.train()
+            logits = fc(feats)
+            loss = loss_fn(logits, y)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            sched.step()
+            hit += (logits.argmax(1) == y).sum()
+            seen += int(y.numel())
+            total += float(loss)
+        log({"%s_linear_probe_train_acc" % dataset_name: float(hit) / max(seen, 1),
+             "%s_linear_probe_train_loss" % dataset_name: float(loss) if loss is not None else float("nan"),
+             "epoch": epoch, "%s_total_loss" % dataset_name: total / max(n_batches, 1)})
+    if fc is None:
+        raise ValueError("train_eval_linear_probe: empty training loader")
+    fc.eval()
+    hit, seen = torch.zeros((), dtype=torch.long, device=device), 0
+    with torch.no_grad():
+        for x, y in test_dataloader:
+            x, y = x.to(device), y.to(device)
+            hit += (fc(model(x)).argmax(1) == y).sum()
+            seen += int(y.numel())
+    log({"%s_linear_probe_acc" % dataset_name: float(hit) / max(seen, 1)})
+    return fc

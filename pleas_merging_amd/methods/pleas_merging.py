@@ -751,8 +751,9 @@ class PleasFitter:
             caller.wait_stream(upd)
 
     def steps(self, batches, lookahead: Optional[bool] = None, pair_sources: bool = True, sources_per_forward: Optional[int] = None):
-        """Run one update per tensor of ``batches``; yields the index of each finished update.  The whole loop stays on
-        the fitter's stream (also current for the consumer's code between two updates).
+        """Run one update per tensor of ``batches``; yields the index of each finished update.  Between two updates the
+        consumer's code runs on ITS OWN current stream, ordered after the update just applied (the fitter's stream is
+        entered and left per update).
 
         ``pair_sources=True`` (default): up to ``sources_per_forward`` consecutive batches of equal shape go through the
         frozen sources as ONE forward of the concatenated batch, and the updates read their slices (views) of its taps --
@@ -778,15 +779,18 @@ class PleasFitter:
         if lookahead is None:
             lookahead = self.world > 1
         keep = group if lookahead else 0      # sources are launched whenever no more than `keep` generations are queued
-        with self._session():
-            it = iter(batches)
-            for gen in list(self._queue):         # forwards enqueued beforehand (FrozenSources.prefetch): same batches first
-                if next(it, None) is not gen[0]:
-                    raise RuntimeError("PleasFitter.steps: the prefetched batches must be the first ones, in order")
-            ahead: List[torch.Tensor] = []        # fetched from `it`, sources not launched yet
-            exhausted = False
-            idx = 0
-            while True:
+        it = iter(batches)
+        for gen in list(self._queue):         # forwards enqueued beforehand (FrozenSources.prefetch): same batches first
+            if next(it, None) is not gen[0]:
+                raise RuntimeError("PleasFitter.steps: the prefetched batches must be the first ones, in order")
+        ahead: List[torch.Tensor] = []        # fetched from `it`, sources not launched yet
+        exhausted = False
+        idx = 0
+        while True:
+            # The fitter's stream is current while an update is put together and ONLY then: the session is entered and left
+            # per update, so a consumer that breaks out of (or raises inside) the loop is on its own stream, ordered after
+            # the updates it has seen -- nothing is left to a generator's finalisation.
+            with self._session():
                 while len(self._queue) <= keep:
                     while len(ahead) < group and not exhausted:
                         nxt = next(it, None)
@@ -811,8 +815,8 @@ class PleasFitter:
                 if not self._queue:
                     break
                 self.step(self._queue[0][0])
-                yield idx
-                idx += 1
+            yield idx
+            idx += 1
 
     @torch.no_grad()
     def step(self, x: torch.Tensor, next_x: Optional[torch.Tensor] = None) -> None:

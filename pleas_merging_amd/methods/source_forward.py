@@ -56,6 +56,15 @@ def _foldable(bn: nn.Module) -> bool:
             and bn.running_var is not None and bn.running_mean.dtype == torch.float32)
 
 
+def _foldable_train(bn: nn.Module) -> bool:
+    """A BatchNorm2d that normalises with the BATCH's statistics (train mode, or no running statistics at all): still
+    one affine map per channel, computed per batch on the device (``hip_ops.bn_train_fold``)."""
+    if not isinstance(bn, nn.BatchNorm2d) or not (bn.training or bn.running_mean is None):
+        return False
+    tensors = [t for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var) if t is not None]
+    return all(t.dtype == torch.float32 for t in tensors)
+
+
 def fold_bn(bn: nn.BatchNorm2d):
     """``(scale, shift)`` fp32 tensors with ``bn(x) == x * scale + shift`` in eval mode (computed in fp64)."""
     with torch.no_grad():

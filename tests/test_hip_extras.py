@@ -1,0 +1,156 @@
+"""SURVEY.md section 8(f) -- the callers and data formats either side of the hot path -- ON THE DEVICE, fed by the HIP
+pipeline's own outputs the way the reference drivers chain them (run_domainnet.py:257-366, run_torchvision.py:251-296):
+
+  matching (HIP) -> [save / load perm + costs] -> ratios (zip / QP) -> partial_merge -> PLeaS -> BN reset -> eval helpers
+"""
+import copy
+
+import pytest
+import torch
+
+from oracle import pleas_oracle as orc
+from stem_gate import STEM
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a.double().cpu() - b.double().cpu()).norm() / (b.double().cpu().norm() + 1e-30))
+
+
+def _cuda_pair(t):
+    return copy.deepcopy(t.m1).cuda(), copy.deepcopy(t.m2).cuda()
+
+
+def test_bn_reset_on_the_merged_cuda_model_equals_the_drivers_loop(tiny_basic):
+    """Row 1 (run_domainnet.py:327-341): after ``train`` the drivers put the merged model in train mode, reset every
+    BatchNorm and forward 101 ``.cuda()`` batches.  ``reset_bn_stats`` on the merged CUDA model of the HIP pipeline vs
+    that loop written out on the CPU oracle's merged model."""
+    from pleas.methods.extras import reset_bn_stats
+    from pleas.methods.partial_matching import partial_merge
+    from pleas.methods.pleas_merging import train
+
+    t = tiny_basic
+    perm, costs_c = t.per_key("am_perm"), t.per_key("am_cost")
+    costs = {k: v.cuda() for k, v in costs_c.items()}
+    m1, m2 = _cuda_pair(t)
+    data = t.batches("xt")
+    m3 = partial_merge(t.spec, m1, m2, perm, costs, 0.5)
+    m3 = train(data, m1, m2, m3, t.spec, perm, costs, 0.5, False, 5, None, num_classes=10).cuda()
+    ref = orc.partial_merge(t.spec, t.m1, t.m2, perm, costs_c, 0.5)
+    ref, _ = orc.train(data, t.m1, t.m2, ref, t.spec, perm, costs_c, 0.5, 5, num_classes=10)
+    # the trained stem is rounding noise integrated by Adam (tests/stem_gate.py) and every statistic downstream depends
+    # on it: both sides get the oracle's stem, so that the BN pass itself is what is compared
+    with torch.no_grad():
+        m3.conv1.weight.copy_(ref.conv1.weight)
+    got = reset_bn_stats(m3, data, 101)
+    assert got.training and next(got.parameters()).is_cuda
+    ref.train()
+    for mod in ref.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.reset_running_stats()
+    with torch.no_grad():
+        for i, b in enumerate(data):
+            ref(b[0].float())
+            if i + 1 > 100:
+                break
+    checked = 0
+    for (k, a), (_, b) in zip(got.state_dict().items(), ref.state_dict().items()):
+        if "running_" in k:
+            assert _rel(a, b) < 2e-4, (k, _rel(a, b))
+            checked += 1
+        elif k.endswith("num_batches_tracked"):
+            assert int(a) == int(b) == len(data)
+    assert checked >= 10
+
+
+def test_eval_helpers_on_a_merged_cuda_backbone_known_answer(tiny_bottleneck):
+    """Row 4 (pleas_merging.py:408-496): model2 = model1 with every group permuted.  Matching (HIP) recovers the
+    permutation, the partially merged backbone (ratio 0.5, fc -> Identity) then emits [merged | separate-1 | separate-2]
+    features, and ``permute_final_features`` / ``eval_perm_model`` must hand EACH source head its own feature order:
+    accuracy 1 against that head's own predictions, features equal to the source backbone's."""
+    from pleas.core.utils import apply_perm, make_random_perm
+    from pleas.methods.activation_matching import activation_matching
+    from pleas.methods.partial_matching import partial_merge
+    from pleas.methods.pleas_merging import eval_perm_model, eval_whole_model, get_fc_perm, permute_final_features
+
+    t = tiny_bottleneck
+    m1 = copy.deepcopy(t.m1)
+    m2 = copy.deepcopy(m1)
+    apply_perm(make_random_perm(t.spec, torch.Generator().manual_seed(3)), t.spec, m2, inplace=True)
+    m1, m2 = m1.cuda().eval(), m2.cuda().eval()
+    perm, costs = activation_matching(t.spec, m1, m2, t.batches(), 2, output_costs=True)
+    m3 = partial_merge(t.spec, m1, m2, perm, costs, 0.5, device="cuda")
+    fc_perm = get_fc_perm(perm, t.spec, costs, 0.5)
+    assert all(b.is_cuda for b in fc_perm) or all(not b.is_cuda for b in fc_perm)
+    backbone = copy.deepcopy(m3)
+    backbone.fc = torch.nn.Identity()
+    xs = [b[0].cuda() for b in t.batches()]
+    for idx, src in enumerate((m1, m2)):
+        body = copy.deepcopy(src)
+        body.fc = torch.nn.Identity()
+        with torch.no_grad():
+            feats = permute_final_features(backbone(xs[0]), fc_perm, idx)
+            assert feats.is_cuda and _rel(feats, body(xs[0])) < 1e-5, idx
+            loader = [(x, src(x).argmax(1)) for x in xs]
+        assert float(eval_perm_model(backbone, src.fc, loader, 10, fc_perm, idx)) == 1.0
+        assert float(eval_whole_model(src, loader, 10)) == 1.0
+
+
+def test_saved_matching_with_cuda_costs_feeds_partial_merge(tiny_basic, tmp_path):
+    """Row 3 (run_domainnet.py:190-193, :362-366 + perm / cost files): costs come off the GPU, go through
+    ``save_matching`` / ``load_matching`` and feed ``partial_merge`` again; the merged model's state dict goes through
+    ``torch.save`` / ``load_checkpoint`` (raw and under 'model')."""
+    from pleas.methods.activation_matching import activation_matching
+    from pleas.methods.extras import load_checkpoint, load_matching, save_matching
+    from pleas.methods.partial_matching import partial_merge
+
+    t = tiny_basic
+    m1, m2 = _cuda_pair(t)
+    perm, costs = activation_matching(t.spec, m1, m2, t.batches(), 3, output_costs=True)
+    assert all(c.is_cuda for c in costs.values())
+    path = str(tmp_path / "matching.pt")
+    save_matching(path, perm, costs)
+    perm2, costs2 = load_matching(path, device="cuda")
+    assert list(perm2) == list(perm)
+    for k in perm:
+        assert torch.equal(perm2[k], perm[k]) and costs2[k].is_cuda and torch.equal(costs2[k], costs[k])
+    a = partial_merge(t.spec, m1, m2, perm, costs, 0.5).state_dict()
+    merged = partial_merge(t.spec, m1, m2, perm2, costs2, 0.5)
+    for k, v in merged.state_dict().items():
+        assert torch.equal(v, a[k]), k
+    for blob in (merged.state_dict(), {"model": merged.state_dict(), "epoch": 1}):
+        torch.save(blob, str(tmp_path / "merged.pt"))
+        again = load_checkpoint(copy.deepcopy(merged), str(tmp_path / "merged.pt"))
+        assert all(torch.equal(x, y) for x, y in zip(again.state_dict().values(), a.values()))
+
+
+@pytest.mark.parametrize("budget", [1.3, 1.7])
+def test_qp_ratios_to_partial_merge_to_pleas_vs_oracle(tiny_basic, budget):
+    """Row 2 (partial_matching.py:205-257 without Gurobi): FLOP model -> ``qp_ratios`` (fractional per-group ratios) ->
+    ``partial_merge`` -> PLeaS updates on the HIP path vs the oracle with the same ratios; the merged model's FLOPs meet
+    the budget."""
+    from pleas.core.utils import count_linear_flops
+    from pleas.methods.partial_matching import partial_merge, partial_merge_flops, qp_ratios
+    from pleas.methods.pleas_merging import train
+
+    t = tiny_basic
+    perm, costs_c = t.per_key("am_perm"), t.per_key("am_cost")
+    costs = {k: v.cuda() for k, v in costs_c.items()}
+    _, terms = count_linear_flops(t.spec, t.m1, ((2, 3, 32, 32),))
+    weights = {k: float(costs_c[k][torch.arange(len(perm[k])), perm[k]].mean().abs()) for k in t.spec}
+    ratios = qp_ratios(t.spec, terms, budget, weights)
+    assert 0.0 < max(ratios.values()) and min(ratios.values()) < 1.0
+    used = partial_merge_flops(t.spec, terms, ratios) / partial_merge_flops(t.spec, terms, 0.0)
+    assert used <= budget + 1e-9
+    m1, m2 = _cuda_pair(t)
+    m3 = partial_merge(t.spec, m1, m2, perm, costs, ratios)
+    o3 = orc.partial_merge(t.spec, t.m1, t.m2, perm, costs_c, ratios)
+    for (k, a), (_, b) in zip(m3.state_dict().items(), o3.state_dict().items()):
+        assert torch.equal(a, b), k
+    data = t.batches("xt")[:4]
+    m3 = train(data, m1, m2, m3, t.spec, perm, costs, ratios, False, 3, None, num_classes=10)
+    o3, _ = orc.train(data, t.m1, t.m2, o3, t.spec, perm, costs_c, ratios, 3, num_classes=10)
+    for (k, a), (_, b) in zip(m3.state_dict().items(), o3.state_dict().items()):
+        if k != STEM and a.dtype.is_floating_point:
+            assert _rel(a, b) < 1e-4, (k, _rel(a, b))

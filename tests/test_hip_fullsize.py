@@ -77,6 +77,34 @@ def rn50():
     return Pair("resnet50")
 
 
+def test_rn101_train_mode_matching_vs_oracle(rn101):
+    """The drivers' real mode (no .eval() before activation_matching): all 104 BatchNorm2d of each ResNet-101 normalise
+    with batch statistics.  HIP path (statistics folded per batch, BatchNorm nodes derived) vs the oracle in train mode:
+    costs, assignments (near-tie rule of _check_matching) and the running statistics left behind."""
+    from pleas.methods.activation_matching import activation_matching
+
+    cpu = [copy.deepcopy(m).train() for m in (rn101.m1, rn101.m2)]
+    gpu = [copy.deepcopy(m).cuda() for m in cpu]
+    want_perm, want_costs = orc.activation_matching(rn101.spec, cpu[0], cpu[1], rn101.data, 2, accumulate=True)
+    perm, costs = activation_matching(rn101.spec, gpu[0], gpu[1], rn101.data, 2, output_costs=True)
+
+    class Want:
+        spec, want_perm, want_costs = rn101.spec, None, None
+
+    Want.want_perm, Want.want_costs = want_perm, want_costs
+    flips = _check_matching(Want, perm, costs, max_flipped_groups=6)
+    worst = 0.0
+    for g, c in zip(gpu, cpu):
+        assert g.training
+        for (k, a), (_, b) in zip(g.state_dict().items(), c.state_dict().items()):
+            if "running_" in k:
+                worst = max(worst, _rel(a, b))
+            elif k.endswith("num_batches_tracked"):
+                assert int(a) == int(b)
+    assert worst < 1e-4, worst
+    print("train-mode matching: flipped groups", flips, "worst running-stat rel", worst)
+
+
 def _value(cost, perm):
     return float(cost.double().cpu()[torch.arange(len(perm)), perm].sum())
 
@@ -250,14 +278,17 @@ def test_rn101_gradients_vs_fp64_on_identical_taps(rn101):
     m3 = partial_merge(p.spec, m1, m2, p.want_perm, p.gpu_costs(), ratio)
     fit = PleasFitter(m1, m2, m3, p.spec, p.want_perm, p.gpu_costs(), ratio, 3, num_classes=1000)
     x = p.data[2][0]
-    fit._run_sources(x.cuda())
-    torch.cuda.synchronize()
-    taps = {n: tuple(t[n].detach().double().cpu() for t in (fit.tap1.inputs, fit.tap2.inputs, fit.tap1.outputs, fit.tap2.outputs))
-            for n in fit.tap1.inputs}
-    fit.tap1.clear()
-    fit.tap2.clear()
+    kept, release = {}, fit._end_update
+
+    def keep_taps():        # the very tensors this update read (a second source forward may pick other vendor algorithms)
+        kept.update(i1=fit.t1_in, i2=fit.t2_in, o1=fit.t1_out, o2=fit.t2_out)
+        release()
+
+    fit._end_update = keep_taps
     fit.step(x)
     torch.cuda.synchronize()
+    taps = {pl.name: tuple(kept[t][pl.name].detach().double().cpu() for t in ("i1", "i2", "o1", "o2")) for pl in fit.plans}
+    kept.clear()
     blocks = orc.spread_blocks(p.spec, orc.get_blocks(p.spec, p.want_perm, p.want_costs, ratio))
     worst_g = worst_l = worst_cpu = 0.0
     kmax = 0

@@ -2,6 +2,8 @@
 
 All tests here need the MI355X (`-m gpu`) and go through libpleas_hip.so.
 """
+import copy
+
 import numpy as np
 import pytest
 import torch
@@ -610,3 +612,37 @@ def test_fwd_batch_matches_conv_and_target(ops, N, Cout, Cin, H, W, k, stride, p
     for i in range(2):
         assert _rel(resid[i].cpu(), want) < 5e-6
         assert abs(float(loss[i]) - want_loss) < 1e-5 * max(1.0, want_loss)
+
+
+# ------------------------------------------------------------------------------------------ train-mode BatchNorm fold
+@pytest.mark.parametrize("shape", [(4, 8, 5, 5), (16, 64, 56, 56), (2, 2048, 7, 7), (3, 37, 1, 9), (8, 256, 14, 14)])
+@pytest.mark.parametrize("momentum", [0.1, None])
+def test_bn_train_fold_equals_train_mode_batchnorm(shape, momentum):
+    """``pleas_bn_train_fold`` + ``pleas_bn_act``: the values, the running statistics and the batch counter of a
+    train-mode ``BatchNorm2d`` forward (torch, fp64 on the CPU as the truth), over two consecutive batches."""
+    from pleas_merging_amd import hip_ops
+
+    g = torch.Generator().manual_seed(sum(shape))
+    C = shape[1]
+    bn = torch.nn.BatchNorm2d(C, momentum=momentum)
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.3 * torch.randn(C, generator=g))
+        bn.bias.copy_(0.2 * torch.randn(C, generator=g))
+    ref = copy.deepcopy(bn).double().train()
+    dev = copy.deepcopy(bn).cuda().train()
+    for step in range(2):
+        x = 3.0 + 2.0 * torch.randn(shape, generator=g)        # mean >> 0: E[x^2] - mean^2 must not cancel in fp32
+        want = ref(x.double())
+        scale, shift = hip_ops.bn_train_fold(dev, x.cuda())
+        got = hip_ops.bn_act(x.cuda(), scale, shift, None, relu=False)
+        assert _rel(got, want) < 1e-6, (step, _rel(got, want))
+        assert _rel(dev.running_mean, ref.running_mean) < 1e-6 and _rel(dev.running_var, ref.running_var) < 1e-6
+        assert int(dev.num_batches_tracked) == int(ref.num_batches_tracked) == step + 1
+    # no running statistics at all: batch statistics, nothing to update
+    free = torch.nn.BatchNorm2d(C, track_running_stats=False).cuda()
+    x = torch.randn(shape, generator=g)
+    scale, shift = hip_ops.bn_train_fold(free, x.cuda())
+    want = torch.nn.functional.batch_norm(x.double(), None, None, free.weight.double().cpu(), free.bias.double().cpu(), True)
+    assert _rel(hip_ops.bn_act(x.cuda(), scale, shift, None, relu=False), want) < 1e-6
+    with pytest.raises(ValueError):
+        hip_ops.bn_train_fold(dev, torch.randn(1, C, 1, 1).cuda())

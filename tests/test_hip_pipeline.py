@@ -623,3 +623,99 @@ def test_config4_zip_budget_partial_merge_and_train_vs_oracle():
     for (k, a), (_, b) in zip(m3.state_dict().items(), o3.state_dict().items()):
         if k != DEGENERATE and a.dtype.is_floating_point:
             assert _rel(a, b) < 1e-4, (k, _rel(a, b))
+
+
+def test_steps_generator_leaves_the_callers_stream_current(tiny_bottleneck):
+    """``PleasFitter.steps`` enters the fitter's stream per update: a consumer that breaks out of the loop early (or
+    raises) is on its own stream again at once, ordered after the updates it saw -- not at some later garbage collection."""
+    from pleas.methods.partial_matching import partial_merge
+    from pleas.methods.pleas_merging import PleasFitter
+
+    t = tiny_bottleneck
+    m1, m2 = _cuda_pair(t)
+    perm = t.per_key("am_perm")
+    costs = {k: v.cuda() for k, v in t.per_key("am_cost").items()}
+    xs = [x for x, _ in t.batches() + t.batches()]
+    m3 = partial_merge(t.spec, m1, m2, perm, costs, 0.5)
+    fit = PleasFitter(m1, m2, m3, t.spec, perm, costs, 0.5, len(xs) - 1, num_classes=10)
+    mine = torch.cuda.Stream()
+    with torch.cuda.stream(mine):
+        gen = fit.steps(xs)
+        for i in gen:
+            assert torch.cuda.current_stream() == mine          # also between two updates
+            if i == 2:
+                break
+        assert torch.cuda.current_stream() == mine
+        seen = fit.loss_sum.clone()                              # ordered after the three updates: no sync needed
+        with pytest.raises(ZeroDivisionError):
+            for i in fit.steps(xs[3:]):
+                1 / 0
+        assert torch.cuda.current_stream() == mine
+    assert fit.step_count == 4 and float(seen.sum()) > 0
+    assert torch.cuda.current_stream() == torch.cuda.default_stream()
+    fit.finish()
+
+
+def test_pinned_stream_handle_is_per_thread():
+    """``hip_ops.pin_stream`` caches the raw stream handle for the calling thread only: another thread (a DataLoader /
+    collate thread, a second fitter) keeps launching on ITS current stream, and scratch workspaces are per stream."""
+    import threading
+
+    from pleas_merging_amd import hip_ops
+
+    side = torch.cuda.Stream()
+    seen = {}
+
+    def other():
+        seen["handle"] = hip_ops._stream()
+        seen["ws"] = hip_ops.Workspace.get(torch.device("cuda", 0))
+
+    with torch.cuda.stream(side), hip_ops.pin_stream():
+        assert hip_ops._stream() == side.cuda_stream
+        with hip_ops.pin_stream():                                # nested pins restore the outer one
+            pass
+        assert hip_ops._stream() == side.cuda_stream
+        th = threading.Thread(target=other)
+        th.start()
+        th.join()
+        ws_side = hip_ops.Workspace.get(torch.device("cuda", 0))
+    assert seen["handle"] == torch.cuda.default_stream().cuda_stream != side.cuda_stream
+    assert seen["ws"] is not ws_side
+    assert hip_ops._stream() == torch.cuda.current_stream().cuda_stream
+
+
+@pytest.mark.parametrize("fx", ["tiny_basic", "tiny_bottleneck"])
+@pytest.mark.parametrize("modes", [(True, True), (True, False)])
+def test_train_mode_matching_vs_oracle(fx, modes, request):
+    """The reference drivers never call .eval() before activation_matching (run_domainnet.py:172-186, :257-264): BatchNorm
+    then normalises with batch statistics and its running statistics move.  The fused / derived path folds those
+    statistics per batch on the device (``pleas_bn_train_fold``): same costs and assignments as the oracle run in the same
+    mode, same running statistics and batch counters afterwards, modes untouched.  Also one model in each mode."""
+    from pleas.methods.activation_matching import activation_matching
+
+    t = request.getfixturevalue(fx)
+    cpu = [copy.deepcopy(t.m1).train(modes[0]), copy.deepcopy(t.m2).train(modes[1])]
+    gpu = [copy.deepcopy(m).cuda() for m in cpu]
+    data = t.batches()
+    want_p, want_c = orc.activation_matching(t.spec, cpu[0], cpu[1], data, 3, accumulate=True)
+    perm, costs = activation_matching(t.spec, gpu[0], gpu[1], data, 3, output_costs=True)
+    for k in t.spec:
+        assert _rel(costs[k], want_c[k]) < 2e-5, (k, _rel(costs[k], want_c[k]))
+        assert (perm[k] == want_p[k]).all(), k
+    for g, c, mode in zip(gpu, cpu, modes):
+        assert g.training == mode
+        for (k, a), (_, b) in zip(g.state_dict().items(), c.state_dict().items()):
+            if "running_" in k:
+                assert torch.allclose(a.cpu(), b, rtol=1e-5, atol=1e-6), k
+                assert mode or torch.equal(a.cpu(), dict(t.m2.state_dict())[k])      # eval mode: untouched
+            elif k.endswith("num_batches_tracked"):
+                assert int(a) == int(b) == (3 if mode else 0), k
+    # the module-by-module path (vendor BatchNorm kernels) gives the same costs
+    from pleas_merging_amd import hip_ops
+    from pleas_merging_amd.methods.activation_matching import accumulate_costs_fused
+
+    again = [copy.deepcopy(m).cuda() for m in (t.m1.train(modes[0]), t.m2.train(modes[1]))]
+    t.m1.eval(), t.m2.eval()
+    plain = accumulate_costs_fused(t.spec, again[0], again[1], data, 3, hip_ops.EPI_NEG_CDIST, fuse_bn=False)
+    for k in t.spec:
+        assert _rel(plain[k], costs[k]) < 2e-5, k

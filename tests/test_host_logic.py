@@ -531,3 +531,47 @@ def test_bench_starts_its_own_ranks_without_touching_the_gpu(monkeypatch):
     # defaults finish within minutes: a step is one whole job (~6.5 s), 1 warm-up + 3 timed
     d = bench.parse([])
     assert (d.gpus, d.steps, d.warmup, d.match_batches, d.updates) == (1, 3, 1, 100, 401)
+
+
+def test_drop_in_namespace_exports_the_reference_surface():
+    """Every name the reference's package __init__ files export (pleas/methods/__init__.py:12-41,
+    pleas/core/__init__.py:9-21) resolves under the drop-in ``pleas`` namespace, so driver imports keep working."""
+    import pleas.core
+    import pleas.methods
+
+    for name in ("activation_matching", "cross_features_cdist", "cross_features_inner_product", "weight_matching",
+                 "partial_merge", "get_blocks", "qp_ratios", "expand_ratios", "partial_merge_flops", "train",
+                 "train_eval_linear_probe", "eval_perm_model", "eval_whole_model", "get_fc_perm"):
+        assert callable(getattr(pleas.methods, name)), name
+    for name in ("Axis", "PermutationGroup", "PermutationSpec", "Permutation", "apply_perm", "make_identity_perm",
+                 "make_random_perm", "invert_perm", "count_linear_flops", "scipy_solve_lsa"):
+        assert getattr(pleas.core, name) is not None, name
+    from pleas.methods.pleas_merging import train_eval_linear_probe  # noqa: F401  (the drivers' import path)
+
+
+def test_linear_probe_learns_a_separable_head():
+    """train_eval_linear_probe (reference pleas_merging.py:499-570): frozen backbone, Adam + cosine schedule on a fresh
+    head, the reference's logging keys; on linearly separable features the probe reaches the labels."""
+    from pleas.methods import train_eval_linear_probe
+
+    g = torch.Generator().manual_seed(0)
+    backbone = torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(12, 6))
+    for p in backbone.parameters():
+        p.requires_grad_(False)
+    truth = torch.nn.Linear(6, 3)
+    xs = [torch.randn(32, 12, generator=g) for _ in range(6)]
+    data = [(x, truth(backbone(x)).argmax(1)) for x in xs]
+    logged = []
+
+    class Run:
+        def log(self, metrics):
+            logged.append(metrics)
+
+    before = [p.clone() for p in backbone.parameters()]
+    fc = train_eval_linear_probe(backbone, data[:5], data[5:], 3, Run(), "toy", lr=5e-2, epochs=30)
+    assert isinstance(fc, torch.nn.Linear) and (fc.in_features, fc.out_features) == (6, 3)
+    assert all(torch.equal(a, b) for a, b in zip(before, backbone.parameters()))     # backbone untouched
+    assert len(logged) == 31 and set(logged[0]) == {"toy_linear_probe_train_acc", "toy_linear_probe_train_loss", "epoch",
+                                                    "toy_total_loss"}
+    assert logged[-1]["toy_linear_probe_acc"] >= 0.85 and logged[-2]["toy_linear_probe_train_acc"] >= 0.9
+    assert logged[-2]["toy_total_loss"] < logged[0]["toy_total_loss"]
