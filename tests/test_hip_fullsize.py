@@ -267,54 +267,16 @@ def test_rn101_gradients_vs_fp64_on_identical_taps(rn101):
     6912, ratio 0.5 so that every layer has merged and separate units) against fp64 autograd of the reference objective
     (pleas_merging.py:281-287) evaluated on the SAME source activations, copied from the GPU taps: rel-fro < 2e-5, or
     within 3x of what fp32 autograd on the CPU reaches against fp64 on that layer."""
-    from copy import deepcopy
-
+    from grad_check import check_update_against_fp64
     from pleas.methods.partial_matching import partial_merge
     from pleas.methods.pleas_merging import PleasFitter
-    from pleas_merging_amd.core.utils import get_attr
 
     p, ratio = rn101, 0.5
     m1, m2 = p.gpu()
     m3 = partial_merge(p.spec, m1, m2, p.want_perm, p.gpu_costs(), ratio)
     fit = PleasFitter(m1, m2, m3, p.spec, p.want_perm, p.gpu_costs(), ratio, 3, num_classes=1000)
-    x = p.data[2][0]
-    kept, release = {}, fit._end_update
-
-    def keep_taps():        # the very tensors this update read (a second source forward may pick other vendor algorithms)
-        kept.update(i1=fit.t1_in, i2=fit.t2_in, o1=fit.t1_out, o2=fit.t2_out)
-        release()
-
-    fit._end_update = keep_taps
-    fit.step(x)
-    torch.cuda.synchronize()
-    taps = {pl.name: tuple(kept[t][pl.name].detach().double().cpu() for t in ("i1", "i2", "o1", "o2")) for pl in fit.plans}
-    kept.clear()
-    blocks = orc.spread_blocks(p.spec, orc.get_blocks(p.spec, p.want_perm, p.want_costs, ratio))
-    worst_g = worst_l = worst_cpu = 0.0
-    kmax = 0
-    for idx, plan in enumerate(fit.plans):
-        ip1, ip2, o1, o2 = taps[plan.name]
-        ip, op = orc.layer_targets(lambda _t, o=o1: o, lambda _t, o=o2: o, blocks, plan.name, ip1, ip2, num_classes=1000)
-        layer = deepcopy(get_attr(m3, plan.name.split("."))).double()
-        for prm in layer.parameters():
-            prm.requires_grad_(True)
-        loss = ((layer(ip) - op) ** 2).mean()
-        grads = torch.autograd.grad(loss, list(layer.parameters()))
-        layer32 = deepcopy(get_attr(m3, plan.name.split("."))).float()       # the same objective in fp32 on the CPU
-        for prm in layer32.parameters():
-            prm.requires_grad_(True)
-        g32 = torch.autograd.grad(((layer32(ip.float()) - op.float()) ** 2).mean(), [layer32.weight])[0]
-        gw = plan.gw.permute(0, 3, 1, 2) if plan.kpos else plan.gw
-        if plan.name != "conv1":        # stem: residual and gradient are rounding noise (DESIGN.md section 1)
-            rg, rg_cpu = _rel(gw, grads[0]), _rel(g32, grads[0])
-            assert rg < max(2e-5, 3 * rg_cpu), (plan.name, tuple(gw.shape), rg, rg_cpu)
-            worst_g, worst_cpu = max(worst_g, rg), max(worst_cpu, rg_cpu)
-            rl = abs(float(fit.loss_now[idx]) - float(loss.detach())) / float(loss.detach())
-            assert rl < 1e-5, (plan.name, rl)
-            worst_l = max(worst_l, rl)
-        if plan.gb is not None:
-            assert _rel(plan.gb, grads[1]) < 2e-5, plan.name
-        kmax = max(kmax, grads[0][0].numel())
+    worst_g, worst_cpu, worst_l, kmax = check_update_against_fp64(fit, m3, p.spec, p.want_perm, p.want_costs, ratio,
+                                                                  p.data[2][0], 1000)
     fit.finish()
     assert kmax >= 4608
     print("worst gradient rel-fro vs fp64: HIP %.2e, fp32 CPU autograd %.2e; worst loss rel %.2e, largest K %d"

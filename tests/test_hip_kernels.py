@@ -635,14 +635,14 @@ def test_bn_train_fold_equals_train_mode_batchnorm(shape, momentum):
         want = ref(x.double())
         scale, shift = hip_ops.bn_train_fold(dev, x.cuda())
         got = hip_ops.bn_act(x.cuda(), scale, shift, None, relu=False)
-        assert _rel(got, want) < 1e-6, (step, _rel(got, want))
-        assert _rel(dev.running_mean, ref.running_mean) < 1e-6 and _rel(dev.running_var, ref.running_var) < 1e-6
+        assert _rel(got.cpu(), want) < 1e-6, (step, _rel(got.cpu(), want))
+        assert _rel(dev.running_mean.cpu(), ref.running_mean) < 1e-6 and _rel(dev.running_var.cpu(), ref.running_var) < 1e-6
         assert int(dev.num_batches_tracked) == int(ref.num_batches_tracked) == step + 1
     # no running statistics at all: batch statistics, nothing to update
     free = torch.nn.BatchNorm2d(C, track_running_stats=False).cuda()
     x = torch.randn(shape, generator=g)
     scale, shift = hip_ops.bn_train_fold(free, x.cuda())
     want = torch.nn.functional.batch_norm(x.double(), None, None, free.weight.double().cpu(), free.bias.double().cpu(), True)
-    assert _rel(hip_ops.bn_act(x.cuda(), scale, shift, None, relu=False), want) < 1e-6
+    assert _rel(hip_ops.bn_act(x.cuda(), scale, shift, None, relu=False).cpu(), want) < 1e-6
     with pytest.raises(ValueError):
         hip_ops.bn_train_fold(dev, torch.randn(1, C, 1, 1).cuda())
