@@ -58,6 +58,9 @@ def parse(argv=None):
     ap.add_argument("--phase-log", action="store_true", help="debug: log the phases of that job as they finish")
     ap.add_argument("--prefetch-groups", type=int, default=24,
                     help="groups of source forwards enqueued while the LAP kernel runs (0: none); also bounded by memory")
+    ap.add_argument("--sources-per-forward", type=int, default=0,
+                    help="updates whose batches go through the frozen sources as ONE forward (0: the fitter's default, "
+                         "2 per rank); the prefetch takes --prefetch-groups forwards of that size")
     ap.add_argument("--grad-buckets", type=int, default=1, help="data parallel: 1 (default) = one all-reduce per update; "
                     "2 = the gradient arena is all-reduced in two halves, each beside the other half's kernels")
     ap.add_argument("--prefetch-memory", type=float, default=0.7, help="share of the free HBM the prefetched taps may take")
@@ -192,7 +195,8 @@ def run_job(cfg, spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, phases
 
     def while_solving():
         early["sources"] = src = FrozenSources(m1, m2, data_parallel=dp)
-        src.prefetch(inputs, max_groups=cfg["prefetch_groups"], memory_fraction=cfg["prefetch_memory"])
+        src.prefetch(inputs, group=cfg["sources_per_forward"], max_groups=cfg["prefetch_groups"],
+                     memory_fraction=cfg["prefetch_memory"])
 
     if phases.on:      # the same two calls activation_matching() makes, with a synchronising boundary between them
         costs = accumulate_costs_fused(spec, m1, m2, match_loader, len(match_loader), hip_ops.EPI_NEG_CDIST)
@@ -209,7 +213,7 @@ def run_job(cfg, spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, phases
                       sources=early.get("sources"), grad_buckets=cfg["grad_buckets"])
     phases.mark("merge_and_setup")
     first = None
-    for i in fit.steps(inputs, lookahead=cfg["lookahead"]):
+    for i in fit.steps(inputs, lookahead=cfg["lookahead"], sources_per_forward=cfg["sources_per_forward"]):
         if i == 0:
             first = fit.loss_now.clone()
     last = fit.loss_now.clone()
@@ -406,7 +410,7 @@ def main():
         os.environ["PLEAS_EMULATE_ALLREDUCE_US"] = str(args.emulate_allreduce_us)
         dp = True
     cfg = {"dp": dp, "ratio": args.ratio, "prefetch_groups": args.prefetch_groups, "prefetch_memory": args.prefetch_memory,
-           "grad_buckets": args.grad_buckets, "lookahead": None if args.lookahead < 0 else bool(args.lookahead)}
+           "grad_buckets": args.grad_buckets, "sources_per_forward": args.sources_per_forward or None, "lookahead": None if args.lookahead < 0 else bool(args.lookahead)}
     log("spec (%d groups, %.2f s on the host, outside `value`) + %d synthetic batches resident" % (len(spec), spec_s, len(pool.items)))
 
     def job(phases=None):

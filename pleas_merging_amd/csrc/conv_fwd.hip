@@ -54,7 +54,8 @@ struct FwdLayerDev {
     int Cout, Cin, Hin, Win, Hout, Wout, KH, KW, stride, pad, Csrc, n_merged;
     uint32_t HWo, Ptot, Kd;
     float dscale;         // 2 / (numel * world)
-    int variant;          // bit0: TM == 64, bit1: scalar W loads, bit2: W is kernel-position-major [Cout][KH*KW][Cin]
+    int variant;          // bit0: TM == 64, bit1: scalar W loads, bit2: W is kernel-position-major [Cout][KH*KW][Cin],
+                          // bit3: flat-shift tile (fwd_flat_tile), bits 4-5: its KIND
     int part_base;        // first loss-partial slot of this layer
     int pad0;
 };
@@ -68,6 +69,138 @@ __device__ long long g_fwd_stamps[32768][4];   // per work item: prologue, K loo
 #else
 #define PLEAS_FWD_STAMP(var)
 #endif
+
+// ---- shared by both tile forms: the block maps / biases of a tile's output channels, and the epilogue
+template <int TM>
+__device__ __forceinline__ void fwd_load_maps(const FwdLayerDev& L, const int i0, int (&m1)[TM / 8], int (&m2)[TM / 8],
+                                              float (&bias_v)[TM / 8]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < TM / 8; ++j) {
+        const int co = min(i0 + (tid >> 5) + 8 * j, L.Cout - 1);
+        m1[j] = PLEAS_GLOBAL_I(L.row1)[co];
+        m2[j] = PLEAS_GLOBAL_I(L.row2)[co];
+        bias_v[j] = L.bias ? PLEAS_GLOBAL(L.bias)[co] : 0.f;
+    }
+}
+
+template <int TM>
+__device__ __forceinline__ void fwd_epilogue(const FwdLayerDev& L, const FwdItemDev& it, f32x16 (&acc)[TM / 64][2],
+                                             const int (&m1)[TM / 8], const int (&m2)[TM / 8],
+                                             const float (&bias_v)[TM / 8], float* smem, float* __restrict__ partials) {
+    constexpr int MTM = TM / 64;
+    constexpr int ROWS = TM / 8, GB = 8, NB = ROWS / GB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i0 = it.tm * TM;
+    const uint32_t p0 = (uint32_t)it.tp * fTN;
+    // ---- epilogue.  Accumulators hold one pixel per lane; go through LDS once ([co][pixel], stride 132) so that
+    //      each thread then owns 4 consecutive pixels of one output channel: 16-B target gathers, 16-B residual stores.
+    if constexpr ((PLEAS_FWD_ABLATE & 2) != 0) {   // keep the accumulators alive with one store per wave
+        float s = 0.f;
+#pragma unroll
+        for (int sm = 0; sm < MTM; ++sm)
+#pragma unroll
+            for (int sn = 0; sn < 2; ++sn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc[sm][sn][r];
+        if (s == 12345.678f) partials[L.part_base + it.slot] = s;
+        return;
+    }
+    constexpr int EL = 132;
+    float* Ct = smem;  // [TM][EL] floats <= the staging buffers just released by the last barrier of the K loop
+    auto spill_acc = [&]() {
+#pragma unroll
+        for (int sm = 0; sm < MTM; ++sm)
+#pragma unroll
+            for (int sn = 0; sn < 2; ++sn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int lco = wm * (TM / 2) + sm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    Ct[lco * EL + wn * 64 + sn * 32 + (lane & 31)] = acc[sm][sn][r];
+                }
+        __syncthreads();
+    };
+    float sq = 0.f;
+    const bool vec_ok = (L.HWo % 4 == 0);   // then a 4-pixel group never straddles samples and is 16-B aligned
+    const int pg = (tid & 31) * 4;           // pixel group of this thread
+    const uint32_t Pg = p0 + pg;
+    const bool gin = Pg < L.Ptot;
+    const uint32_t gn = gin ? Pg / L.HWo : 0u, gp = gin ? Pg - gn * L.HWo : 0u;
+    // Each thread owns TM/8 output channels (lco = tid/32 + 8 j) x 4 pixels.  Order, chosen so that global-memory latency
+    // is exposed once instead of once per step: block maps + bias -> first batch of target gathers (8 channels, branch
+    // free: absent / out-of-range rows read element 0 and are masked) -> accumulators through LDS (the gathers are in
+    // flight meanwhile) -> second batch issued -> first consumed -> second consumed.
+    if (vec_ok) {
+        f32x4 ta[NB][GB], tb[NB][GB];
+        auto gather = [&](const int bt) {
+#pragma unroll
+            for (int u = 0; u < GB; ++u) {
+                const int j = bt * GB + u;
+                const size_t oa = (((size_t)gn * L.Csrc + max(m1[j], 0)) * L.HWo + gp) & (size_t)(-(long long)(gin && m1[j] >= 0));
+                const size_t ob = (((size_t)gn * L.Csrc + max(m2[j], 0)) * L.HWo + gp) & (size_t)(-(long long)(gin && m2[j] >= 0));
+                if constexpr ((PLEAS_FWD_ABLATE & 1) != 0) {
+                    ta[bt][u] = f32x4{(float)(oa & 3), 0.f, 0.f, 0.f};
+                    tb[bt][u] = f32x4{(float)(ob & 3), 0.f, 0.f, 0.f};
+                } else {
+                    ta[bt][u] = *(const __attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL(L.o1) + oa);
+                    tb[bt][u] = *(const __attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL(L.o2) + ob);
+                }
+            }
+        };
+        auto consume = [&](const int bt) {
+#pragma unroll
+            for (int u = 0; u < GB; ++u) {
+                const int j = bt * GB + u;
+                const int lco = (tid >> 5) + 8 * j, co = i0 + lco;
+                const bool live = gin && co < L.Cout;
+                const float coef = co < L.n_merged ? 0.5f : 1.0f;
+                const float fa = m1[j] >= 0 ? 1.f : 0.f, fb = m2[j] >= 0 ? 1.f : 0.f;
+                const f32x4 o = *reinterpret_cast<const f32x4*>(Ct + lco * EL + pg);
+                f32x4 d;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float dd = (o[e] + bias_v[j]) - (ta[bt][u][e] * fa + tb[bt][u][e] * fb) * coef;
+                    sq = live ? fmaf(dd, dd, sq) : sq;
+                    d[e] = L.dscale * dd;
+                }
+                if (live) *(__attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL_W(L.resid) + ((size_t)gn * L.Cout + co) * L.HWo + gp) = d;
+            }
+        };
+        gather(0);
+        spill_acc();
+        if constexpr (NB > 1) gather(1);
+        consume(0);
+        if constexpr (NB > 1) consume(1);
+    } else {
+        spill_acc();
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            const int lco = (tid >> 5) + 8 * j, co = i0 + lco;
+            if (co >= L.Cout || !gin) continue;
+            const float coef = co < L.n_merged ? 0.5f : 1.0f;
+            const f32x4 o = *reinterpret_cast<const f32x4*>(Ct + lco * EL + pg);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t Pe = Pg + e;
+                if (Pe >= L.Ptot) break;
+                const uint32_t n = Pe / L.HWo, p = Pe - n * L.HWo;
+                float a = 0.f, b = 0.f;
+                if (m1[j] >= 0) a = PLEAS_GLOBAL(L.o1)[((size_t)n * L.Csrc + m1[j]) * L.HWo + p];
+                if (m2[j] >= 0) b = PLEAS_GLOBAL(L.o2)[((size_t)n * L.Csrc + m2[j]) * L.HWo + p];
+                const float dd = (o[e] + bias_v[j]) - (a + b) * coef;
+                sq = fmaf(dd, dd, sq);
+                PLEAS_GLOBAL_W(L.resid)[((size_t)n * L.Cout + co) * L.HWo + p] = L.dscale * dd;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off);
+    __syncthreads();  // everyone is done with Ct: reuse its first floats for the block sum
+    if (lane == 0) smem[wave] = sq;
+    __syncthreads();
+    if (tid == 0) partials[L.part_base + it.slot] = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+}
 
 template <int TM, int VECA>
 __device__ __forceinline__ void fwd_tile(const FwdLayerDev& L, const FwdItemDev& it, float* smem, float* __restrict__ partials) {
@@ -246,18 +379,10 @@ __device__ __forceinline__ void fwd_tile(const FwdLayerDev& L, const FwdItemDev&
     PLEAS_FWD_STAMP(st1);
     // The block maps and biases of the epilogue are requested before the LAST chunk's MFMAs (no staging loads are in
     // flight then): their round trip is covered by that chunk instead of opening the epilogue.
-    constexpr int ROWS = TM / 8, GB = 8, NB = ROWS / GB;
+    constexpr int ROWS = TM / 8;
     int m1[ROWS], m2[ROWS];
     float bias_v[ROWS];
-    auto load_maps = [&]() {
-#pragma unroll
-        for (int j = 0; j < ROWS; ++j) {
-            const int co = min(i0 + (tid >> 5) + 8 * j, L.Cout - 1);
-            m1[j] = PLEAS_GLOBAL_I(L.row1)[co];
-            m2[j] = PLEAS_GLOBAL_I(L.row2)[co];
-            bias_v[j] = L.bias ? PLEAS_GLOBAL(L.bias)[co] : 0.f;
-        }
-    };
+    auto load_maps = [&]() { fwd_load_maps<TM>(L, i0, m1, m2, bias_v); };
     for (int c = 0; c + 1 < nchunks; ++c) {
         const int buf = c & 1;
         load_chunk(c + 1);
@@ -270,112 +395,7 @@ __device__ __forceinline__ void fwd_tile(const FwdLayerDev& L, const FwdItemDev&
     __syncthreads();
     PLEAS_FWD_STAMP(st2);
 
-    // ---- epilogue.  Accumulators hold one pixel per lane; go through LDS once ([co][pixel], stride 132) so that
-    //      each thread then owns 4 consecutive pixels of one output channel: 16-B target gathers, 16-B residual stores.
-    if constexpr ((PLEAS_FWD_ABLATE & 2) != 0) {   // keep the accumulators alive with one store per wave
-        float s = 0.f;
-#pragma unroll
-        for (int sm = 0; sm < MTM; ++sm)
-#pragma unroll
-            for (int sn = 0; sn < 2; ++sn)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s += acc[sm][sn][r];
-        if (s == 12345.678f) partials[L.part_base + it.slot] = s;
-        return;
-    }
-    constexpr int EL = 132;
-    float* Ct = smem;  // [TM][EL] floats <= the staging buffers just released by the last barrier of the K loop
-    auto spill_acc = [&]() {
-#pragma unroll
-        for (int sm = 0; sm < MTM; ++sm)
-#pragma unroll
-            for (int sn = 0; sn < 2; ++sn)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int lco = wm * (TM / 2) + sm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    Ct[lco * EL + wn * 64 + sn * 32 + (lane & 31)] = acc[sm][sn][r];
-                }
-        __syncthreads();
-    };
-    float sq = 0.f;
-    const bool vec_ok = (L.HWo % 4 == 0);   // then a 4-pixel group never straddles samples and is 16-B aligned
-    const int pg = (tid & 31) * 4;           // pixel group of this thread
-    const uint32_t Pg = p0 + pg;
-    const bool gin = Pg < L.Ptot;
-    const uint32_t gn = gin ? Pg / L.HWo : 0u, gp = gin ? Pg - gn * L.HWo : 0u;
-    // Each thread owns TM/8 output channels (lco = tid/32 + 8 j) x 4 pixels.  Order, chosen so that global-memory latency
-    // is exposed once instead of once per step: block maps + bias -> first batch of target gathers (8 channels, branch
-    // free: absent / out-of-range rows read element 0 and are masked) -> accumulators through LDS (the gathers are in
-    // flight meanwhile) -> second batch issued -> first consumed -> second consumed.
-    if (vec_ok) {
-        f32x4 ta[NB][GB], tb[NB][GB];
-        auto gather = [&](const int bt) {
-#pragma unroll
-            for (int u = 0; u < GB; ++u) {
-                const int j = bt * GB + u;
-                const size_t oa = (((size_t)gn * L.Csrc + max(m1[j], 0)) * L.HWo + gp) & (size_t)(-(long long)(gin && m1[j] >= 0));
-                const size_t ob = (((size_t)gn * L.Csrc + max(m2[j], 0)) * L.HWo + gp) & (size_t)(-(long long)(gin && m2[j] >= 0));
-                if constexpr ((PLEAS_FWD_ABLATE & 1) != 0) {
-                    ta[bt][u] = f32x4{(float)(oa & 3), 0.f, 0.f, 0.f};
-                    tb[bt][u] = f32x4{(float)(ob & 3), 0.f, 0.f, 0.f};
-                } else {
-                    ta[bt][u] = *(const __attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL(L.o1) + oa);
-                    tb[bt][u] = *(const __attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL(L.o2) + ob);
-                }
-            }
-        };
-        auto consume = [&](const int bt) {
-#pragma unroll
-            for (int u = 0; u < GB; ++u) {
-                const int j = bt * GB + u;
-                const int lco = (tid >> 5) + 8 * j, co = i0 + lco;
-                const bool live = gin && co < L.Cout;
-                const float coef = co < L.n_merged ? 0.5f : 1.0f;
-                const float fa = m1[j] >= 0 ? 1.f : 0.f, fb = m2[j] >= 0 ? 1.f : 0.f;
-                const f32x4 o = *reinterpret_cast<const f32x4*>(Ct + lco * EL + pg);
-                f32x4 d;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float dd = (o[e] + bias_v[j]) - (ta[bt][u][e] * fa + tb[bt][u][e] * fb) * coef;
-                    sq = live ? fmaf(dd, dd, sq) : sq;
-                    d[e] = L.dscale * dd;
-                }
-                if (live) *(__attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL_W(L.resid) + ((size_t)gn * L.Cout + co) * L.HWo + gp) = d;
-            }
-        };
-        gather(0);
-        spill_acc();
-        if constexpr (NB > 1) gather(1);
-        consume(0);
-        if constexpr (NB > 1) consume(1);
-    } else {
-        spill_acc();
-#pragma unroll
-        for (int j = 0; j < ROWS; ++j) {
-            const int lco = (tid >> 5) + 8 * j, co = i0 + lco;
-            if (co >= L.Cout || !gin) continue;
-            const float coef = co < L.n_merged ? 0.5f : 1.0f;
-            const f32x4 o = *reinterpret_cast<const f32x4*>(Ct + lco * EL + pg);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const uint32_t Pe = Pg + e;
-                if (Pe >= L.Ptot) break;
-                const uint32_t n = Pe / L.HWo, p = Pe - n * L.HWo;
-                float a = 0.f, b = 0.f;
-                if (m1[j] >= 0) a = PLEAS_GLOBAL(L.o1)[((size_t)n * L.Csrc + m1[j]) * L.HWo + p];
-                if (m2[j] >= 0) b = PLEAS_GLOBAL(L.o2)[((size_t)n * L.Csrc + m2[j]) * L.HWo + p];
-                const float dd = (o[e] + bias_v[j]) - (a + b) * coef;
-                sq = fmaf(dd, dd, sq);
-                PLEAS_GLOBAL_W(L.resid)[((size_t)n * L.Cout + co) * L.HWo + p] = L.dscale * dd;
-            }
-        }
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off);
-    __syncthreads();  // everyone is done with Ct: reuse its first floats for the block sum
-    if (lane == 0) smem[wave] = sq;
-    __syncthreads();
-    if (tid == 0) partials[L.part_base + it.slot] = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+    fwd_epilogue<TM>(L, it, acc, m1, m2, bias_v, smem, partials);
 #if (PLEAS_FWD_ABLATE & 16)
     if (tid == 0 && blockIdx.x < 32768) {
         const long long st3 = clock64();
@@ -387,6 +407,273 @@ __device__ __forceinline__ void fwd_tile(const FwdLayerDev& L, const FwdItemDev&
 #endif
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// "Flat-shift" tile: stride-1, same-size convolutions (1x1, 3x3 pad 1, 5x5 pad 2 ...) with Cin % 32 == 0 -- 97 % of a
+// ResNet's merged-layer flops.  For a fixed channel the HW pixels of a sample are contiguous, and tap (kh, kw) of a
+// stride-1 same-size convolution reads the SAME flat pixel run shifted by delta = (kh - pad) * W + (kw - pad).  So the
+// input operand of a whole channel block (32 channels x all KH*KW taps) is ONE LDS image
+//     Bs[k][j],  j = 0 .. 128 + 2 * halo,   halo = pad * (W + 1),   holding flat pixels p0 - halo .. p0 + 127 + halo,
+// loaded once per channel block (16-B loads along the pixel axis for 1x1 layers, 9x fewer loads than one gather per tap
+// for 3x3), and the MFMA B fragment of tap r is a plain ds_read_b32 at  Bs[k][halo + pixel + delta_r].  Border taps
+// (left / right column, top / bottom row, neighbouring sample) are not masked value by value: a lane whose pixel does not
+// have tap r reads the row's ZERO COLUMN instead (one select on the address per tap and 32-pixel fragment).
+// Weights: kernel-position-major chunks (tap r, channel block) exactly as in fwd_tile; accumulators and epilogue shared.
+constexpr int fFlatRow1 = 132;     // Bs row stride of 1x1 layers: 128 pixels + zero column, 16-B aligned rows
+constexpr int fFlatRowK = 260;     // Bs row stride of k x k layers: 128 + 2 * halo <= 256 data columns + zero column
+// KIND 0: 1x1, 16-B loads along the pixel axis (HW % 4 == 0), two images (double buffer)
+// KIND 1: 1x1, scalar loads (HW % 4 != 0, e.g. 7 x 7), two images
+// KIND 2: k x k, scalar loads, ONE image per channel block shared by all taps
+template <int TM, int KIND>
+__device__ __forceinline__ void fwd_flat_tile(const FwdLayerDev& L, const FwdItemDev& it, float* smem, float* __restrict__ partials) {
+    constexpr int MTM = TM / 64;
+    constexpr int LPR = fBK / 4, RPP = fThreads / LPR, PASS = TM / RPP;   // weight staging: 16-B loads
+    constexpr int Lr = KIND == 2 ? fFlatRowK : fFlatRow1;               // compile-time: LDS offsets are immediates
+    constexpr int jz = Lr - 1;                                           // the zero column
+    constexpr int NBUF = KIND == 2 ? 1 : 2;
+    constexpr int MCOL = KIND == 2 ? 4 : 2;                              // scalar form: column passes of 64 lanes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i0 = it.tm * TM;
+    const uint32_t p0 = (uint32_t)it.tp * fTN;
+    const int R = KIND == 2 ? L.KH * L.KW : 1;
+    const int W = L.Win;
+    const uint32_t HW = L.HWo;                       // == Hin * Win
+    const int halo = KIND == 2 ? L.pad * (W + 1) : 0;
+    const int span = fTN + 2 * halo;                 // data columns of a Bs row
+    const int CB = L.Cin / fBK;
+    const int nchunks = CB * R;
+    float* As = smem;                                // [2][TM][fLdsA]
+    float* Bs = smem + 2 * TM * fLdsA;               // [NBUF][32][Lr]
+
+    // ---- A (weights) staging, as in fwd_tile with VECA = 4
+    const int arow = tid / LPR, acol = (tid % LPR) * 4;
+    f32x4 ra0[PASS], ra1[PASS];    // two register sets: the weights of chunk c + 2 are requested while chunk c computes
+    unsigned oka = 0;
+    uint32_t offa[PASS];
+#pragma unroll
+    for (int q = 0; q < PASS; ++q) {
+        const int gi = i0 + arow + q * RPP;
+        if (gi < L.Cout) oka |= 1u << q;
+        offa[q] = (uint32_t)min(gi, L.Cout - 1) * L.Kd;
+    }
+    // ---- B (input) staging.
+    //   KIND 0: thread = (row tid / 32 + 8 i, pixel group tid % 32), i < 4: four 16-B loads per chunk
+    //   else  : wave w owns rows 8 w .. 8 w + 7, lane covers columns lane + 64 m (columns >= span unused)
+    uint32_t voff[MCOL];
+    unsigned vok = 0;
+    constexpr int NRB = KIND == 0 ? 16 : 8 * MCOL;
+    float rb0[NRB], rb1[KIND == 2 ? 1 : NRB];   // 1x1 forms: two sets as well (a new image every chunk)
+    if constexpr (KIND == 0) {
+        const uint32_t P4 = p0 + 4u * (tid & 31);
+        const bool ok = P4 < L.Ptot;
+        const uint32_t n = ok ? P4 / HW : 0u, p = ok ? P4 - n * HW : 0u;
+        voff[0] = ok ? n * (uint32_t)L.Cin * HW + p + (uint32_t)(tid >> 5) * HW : 0u;
+        voff[1] = 0;
+        vok = ok ? 1u : 0u;
+    } else {
+#pragma unroll
+        for (int m = 0; m < MCOL; ++m) {
+            const int j = lane + 64 * m;
+            const long long Pv = (long long)p0 - halo + j;
+            const bool ok = j < span && Pv >= 0 && Pv < (long long)L.Ptot;
+            const uint32_t n = ok ? (uint32_t)Pv / HW : 0u, p = ok ? (uint32_t)Pv - n * HW : 0u;
+            voff[m] = ok ? n * (uint32_t)L.Cin * HW + p : 0u;
+            vok |= (ok ? 1u : 0u) << m;
+        }
+    }
+    const int M = (span + 63) / 64;                    // scalar form: column passes that hold data (wave-uniform)
+
+    // ---- MFMA-side view of this lane's two pixels (fragments sn = 0, 1): LDS column and tap validity
+    int jb[2];
+    unsigned tapok[2];
+#pragma unroll
+    for (int sn = 0; sn < 2; ++sn) {
+        const int q = wn * 64 + sn * 32 + (lane & 31);
+        const uint32_t P = p0 + q;
+        jb[sn] = halo + q;
+        unsigned mask = 0;
+        if (P < L.Ptot) {
+            if constexpr (KIND == 2) {
+                const uint32_t n = P / HW, pp = P - n * HW;
+                const int oh = (int)(pp / (uint32_t)W), ow = (int)(pp - (uint32_t)oh * W);
+                for (int r = 0; r < R; ++r) {
+                    const int kh = r / L.KW, kw = r - kh * L.KW;
+                    const int ih = oh + kh - L.pad, iw = ow + kw - L.pad;
+                    mask |= (unsigned)(ih >= 0 && ih < L.Hin && iw >= 0 && iw < W) << r;
+                }
+            } else {
+                mask = 1u;
+            }
+        }
+        tapok[sn] = mask;
+    }
+
+    f32x16 acc[MTM][2];
+#pragma unroll
+    for (int a = 0; a < MTM; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    auto load_a = [&](int cb, int r, f32x4 (&ra)[PASS]) {
+        const uint32_t k = (uint32_t)r * L.Cin + (uint32_t)cb * fBK + acol;    // kernel-position-major (== plain for 1x1)
+#pragma unroll
+        for (int q = 0; q < PASS; ++q) {
+            if constexpr ((PLEAS_FWD_ABLATE & 8) != 0) ra[q] = f32x4{(float)(k & 3), 0.f, 1.f, 0.f}; else
+            ra[q] = *(const __attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL(L.w) + offa[q] + k);
+        }
+    };
+    auto store_a = [&](int buf, const f32x4 (&ra)[PASS]) {
+        float* a = As + buf * TM * fLdsA;
+#pragma unroll
+        for (int q = 0; q < PASS; ++q) {
+            const bool ok = (oka >> q) & 1u;
+            const f32x4 v = {ok ? ra[q][0] : 0.f, ok ? ra[q][1] : 0.f, ok ? ra[q][2] : 0.f, ok ? ra[q][3] : 0.f};
+            *reinterpret_cast<f32x4*>(a + (arow + q * RPP) * fLdsA + acol) = v;
+        }
+    };
+    auto load_b = [&](int cb, auto& rb) {
+        const cgfloat* base = PLEAS_GLOBAL(L.ip) + (size_t)cb * fBK * HW;
+        if constexpr (KIND == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 v;
+                if constexpr ((PLEAS_FWD_ABLATE & 4) != 0) v = f32x4{(float)(cb & 3), 0.f, 1.f, 0.f}; else
+                v = *(const __attribute__((address_space(1))) f32x4*)(base + voff[0] + (uint32_t)(8 * i) * HW);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rb[4 * i + e] = v[e];
+            }
+        } else {
+            const cgfloat* wbase = base + (size_t)(8 * wave) * HW;     // wave-uniform row block
+#pragma unroll
+            for (int kr = 0; kr < 8; ++kr)
+#pragma unroll
+                for (int m = 0; m < MCOL; ++m)
+                    if (m < M) {
+                        if constexpr ((PLEAS_FWD_ABLATE & 4) != 0) rb[kr * MCOL + m] = (float)((cb + kr) & 3); else
+                        rb[kr * MCOL + m] = wbase[(size_t)kr * HW + voff[m]];
+                    }
+        }
+    };
+    auto store_b = [&](int buf, const auto& rb) {
+        float* b = Bs + buf * fBK * Lr;
+        if constexpr (KIND == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 v = {vok ? rb[4 * i] : 0.f, vok ? rb[4 * i + 1] : 0.f, vok ? rb[4 * i + 2] : 0.f, vok ? rb[4 * i + 3] : 0.f};
+                *reinterpret_cast<f32x4*>(b + ((tid >> 5) + 8 * i) * Lr + 4 * (tid & 31)) = v;
+            }
+        } else {
+#pragma unroll
+            for (int kr = 0; kr < 8; ++kr)
+#pragma unroll
+                for (int m = 0; m < MCOL; ++m)
+                    if (m < M && lane + 64 * m < span)
+                        b[(8 * wave + kr) * Lr + lane + 64 * m] = ((vok >> m) & 1u) ? rb[kr * MCOL + m] : 0.f;
+        }
+    };
+    auto compute = [&](int abuf, int bbuf, int r) {
+        int delta = 0;
+        if constexpr (KIND == 2) {
+            const int kh = r / L.KW, kw = r - kh * L.KW;
+            delta = (kh - L.pad) * W + (kw - L.pad);
+        }
+        const float* a = As + abuf * TM * fLdsA + (wm * (TM / 2) + (lane & 31)) * fLdsA + 4 * (lane >> 5);
+        const float* bb = Bs + bbuf * fBK * Lr + 4 * (lane >> 5) * Lr;     // half-wave h takes k = 8 kk + e + 4 h
+        const float* b0 = bb + (((tapok[0] >> r) & 1u) ? jb[0] + delta : jz);
+        const float* b1 = bb + (((tapok[1] >> r) & 1u) ? jb[1] + delta : jz);
+#pragma unroll
+        for (int kk = 0; kk < fBK / 8; ++kk) {
+            f32x4 fa[MTM];
+#pragma unroll
+            for (int s = 0; s < MTM; ++s) fa[s] = *reinterpret_cast<const f32x4*>(a + s * 32 * fLdsA + kk * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float f0 = b0[(kk * 8 + e) * Lr], f1 = b1[(kk * 8 + e) * Lr];
+#pragma unroll
+                for (int sm = 0; sm < MTM; ++sm) {
+                    acc[sm][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sm][e], f0, acc[sm][0], 0, 0, 0);
+                    acc[sm][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sm][e], f1, acc[sm][1], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    // zero column of every row of every image (never overwritten: data columns end at span - 1 < jz)
+    if (tid < fBK * NBUF) Bs[tid * Lr + jz] = 0.f;
+    load_a(0, 0, ra0);
+    load_b(0, rb0);
+    store_a(0, ra0);
+    store_b(0, rb0);
+    __syncthreads();
+    constexpr int ROWS = TM / 8;
+    int m1[ROWS], m2[ROWS];
+    float bias_v[ROWS];
+    // Software pipeline, two chunks deep for the global loads: while chunk c computes, the operands of chunk c + 1 are in
+    // flight or in registers (requested one iteration earlier) and those of chunk c + 2 are requested.  k x k forms load
+    // the input image of the next channel block two taps before its first use.
+    int bsel = 0;
+    int r1 = R > 1 ? 1 : 0, cb1 = R > 1 ? 0 : 1;       // (channel block, tap) of chunk c + 1
+    if (nchunks > 1) {
+        load_a(cb1, r1, ra1);
+        if constexpr (KIND != 2) load_b(cb1, rb1);
+    }
+    auto step = [&](int c, int r, f32x4 (&ra_next)[PASS], f32x4 (&ra_far)[PASS], auto& rb_next, auto& rb_far) {
+        // chunk c computes; chunk c + 1 (operands in *_next) is stored afterwards; chunk c + 2 is requested into *_far
+        int r2 = r1 + 1, cb2 = cb1;
+        if (r2 == R) { r2 = 0; ++cb2; }
+        const bool far = c + 2 < nchunks;
+        const bool newb = r1 == 0;                   // chunk c + 1 starts a new channel block
+        if (far) load_a(cb2, r2, ra_far);
+        if constexpr (KIND != 2) {
+            if (far) load_b(cb2, rb_far);
+        } else {
+            // the image of block cb1 + 1 (first used by chunk c + 1 + (R - r1)) is requested when chunk c + 1 is its
+            // block's second-to-last tap, i.e. two chunks before the store below needs it
+            if (r1 == R - 2 && cb1 + 1 < CB) load_b(cb1 + 1, rb0);     // ONE register set: an image per R chunks
+        }
+        compute(c & 1, bsel, r);
+        store_a((c + 1) & 1, ra_next);
+        if (newb) {
+            if constexpr (NBUF == 2) {
+                bsel ^= 1;
+                store_b(bsel, rb_next);
+            } else {
+                __syncthreads();                     // every wave is done reading the single image
+                store_b(0, rb0);
+            }
+        }
+        __syncthreads();
+        r1 = r2;
+        cb1 = cb2;
+    };
+    int r = 0;
+    int c = 0;
+    for (; c + 2 < nchunks; c += 2) {
+        const int ra_ = r1;                          // tap of chunk c + 1, read before step() advances it
+        step(c, r, ra1, ra0, rb1, rb0);
+        const int rb_ = r1;
+        step(c + 1, ra_, ra0, ra1, rb0, rb1);
+        r = rb_;
+    }
+    if (c + 1 < nchunks) {
+        const int ra_ = r1;
+        step(c, r, ra1, ra0, rb1, rb0);
+        r = ra_;
+    }
+    fwd_load_maps<TM>(L, i0, m1, m2, bias_v);        // epilogue operands, requested under the last chunk's MFMAs
+    compute((nchunks - 1) & 1, bsel, r);
+    __syncthreads();
+    fwd_epilogue<TM>(L, it, acc, m1, m2, bias_v, smem, partials);
+}
+
+// One kernel per tile form (register allocation and LDS are then per form, not the maximum over all of them); the host
+// launches each form's slice of the item list.  Form ids: 0-3 = fwd_tile<128,4>, <64,4>, <128,1>, <64,1>;
+// 4-6 = fwd_flat_tile<128, KIND 0-2>;  7-9 = fwd_flat_tile<64, KIND 0-2>.
+constexpr int fForms = 10;
+template <int FORM>
 __global__ __launch_bounds__(fThreads, 2) void fwd_batch_kernel(const FwdLayerDev* __restrict__ layers,
                                                              const FwdItemDev* __restrict__ items,
                                                              float* __restrict__ partials) {
@@ -394,12 +681,35 @@ __global__ __launch_bounds__(fThreads, 2) void fwd_batch_kernel(const FwdLayerDe
     const FwdItemDev it = items[blockIdx.x];
     if (it.layer < 0) return;   // padding of the XCD-aware item order
     const FwdLayerDev L = layers[it.layer];
-    switch (L.variant & 3) {
-        case 0: fwd_tile<128, 4>(L, it, smem, partials); break;
-        case 1: fwd_tile<64, 4>(L, it, smem, partials); break;
-        case 2: fwd_tile<128, 1>(L, it, smem, partials); break;
-        default: fwd_tile<64, 1>(L, it, smem, partials); break;
+    if constexpr (FORM == 0) fwd_tile<128, 4>(L, it, smem, partials);
+    else if constexpr (FORM == 1) fwd_tile<64, 4>(L, it, smem, partials);
+    else if constexpr (FORM == 2) fwd_tile<128, 1>(L, it, smem, partials);
+    else if constexpr (FORM == 3) fwd_tile<64, 1>(L, it, smem, partials);
+    else if constexpr (FORM < 7) fwd_flat_tile<128, FORM - 4>(L, it, smem, partials);
+    else fwd_flat_tile<64, FORM - 7>(L, it, smem, partials);
+}
+// side streams + events of the library for the concurrent forms (created once per process; no device memory)
+struct FwdSideStreams {
+    hipStream_t streams[fForms - 1];
+    hipEvent_t forked, joined[fForms - 1];
+    bool ok = false;
+};
+static FwdSideStreams& fwd_side_streams() {
+    static FwdSideStreams s;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        bool ok = hipEventCreateWithFlags(&s.forked, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; ok && i < fForms - 1; ++i)
+            ok = hipStreamCreateWithFlags(&s.streams[i], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&s.joined[i], hipEventDisableTiming) == hipSuccess;
+        s.ok = ok;
     }
+    return s;
+}
+static inline int fwd_form_of(int variant) {
+    if (variant & 8) return ((variant & 1) ? 7 : 4) + ((variant >> 4) & 3);
+    return variant & 3;
 }
 
 // loss[l] = scale[l] * sum of this layer's partials (fixed order, fp64 combine)
@@ -450,7 +760,9 @@ struct FwdPlan {
     std::vector<FwdLayerDev> layers;
     std::vector<FwdItemDev> items;
     std::vector<FwdLossDev> loss;
-    size_t off_layers = 0, off_items = 0, off_loss = 0, off_parts = 0, total = 0, lds = 0;
+    size_t off_layers = 0, off_items = 0, off_loss = 0, off_parts = 0, total = 0;
+    int form_begin[fForms] = {0}, form_count[fForms] = {0}, form_order[fForms] = {0};
+    size_t form_lds[fForms] = {0};
     double flops = 0, bytes = 0;
     int n_parts = 0;
     bool uploaded = false;
@@ -464,8 +776,9 @@ static int build_fwd_plan(FwdPlan& P, const pleas_fwd_layer* ly, int n) {
     P.items.clear();
     P.loss.assign(n, FwdLossDev());
     P.flops = P.bytes = 0;
-    P.lds = 0;
-    std::vector<XcdWork<FwdItemDev>> work;
+    std::vector<XcdWork<FwdItemDev>> work[fForms];
+    double form_work[fForms] = {0};
+    for (int f = 0; f < fForms; ++f) P.form_lds[f] = 0;
     int parts = 0;
     for (int i = 0; i < n; ++i) {
         const pleas_fwd_layer& l = ly[i];
@@ -482,11 +795,32 @@ static int build_fwd_plan(FwdPlan& P, const pleas_fwd_layer* ly, int n) {
         d.KH = l.KH; d.KW = l.KW; d.stride = l.stride; d.pad = l.pad; d.Csrc = l.Csrc; d.n_merged = l.n_merged;
         d.HWo = (uint32_t)HWo; d.Ptot = (uint32_t)Ptot; d.Kd = (uint32_t)Kd;
         d.dscale = l.dscale;
-        const int TM = l.Cout > 64 ? 128 : 64;
+        // short-K layers (1x1 with few input channels) are bound by their epilogue's memory traffic, not by the MFMAs:
+        // 64-row tiles (52 KB of LDS, <= 132 registers) let THREE workgroups share a CU and overlap more of it
+        static const int tm64_k = std::getenv("PLEAS_FWD_TM64_K") ? std::atoi(std::getenv("PLEAS_FWD_TM64_K")) : 256;
+        const int TM = (l.Cout > 64 && !(l.KH * l.KW == 1 && l.stride == 1 && Kd <= tm64_k && l.Cin % fBK == 0)) ? 128 : 64;
         d.variant = (TM == 64 ? 1 : 0) | (Kd % 4 == 0 ? 0 : 2);
         if (l.flags & PLEAS_FWD_KPOS_MAJOR) {
             if (l.Cin % fBK != 0) return bad_arg("conv_fwd: kernel-position-major weights need Cin % 32 == 0");
             d.variant |= 4;
+        }
+        size_t lds_bytes = (size_t)(2 * TM * fLdsA + 2 * fTN * fLdsB) * sizeof(float);  // >= TM*132 floats (epilogue)
+        {
+            // flat-shift form: stride 1, square odd kernel with "same" padding, whole 32-channel blocks, and (for k > 1)
+            // kernel-position-major weights; its LDS must not exceed the general form's (two workgroups per CU)
+            static const bool flat_on = !(std::getenv("PLEAS_FWD_FLAT") && std::atoi(std::getenv("PLEAS_FWD_FLAT")) == 0);
+            const int R = l.KH * l.KW;
+            const bool same = l.stride == 1 && l.KH == l.KW && (l.KH & 1) && l.pad == (l.KH - 1) / 2;
+            const int halo = l.pad * (l.Win + 1);
+            const int kind = R > 1 ? 2 : (HWo % 4 == 0 ? 0 : 1);
+            const int Lr = kind == 2 ? fFlatRowK : fFlatRow1;
+            const size_t flat_lds = std::max((size_t)(2 * TM * fLdsA + (kind == 2 ? 1 : 2) * fBK * Lr) * sizeof(float),
+                                             (size_t)TM * 132 * sizeof(float));
+            if (flat_on && same && l.Cin % fBK == 0 && R <= 32 && (R == 1 || (l.flags & PLEAS_FWD_KPOS_MAJOR)) &&
+                fTN + 2 * halo < Lr && flat_lds <= lds_bytes && (int64_t)l.N * l.Cin * HWo < (1ll << 32)) {
+                d.variant |= 8 | (kind << 4);
+                lds_bytes = flat_lds;
+            }
         }
         d.part_base = parts;
         const int tms = (int)ceil_div(l.Cout, TM), tps = (int)ceil_div(Ptot, fTN);
@@ -504,37 +838,46 @@ static int build_fwd_plan(FwdPlan& P, const pleas_fwd_layer* ly, int n) {
                 // all items of a layer re-read its weights (and, across tm, its input): keep them on one XCD; layers
                 // with many pixel tiles are cut into runs of 32 tiles so that the 8 queues still balance
                 w.key = (int64_t)i * 65536 + tp / 32;
-                work.push_back(w);
+                work[fwd_form_of(d.variant)].push_back(w);
+                form_work[fwd_form_of(d.variant)] += w.w;
             }
         P.loss[i] = FwdLossDev{parts, slot, l.loss_scale, 0};
         parts += slot;
-        P.lds = std::max(P.lds, (size_t)(2 * TM * fLdsA + 2 * fTN * fLdsB) * sizeof(float));  // >= TM*132 floats (epilogue)
+        P.form_lds[fwd_form_of(d.variant)] = std::max(P.form_lds[fwd_form_of(d.variant)], lds_bytes);
         P.flops += 2.0 * l.Cout * (double)Kd * (double)Ptot;
         P.bytes += ((double)l.Cin * l.N * l.Hin * l.Win + 3.0 * l.Cout * (double)Ptot) * sizeof(float);
     }
     // Off by default for this kernel (PLEAS_XCD_ORDER=1 turns it on): it cuts FETCH_SIZE by 32 % (8.3 -> 6.1 GB per launch)
     // but costs 1-4 % of time -- co-resident workgroups of one layer reach their latency-bound epilogues together,
     // while the plain longest-first order mixes layers on a CU.
-    P.items = xcd_order_items(work, FwdItemDev{-1, 0, 0, 0}, /*by_default=*/false);
-    if (const char* env = std::getenv("PLEAS_FWD_ORDER")) {   // experiments: 1 = pseudo-random order, 2 = long / short interleaved
-        const int mode = std::atoi(env);
-        if (mode == 1) {
-            uint64_t st = 0x9E3779B97F4A7C15ull;
-            for (size_t i = P.items.size(); i > 1; --i) {
-                st = st * 6364136223846793005ull + 1442695040888963407ull;
-                std::swap(P.items[i - 1], P.items[(size_t)((st >> 33) % i)]);
+    for (int f = 0; f < fForms; ++f) {
+        P.form_begin[f] = (int)P.items.size();
+        std::vector<FwdItemDev> part = xcd_order_items(work[f], FwdItemDev{-1, 0, 0, 0}, /*by_default=*/false);
+        if (const char* env = std::getenv("PLEAS_FWD_ORDER")) {   // experiments: 1 = pseudo-random order, 2 = long / short interleaved
+            const int mode = std::atoi(env);
+            if (mode == 1) {
+                uint64_t st = 0x9E3779B97F4A7C15ull;
+                for (size_t i = part.size(); i > 1; --i) {
+                    st = st * 6364136223846793005ull + 1442695040888963407ull;
+                    std::swap(part[i - 1], part[(size_t)((st >> 33) % i)]);
+                }
+            } else if (mode == 2) {   // longest-first list folded: item k from the front, then item k from the back
+                std::vector<FwdItemDev> folded;
+                folded.reserve(part.size());
+                size_t lo = 0, hi = part.size();
+                while (lo < hi) {
+                    folded.push_back(part[lo++]);
+                    if (lo < hi) folded.push_back(part[--hi]);
+                }
+                part.swap(folded);
             }
-        } else if (mode == 2) {   // longest-first list folded: item k from the front, then item k from the back
-            std::vector<FwdItemDev> folded;
-            folded.reserve(P.items.size());
-            size_t lo = 0, hi = P.items.size();
-            while (lo < hi) {
-                folded.push_back(P.items[lo++]);
-                if (lo < hi) folded.push_back(P.items[--hi]);
-            }
-            P.items.swap(folded);
         }
+        P.items.insert(P.items.end(), part.begin(), part.end());
+        P.form_count[f] = (int)part.size();
+        P.form_order[f] = f;
     }
+    // launch order: the form with the most work first (its tail is then covered by nothing, the small ones' tails are short)
+    std::stable_sort(P.form_order, P.form_order + fForms, [&](int a, int b) { return form_work[a] > form_work[b]; });
     P.n_parts = parts;
     size_t off = 0;
     P.off_layers = off;
@@ -628,9 +971,42 @@ extern "C" int pleas_fwd_batch(const pleas_fwd_layer* layers, int n_layers, floa
     }
     float* parts = reinterpret_cast<float*>(base + P.off_parts);
     {
+        // The forms are independent grids.  Back to back on one stream each would wait for the previous one's LAST
+        // workgroup (a stride-2 3x3 layer has 28 items of 144 chunks: half a millisecond of tail on an empty chip), so every
+        // form but the largest goes to a side stream of the library (fork / join with events around the group): the long
+        // items of the small forms then run beside the large forms' thousands of short ones, as in one grid.
         ProfScope prof(kProfConvFwd, P.flops, P.bytes, stream);
-        hipLaunchKernelGGL(fwd_batch_kernel, dim3((unsigned)P.items.size()), dim3(fThreads), P.lds, stream, dl,
-                           reinterpret_cast<const FwdItemDev*>(base + P.off_items), parts);
+        const FwdItemDev* items = reinterpret_cast<const FwdItemDev*>(base + P.off_items);
+        FwdSideStreams& side = fwd_side_streams();
+        static const bool serial = std::getenv("PLEAS_FWD_SERIAL") && std::atoi(std::getenv("PLEAS_FWD_SERIAL")) != 0;
+        int active = 0;
+        for (int f = 0; f < fForms; ++f) active += P.form_count[f] > 0;
+        const bool fork = !serial && active > 1 && side.ok;
+        if (fork) PLEAS_HIP_CHECK(hipEventRecord(side.forked, stream));
+        int used = 0;
+        for (int o = 0; o < fForms; ++o) {
+            const int f = P.form_order[o];
+            if (P.form_count[f] == 0) continue;
+            hipStream_t st = stream;
+            if (fork && used > 0) {
+                st = side.streams[used - 1];
+                PLEAS_HIP_CHECK(hipStreamWaitEvent(st, side.forked, 0));
+            }
+            const dim3 grid((unsigned)P.form_count[f]);
+            const FwdItemDev* its = items + P.form_begin[f];
+            const size_t lds = P.form_lds[f];
+            switch (f) {
+#define PLEAS_FWD_LAUNCH(F) case F: hipLaunchKernelGGL(fwd_batch_kernel<F>, grid, dim3(fThreads), lds, st, dl, its, parts); break
+                PLEAS_FWD_LAUNCH(0); PLEAS_FWD_LAUNCH(1); PLEAS_FWD_LAUNCH(2); PLEAS_FWD_LAUNCH(3); PLEAS_FWD_LAUNCH(4);
+                PLEAS_FWD_LAUNCH(5); PLEAS_FWD_LAUNCH(6); PLEAS_FWD_LAUNCH(7); PLEAS_FWD_LAUNCH(8); PLEAS_FWD_LAUNCH(9);
+#undef PLEAS_FWD_LAUNCH
+            }
+            if (fork && used > 0) {
+                PLEAS_HIP_CHECK(hipEventRecord(side.joined[used - 1], st));
+                PLEAS_HIP_CHECK(hipStreamWaitEvent(stream, side.joined[used - 1], 0));
+            }
+            ++used;
+        }
     }
     PLEAS_LAUNCH_CHECK("fwd_batch_kernel");
     hipLaunchKernelGGL(fwd_loss_kernel, dim3(n_layers), dim3(64), 0, stream, parts,

@@ -574,6 +574,15 @@ FWD_CASES = [
     (2, 64, 32, 12, 12, 5, 1, 2, False),      # 5x5 taps
     (2, 64, 3, 32, 32, 7, 2, 3, False),       # stem geometry: Kd = 147 (scalar weight loads)
     (16, 70, 300, 1, 1, 1, 1, 0, True),       # linear layer with bias
+    # flat-shift tile forms (stride 1, "same" padding, Cin % 32 == 0): one LDS image per channel block, taps = shifts
+    (5, 200, 96, 14, 14, 1, 1, 0, False),     # 1x1, 16-B pixel loads, ragged last pixel tile (980 pixels) and channel tile
+    (3, 136, 64, 7, 7, 1, 1, 0, False),       # 1x1, HW = 49: scalar pixel loads, tiles straddle samples
+    (16, 40, 64, 1, 1, 1, 1, 0, True),        # linear layer on the flat path (HW = 1), TM = 64, bias
+    (5, 136, 64, 14, 14, 3, 1, 1, False),     # 3x3: tiles straddle samples and rows, every border case
+    (2, 64, 32, 56, 56, 3, 1, 1, False),      # 3x3 at W = 56: widest halo (242 data columns), TM = 64
+    (3, 130, 96, 7, 7, 3, 1, 1, False),       # 3x3 at 7x7: halo 8, three samples per tile
+    (2, 72, 32, 9, 11, 5, 1, 2, False),       # 5x5 "same", non-square image
+    (3, 96, 64, 28, 28, 3, 1, 1, True),       # 3x3 at W = 28 with bias
 ]
 
 
