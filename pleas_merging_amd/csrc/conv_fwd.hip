@@ -689,9 +689,10 @@ __global__ __launch_bounds__(fThreads, 2) void fwd_batch_kernel(const FwdLayerDe
     else fwd_flat_tile<64, FORM - 7>(L, it, smem, partials);
 }
 // side streams + events of the library for the concurrent forms (created once per process; no device memory)
+constexpr int fLanes = 3;          // side streams (+ the caller's stream = four hardware queues)
 struct FwdSideStreams {
-    hipStream_t streams[fForms - 1];
-    hipEvent_t forked, joined[fForms - 1];
+    hipStream_t streams[fLanes];
+    hipEvent_t forked, joined[fLanes];
     bool ok = false;
 };
 static FwdSideStreams& fwd_side_streams() {
@@ -700,7 +701,7 @@ static FwdSideStreams& fwd_side_streams() {
     if (!tried) {
         tried = true;
         bool ok = hipEventCreateWithFlags(&s.forked, hipEventDisableTiming) == hipSuccess;
-        for (int i = 0; ok && i < fForms - 1; ++i)
+        for (int i = 0; ok && i < fLanes; ++i)
             ok = hipStreamCreateWithFlags(&s.streams[i], hipStreamNonBlocking) == hipSuccess &&
                  hipEventCreateWithFlags(&s.joined[i], hipEventDisableTiming) == hipSuccess;
         s.ok = ok;
@@ -761,7 +762,7 @@ struct FwdPlan {
     std::vector<FwdItemDev> items;
     std::vector<FwdLossDev> loss;
     size_t off_layers = 0, off_items = 0, off_loss = 0, off_parts = 0, total = 0;
-    int form_begin[fForms] = {0}, form_count[fForms] = {0}, form_order[fForms] = {0};
+    int form_begin[fForms] = {0}, form_count[fForms] = {0}, form_order[fForms] = {0}, form_lane[fForms] = {0};
     size_t form_lds[fForms] = {0};
     double flops = 0, bytes = 0;
     int n_parts = 0;
@@ -878,6 +879,19 @@ static int build_fwd_plan(FwdPlan& P, const pleas_fwd_layer* ly, int n) {
     }
     // launch order: the form with the most work first (its tail is then covered by nothing, the small ones' tails are short)
     std::stable_sort(P.form_order, P.form_order + fForms, [&](int a, int b) { return form_work[a] > form_work[b]; });
+    {   // lanes: the largest form keeps the caller's stream (lane 0), the others go to the least-loaded lane, largest first
+        double load[fLanes + 1] = {0};
+        for (int o = 0; o < fForms; ++o) {
+            const int f = P.form_order[o];
+            if (P.form_count[f] == 0) continue;
+            int best = 0;
+            for (int l = 1; l <= fLanes; ++l)
+                if (load[l] < load[best]) best = l;
+            if (o == 0) best = 0;
+            P.form_lane[f] = best;
+            load[best] += form_work[f];
+        }
+    }
     P.n_parts = parts;
     size_t off = 0;
     P.off_layers = off;
@@ -973,8 +987,10 @@ extern "C" int pleas_fwd_batch(const pleas_fwd_layer* layers, int n_layers, floa
     {
         // The forms are independent grids.  Back to back on one stream each would wait for the previous one's LAST
         // workgroup (a stride-2 3x3 layer has 28 items of 144 chunks: half a millisecond of tail on an empty chip), so every
-        // form but the largest goes to a side stream of the library (fork / join with events around the group): the long
-        // items of the small forms then run beside the large forms' thousands of short ones, as in one grid.
+        // form but the largest goes to one of THREE side streams of the library (fork / join with events around the group;
+        // the runtime multiplexes a process's streams onto four hardware queues, so more lanes would only queue up behind
+        // each other): forms are dealt to the least-loaded lane, largest first, and the long items of the small forms run
+        // beside the large forms' thousands of short ones, as in one grid.
         ProfScope prof(kProfConvFwd, P.flops, P.bytes, stream);
         const FwdItemDev* items = reinterpret_cast<const FwdItemDev*>(base + P.off_items);
         FwdSideStreams& side = fwd_side_streams();
@@ -983,15 +999,14 @@ extern "C" int pleas_fwd_batch(const pleas_fwd_layer* layers, int n_layers, floa
         for (int f = 0; f < fForms; ++f) active += P.form_count[f] > 0;
         const bool fork = !serial && active > 1 && side.ok;
         if (fork) PLEAS_HIP_CHECK(hipEventRecord(side.forked, stream));
-        int used = 0;
+        bool lane_used[fLanes + 1] = {false};
         for (int o = 0; o < fForms; ++o) {
             const int f = P.form_order[o];
             if (P.form_count[f] == 0) continue;
-            hipStream_t st = stream;
-            if (fork && used > 0) {
-                st = side.streams[used - 1];
-                PLEAS_HIP_CHECK(hipStreamWaitEvent(st, side.forked, 0));
-            }
+            const int lane = fork ? P.form_lane[f] : 0;          // lane 0 = the caller's stream
+            hipStream_t st = lane == 0 ? stream : side.streams[lane - 1];
+            if (lane > 0 && !lane_used[lane]) PLEAS_HIP_CHECK(hipStreamWaitEvent(st, side.forked, 0));
+            lane_used[lane] = true;
             const dim3 grid((unsigned)P.form_count[f]);
             const FwdItemDev* its = items + P.form_begin[f];
             const size_t lds = P.form_lds[f];
@@ -1001,12 +1016,12 @@ extern "C" int pleas_fwd_batch(const pleas_fwd_layer* layers, int n_layers, floa
                 PLEAS_FWD_LAUNCH(5); PLEAS_FWD_LAUNCH(6); PLEAS_FWD_LAUNCH(7); PLEAS_FWD_LAUNCH(8); PLEAS_FWD_LAUNCH(9);
 #undef PLEAS_FWD_LAUNCH
             }
-            if (fork && used > 0) {
-                PLEAS_HIP_CHECK(hipEventRecord(side.joined[used - 1], st));
-                PLEAS_HIP_CHECK(hipStreamWaitEvent(stream, side.joined[used - 1], 0));
-            }
-            ++used;
         }
+        for (int lane = 1; lane <= fLanes; ++lane)
+            if (lane_used[lane]) {
+                PLEAS_HIP_CHECK(hipEventRecord(side.joined[lane - 1], side.streams[lane - 1]));
+                PLEAS_HIP_CHECK(hipStreamWaitEvent(stream, side.joined[lane - 1], 0));
+            }
     }
     PLEAS_LAUNCH_CHECK("fwd_batch_kernel");
     hipLaunchKernelGGL(fwd_loss_kernel, dim3(n_layers), dim3(64), 0, stream, parts,

@@ -764,8 +764,8 @@ class PleasFitter:
         vendor library its first-use set-up, so the default is two per rank: ``2 * world`` under data parallelism, where an
         update's share is ``batch / world`` samples -- the source forward then has the same size for every ``world``, and its
         ~5 ms of host dispatch (which bounds a rank at 6.8 ms per update when every update forwards its own 2 samples,
-        ``tools/probe_dp_rank.py``) is paid once per group.  Only FULL groups are formed; what is left when ``batches`` runs
-        out goes one by one, so the job meets two forward shapes in total.
+        ``tools/probe_dp_rank.py``) is paid once per group.  What is left when ``batches`` runs out forms one smaller group
+        (a single left-over batch goes alone), so a job meets at most three forward shapes.
 
         ``lookahead=True``: the source forwards of the NEXT group (or batch) are enqueued before the current group's updates
         and run beside them on the side streams (two tap generations in flight).  On one GPU the update kernels already
@@ -806,9 +806,11 @@ class PleasFitter:
                             run.append(cand)
                         else:
                             break
-                    if group > 1 and len(run) == group:
+                    if group > 1 and (len(run) == group or (exhausted and len(run) > 1 and len(run) == len(ahead))):
+                        # a full group -- or, when the batches have run out, what is left of one (one more forward size,
+                        # instead of one forward per left-over batch)
                         self.sources.launch_group(run)      # one generation per batch of the run
-                        del ahead[:group]
+                        del ahead[:len(run)]
                     else:
                         b = ahead.pop(0)
                         self._queue.append((b,) + self._launch_sources(b))

@@ -20,7 +20,10 @@ def _rel(a, b):
 
 def check_update_against_fp64(fit, m3, spec, perm, costs_cpu, ratios, x, num_classes, tol=2e-5, skip=("conv1",)):
     """Applies ``fit.step(x)`` and compares every layer's weight (and bias) gradient and loss with fp64.  Returns
-    ``(worst gradient rel-fro, worst fp32-CPU-autograd rel-fro, worst loss rel, largest K)``."""
+    ``(worst gradient rel-fro, worst fp32-CPU-autograd rel-fro, worst loss rel, largest K)``; afterwards
+    ``check_update_against_fp64.levels`` maps every layer to ``loss / mean(target^2)`` in fp64 -- a layer whose input AND
+    output groups are (all but) fully separate reproduces its target exactly, like the stem: its loss is ~1e-14 and its
+    trained weights are rounding noise integrated by Adam in the reference itself."""
     from pleas_merging_amd.core.utils import get_attr
 
     kept, release = {}, fit._end_update
@@ -40,6 +43,7 @@ def check_update_against_fp64(fit, m3, spec, perm, costs_cpu, ratios, x, num_cla
     blocks = orc.spread_blocks(spec, orc.get_blocks(spec, perm, costs_cpu, ratios))
     worst_g = worst_l = worst_cpu = 0.0
     kmax = 0
+    check_update_against_fp64.levels = levels = {}      # layer -> loss / mean(target^2): ~0 marks a degenerate layer
     for idx, plan in enumerate(fit.plans):
         ip1, ip2, o1, o2 = taps[plan.name]
         ip, op = orc.layer_targets(lambda _t, o=o1: o, lambda _t, o=o2: o, blocks, plan.name, ip1, ip2, num_classes=num_classes)
@@ -60,6 +64,7 @@ def check_update_against_fp64(fit, m3, spec, perm, costs_cpu, ratios, x, num_cla
             # where the residual all but cancels (rows of fully separate units), fp32 leaves rounding noise of relative
             # size ~1e-7 in `out`: the loss is compared above that floor
             want_l, floor = float(loss.detach()), 1e-10 * float((op ** 2).mean())
+            levels[plan.name] = want_l / max(float((op ** 2).mean()), 1e-30)
             rl = abs(float(fit.loss_now[idx]) - want_l) / (want_l + floor)
             assert rl < 1e-5 or abs(float(fit.loss_now[idx]) - want_l) < floor, (plan.name, rl, want_l, floor)
             worst_l = max(worst_l, rl if want_l > 100 * floor else 0.0)

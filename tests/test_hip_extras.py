@@ -159,12 +159,24 @@ def test_qp_ratios_to_partial_merge_to_pleas_vs_oracle(tiny_basic, budget):
     # trained weights: Adam's sign-like first steps land +-lr apart on coordinates whose gradient is a near-cancellation
     # (rows of the fully separate units of ratio-1.0 groups see the residual of ONE merged input channel), so the gate is
     # the flip-aware one of test_hip_fullsize.py: few coordinates affected, all others within the north-star tolerance
+    degenerate = {n for n, lvl in check_update_against_fp64.levels.items() if lvl < 1e-9} | {"conv1"}
+    merged = {k: v.clone() for k, v in o3.state_dict().items()}
     m3 = train(data, m1, m2, m3, t.spec, perm, costs, ratios, False, 3, None, num_classes=10)
     o3, _ = orc.train(data, t.m1, t.m2, o3, t.spec, perm, costs_c, ratios, 3, num_classes=10)
+    compared = 0
     for (k, a), (_, b) in zip(m3.state_dict().items(), o3.state_dict().items()):
-        if k != STEM and a.dtype.is_floating_point:
-            d = (a.double().cpu() - b.double()).abs()
-            affected = d > 5e-4 / 10
-            assert float(affected.double().mean()) <= 0.02, (k, float(affected.double().mean()))
-            assert float((d * ~affected).norm() / (b.double().norm() + 1e-30)) < 1e-4, k
-    print("qp ratios %r: worst gradient rel-fro vs fp64 %.2e (fp32 CPU %.2e)" % (sorted(set(ratios.values())), worst_g, worst_cpu))
+        if not a.dtype.is_floating_point:
+            continue
+        if k.rsplit(".", 1)[0] in degenerate:
+            # the reference's own fit of such a layer is a noise walk (stem_gate.py): only its travel is comparable
+            travel = float((b - merged[k]).abs().max())
+            assert float((a.cpu() - merged[k]).abs().max()) <= 1.5 * travel + 5e-4, k
+            continue
+        d = (a.double().cpu() - b.double()).abs()
+        affected = d > 5e-4 / 10
+        assert float(affected.double().mean()) <= 0.02, (k, float(affected.double().mean()))
+        assert float((d * ~affected).norm() / (b.double().norm() + 1e-30)) < 1e-4, k
+        compared += 1
+    assert compared >= 20 and len(degenerate) < 8, (compared, sorted(degenerate))
+    print("qp ratios %r: worst gradient rel-fro vs fp64 %.2e (fp32 CPU %.2e); degenerate layers %r"
+          % (sorted(set(ratios.values())), worst_g, worst_cpu, sorted(degenerate)))
