@@ -56,8 +56,10 @@ def parse(argv=None):
     ap.add_argument("--no-alt-solver", action="store_true", help="skip the closed-form (normal equations) leg")
     ap.add_argument("--no-phases", action="store_true", help="skip the extra synchronised job that fills phases_s")
     ap.add_argument("--phase-log", action="store_true", help="debug: log the phases of that job as they finish")
-    ap.add_argument("--prefetch-groups", type=int, default=6,
-                    help="groups of source forwards enqueued while the LAP kernel runs (0: none); also bounded by memory")
+    ap.add_argument("--prefetch-groups", type=int, default=2,
+                    help="groups of source forwards enqueued while the LAP kernel runs (0: none); also bounded by memory.  "
+                         "Two 128-sample groups take about as long as the LAP kernel (0.16 s); more would still be running "
+                         "beside the first updates and stretch their kernels (fwd 2.7 -> 3.2 ms at 6 groups, same job time)")
     ap.add_argument("--sources-per-forward", type=int, default=8,
                     help="updates PER RANK whose batches go through the frozen sources as ONE forward (128 samples per "
                          "forward at 8: the vendor convolutions run 15-30 %% faster per sample than at 32); 0 = the fitter's "
@@ -245,7 +247,7 @@ def check_result(spec, res, full=True):
     return out
 
 
-def time_normal_eq(spec, m1, m2, perm, costs, loader, ratio):
+def time_normal_eq(spec, m1, m2, perm, costs, loader, ratio, sources_per_forward=None):
     """Closed-form alternative to the Adam phase on the same batches: accumulate A, B^T, then solve."""
     from pleas_merging_amd import hip_ops
     from pleas_merging_amd.methods.normal_eq import NormalEqFitter
@@ -263,7 +265,7 @@ def time_normal_eq(spec, m1, m2, perm, costs, loader, ratio):
     hip_ops.profile_enable(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in fit.steps(x for x, _ in loader):
+    for _ in fit.steps((x for x, _ in loader), sources_per_forward=sources_per_forward):   # same source-forward size as the jobs
         pass
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -283,13 +285,12 @@ def time_normal_eq(spec, m1, m2, perm, costs, loader, ratio):
                                          "block triangle only (K^2 * N*HWo per layer)"}}
 
 
-def time_sources_alone(m1, m2, pool, n_updates, groups=6):
+def time_sources_alone(m1, m2, pool, n_updates, per=2, groups=4):
     """The frozen source forwards of the PLeaS phase (vendor convolutions + pleas_bn_act, both models on two streams,
-    32 samples per forward) with nothing else on the GPU, scaled to the job's updates."""
+    ``per`` updates' batches per forward as in the jobs) with nothing else on the GPU, scaled to the job's updates."""
     from pleas_merging_amd.methods.pleas_merging import FrozenSources
 
     src = FrozenSources(m1, m2)
-    per = 2
     for timed in (False, True):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -471,13 +472,15 @@ def main():
     alt = vendor = None
     if world == 1 and args.emulate_world <= 1:
         if not args.no_alt_solver:
-            alt = time_normal_eq(spec, m1, m2, res["perm"], res["costs"], pool.loader(0, n_pleas), args.ratio)
+            alt = time_normal_eq(spec, m1, m2, res["perm"], res["costs"], pool.loader(0, n_pleas), args.ratio,
+                                 cfg["sources_per_forward"])
             log("closed form: accumulate %.2fs, solve %.2fs" % (alt["accumulate_s"], alt["solve_s"]))
-        src_s, src_per = time_sources_alone(m1, m2, pool, n_pleas)
+        src_s, src_per = time_sources_alone(m1, m2, pool, n_pleas, per=cfg["sources_per_forward"] or 2)
         vendor = {"source_forwards_alone_s_per_job": round(src_s, 3), "ms_per_update": round(src_per * 1e3, 3),
                   "share_of_value": round(src_s / value, 3),
                   "note": "frozen source forwards of the PLeaS phase (MIOpen / Tensile convolutions + pleas_bn_act, both "
-                          "models, 32 samples per forward) with nothing else on the GPU; rocprofv3 kernel shares: profiles/"}
+                          "models, %d samples per forward) with nothing else on the GPU; rocprofv3 kernel shares: profiles/"
+                          % ((cfg["sources_per_forward"] or 2) * args.batch)}
     if rank == 0:  # {kernel: (launches, total_ms, flops, bytes)}
         labels = {
             "gram_partial": "gram_batch_kernel (grouped fp32 MFMA 32x32x2 contraction, one launch per matching batch)",
@@ -527,6 +530,7 @@ def main():
                             % (args.arch, n_match, len(spec), args.ratio, n_pleas, args.batch,
                                "" if full else " (SHORTENED job: not a benchmark result)"),
                 "solver": "adam", "parallelism": "dp%d" % world,
+                "sources_per_forward": cfg["sources_per_forward"] or 2 * ranks,
                 "not_in_value": "get_permutation_spec %.2f s (host, once per model)" % spec_s,
             },
             "job_s": {"mean": round(value, 4), "median": round(srt[len(srt) // 2], 4), "min": round(srt[0], 4),

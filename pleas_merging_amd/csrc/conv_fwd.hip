@@ -878,8 +878,13 @@ static int build_fwd_plan(FwdPlan& P, const pleas_fwd_layer* ly, int n) {
         P.form_order[f] = f;
     }
     // launch order: the form with the most work first (its tail is then covered by nothing, the small ones' tails are short)
+    // Expected duration of a form relative to its MFMA work (measured on the ResNet-101 list, each form alone): the
+    // general tile (stride-2 layers: few, long items; stem: scalar weight loads) runs at ~0.4x the flat forms' rate, the
+    // scalar-pixel 1x1 form (7x7 images) at ~0.5x.
+    for (int f = 0; f < fForms; ++f) form_work[f] *= f < 4 ? 2.5 : ((f == 5 || f == 8) ? 2.0 : 1.0);
     std::stable_sort(P.form_order, P.form_order + fForms, [&](int a, int b) { return form_work[a] > form_work[b]; });
-    {   // lanes: the largest form keeps the caller's stream (lane 0), the others go to the least-loaded lane, largest first
+    {   // lanes (longest-processing-time first): the largest form keeps the caller's stream (lane 0), every other form goes
+        // to the lane that is least loaded so far
         double load[fLanes + 1] = {0};
         for (int o = 0; o < fForms; ++o) {
             const int f = P.form_order[o];

@@ -11,6 +11,10 @@ static float* dev_rand(size_t n) { std::vector<float> h(n); for (auto& v : h) v 
 int main(int argc, char** argv) {
     const char* path = argc > 1 ? argv[1] : "rn101_layers.txt"; int reps = argc > 2 ? atoi(argv[2]) : 5, N = 16;
     const int kpos = argc > 3 ? atoi(argv[3]) : 1;   // 1: k x k layers with Cin % 32 == 0 use kernel-position-major weights
+    // PLEAS_TAP_GROUP=g, PLEAS_TAP_WINDOW=w: the source outputs o1 / o2 are the w-th 16-sample window of tensors that hold
+    // g times as many samples (the taps of ONE source forward over g updates' batches, as PleasFitter.steps groups them)
+    const int tap_group = getenv("PLEAS_TAP_GROUP") ? atoi(getenv("PLEAS_TAP_GROUP")) : 1;
+    const int tap_window = getenv("PLEAS_TAP_WINDOW") ? atoi(getenv("PLEAS_TAP_WINDOW")) : 0;
     FILE* f = fopen(path, "r"); if (!f) { printf("cannot open %s\n", path); return 1; }
     int n; fscanf(f, "%d", &n);
     std::vector<pleas_fwd_layer> L(n); double flops = 0, bytes = 0;
@@ -19,7 +23,7 @@ int main(int argc, char** argv) {
         l.N = N; l.Cout = co; l.Cin = ci; l.Hin = h; l.Win = w; l.KH = l.KW = k; l.stride = s; l.pad = p; l.Csrc = co; l.n_merged = co; l.flags = (kpos && k > 1 && ci % 32 == 0) ? PLEAS_FWD_KPOS_MAJOR : 0;
         l.dscale = 2.0f / (co * P); l.loss_scale = 1.0f / (co * P);
         l.ip = dev_rand((size_t)N * ci * h * w); l.w = dev_rand((size_t)co * ci * k * k); l.bias = nullptr;
-        l.o1 = dev_rand(co * P); l.o2 = dev_rand(co * P); float* r; hipMalloc(&r, co * P * 4); l.resid = r;
+        l.o1 = dev_rand(co * P * tap_group) + (size_t)co * P * tap_window; l.o2 = dev_rand(co * P * tap_group) + (size_t)co * P * tap_window; float* r; hipMalloc(&r, co * P * 4); l.resid = r;
         std::vector<int32_t> id(co); for (int i = 0; i < co; ++i) id[i] = i; int32_t* m; hipMalloc(&m, co * 4); hipMemcpy(m, id.data(), co * 4, hipMemcpyHostToDevice); l.row1 = m; l.row2 = m;
         flops += 2.0 * co * ci * k * k * (double)P; bytes += ((double)N * ci * h * w + 3.0 * co * P + (double)co * ci * k * k) * 4; }
     float* loss; hipMalloc(&loss, n * 4);

@@ -35,6 +35,13 @@ print("updates %d: wall per update's forward group avg %.1f us; sum of kernel du
       (len(g), sum(tot) / len(tot), sum(sum((e - s) / 1e3 for s, e, _ in x) for x in g) / len(g)))
 x = g[len(g) // 2]; t0 = min(s for s, _, _ in x)
 for s, e, f in sorted(x): print("   form %s start +%.1f us dur %.1f us end +%.1f" % (f, (s - t0) / 1e3, (e - s) / 1e3, (e - t0) / 1e3))
+print("wall of consecutive updates' forward groups (us) and gap to the previous group's end (ms):")
+prev = None
+for x in groups[-26:]:
+    s0, e1 = min(s for s, _, _ in x), max(e for _, e, _ in x)
+    print("   %.0f (gap %.2f)" % ((e1 - s0) / 1e3, (s0 - prev) / 1e6 if prev else 0.0), end="")
+    prev = e1
+print()
 others = collections.defaultdict(list)
 for r in rows:
     n = r["Kernel_Name"]
