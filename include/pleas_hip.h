@@ -112,6 +112,11 @@ int pleas_gram_batch(const pleas_gram_node* nodes, int n_nodes, float* const* gr
 #define PLEAS_LSAP_MAX_N 2048
 int pleas_lsap_batched(const float* const* cost, const int* n, int nprob, int maximize, int64_t* const* col_ind,
                        void* stream);
+/* The same solver for ONE problem whose cost matrix is in HOST memory (fp32 when is_double == 0, else fp64; n >= 1, no
+ * upper limit), synchronous, no GPU involved: the explicit host entry point for callers that hold host data
+ * (weight matching of CPU state dicts: reference weight_matching.py:78 with CPU tensors, BASELINE.json configs[0]).
+ * Same scan order and tie rule, hence the same col_ind as scipy.optimize.linear_sum_assignment. */
+int pleas_lsap_host(const void* cost, int is_double, int n, int maximize, int64_t* col_ind);
 
 /* ------------------------------------------------------------------------------------
  * Block gather / average used by partial merging and by the PLeaS regression targets.

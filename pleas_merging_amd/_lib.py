@@ -23,6 +23,7 @@ SIGNATURES = {
     "pleas_gram_accum": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_size_t,
                                  c_void_p]),
     "pleas_lsap_batched": (c_int, [POINTER(c_void_p), POINTER(c_int), c_int, c_int, POINTER(c_void_p), c_void_p]),
+    "pleas_lsap_host": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "pleas_merge_blocks": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int, c_int, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "pleas_merge_batch_ws_bytes": (c_size_t, [c_void_p, c_int]),

@@ -11,4 +11,4 @@ from .utils import (
     perm_eq,
 )
 from .compiler import get_permutation_spec
-from .solvers import hip_solve_lsa, scipy_solve_lsa
+from .solvers import hip_solve_lsa, host_solve_lsa, scipy_solve_lsa

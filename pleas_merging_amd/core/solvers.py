@@ -15,6 +15,14 @@ def hip_solve_lsa(A: torch.Tensor, maximize: bool = True) -> torch.Tensor:
     return _impl(A, maximize)
 
 
+def host_solve_lsa(A: torch.Tensor, maximize: bool = True) -> torch.Tensor:
+    """The library's own solver on a HOST cost matrix (``pleas_lsap_host``, scipy's scan order and tie rule): what a
+    caller with CPU state dicts passes as ``lsa_solver`` -- explicitly; device tensors always take ``hip_solve_lsa``."""
+    from ..hip_ops import host_solve_lsa as _impl
+
+    return _impl(A, maximize)
+
+
 def scipy_solve_lsa(A: torch.Tensor, maximize: bool = True) -> torch.Tensor:
     """Host solver of the reference (pleas/core/solvers.py:18-33); never a default here."""
     import scipy.optimize

@@ -20,6 +20,8 @@
 #include <algorithm>
 #include <vector>
 
+#include <limits>
+
 #include "common.hpp"
 
 namespace pleas {
@@ -327,6 +329,71 @@ __global__ __launch_bounds__(kLsapThreads) void lsap_kernel(const LsapBatch batc
 }  // namespace pleas
 
 using namespace pleas;
+
+// Host solve of ONE problem with the same scan order and tie rule (the explicit host entry point of the
+// C-ABI, for callers whose cost matrix lives on the host -- weight matching of CPU state dicts, BASELINE.json's
+// configs[0]).  Never selected implicitly: device tensors always go to the kernel above.
+template <class T>
+static void lsap_host_solve(const T* cost, int n, double sign, int64_t* col4row_out) {
+    std::vector<double> u(n, 0.0), v(n, 0.0), shortest(n);
+    std::vector<int> path(n, -1), col4row(n, -1), row4col(n, -1), remaining(n);
+    std::vector<char> in_rows(n), in_cols(n);
+    for (int cur = 0; cur < n; ++cur) {
+        std::fill(shortest.begin(), shortest.end(), std::numeric_limits<double>::infinity());
+        std::fill(in_rows.begin(), in_rows.end(), 0);
+        std::fill(in_cols.begin(), in_cols.end(), 0);
+        int count = n;
+        for (int j = 0; j < n; ++j) remaining[j] = n - 1 - j;          // unscanned columns, reversed
+        double min_val = 0.0;
+        int i = cur, sink = -1;
+        while (sink < 0) {
+            in_rows[i] = 1;
+            double lowest = std::numeric_limits<double>::infinity();
+            int index = -1;
+            const T* row = cost + (size_t)i * n;
+            for (int it = 0; it < count; ++it) {                       // list order; strict update; ties prefer a free column
+                const int j = remaining[it];
+                const double r = min_val + sign * (double)row[j] - u[i] - v[j];
+                if (r < shortest[j]) {
+                    shortest[j] = r;
+                    path[j] = i;
+                }
+                if (shortest[j] < lowest || (shortest[j] == lowest && row4col[j] == -1)) {
+                    lowest = shortest[j];
+                    index = it;
+                }
+            }
+            min_val = lowest;
+            const int j = remaining[index];
+            if (row4col[j] == -1) sink = j;
+            else i = row4col[j];
+            in_cols[j] = 1;
+            remaining[index] = remaining[--count];                     // swap-remove
+        }
+        u[cur] += min_val;
+        for (int r = 0; r < n; ++r)
+            if (in_rows[r] && r != cur) u[r] += min_val - shortest[col4row[r]];
+        for (int j = 0; j < n; ++j)
+            if (in_cols[j]) v[j] -= min_val - shortest[j];
+        int j = sink;
+        for (;;) {                                                     // augment back to `cur`
+            const int r = path[j];
+            row4col[j] = r;
+            std::swap(col4row[r], j);
+            if (r == cur) break;
+        }
+    }
+    for (int r = 0; r < n; ++r) col4row_out[r] = col4row[r];
+}
+
+extern "C" int pleas_lsap_host(const void* cost, int is_double, int n, int maximize, int64_t* col_ind) {
+    if (!cost || !col_ind) return bad_arg("null pointer");
+    if (n < 1) return bad_arg("n < 1");
+    const double sign = maximize ? -1.0 : 1.0;
+    if (is_double) lsap_host_solve((const double*)cost, n, sign, col_ind);
+    else lsap_host_solve((const float*)cost, n, sign, col_ind);
+    return PLEAS_OK;
+}
 
 extern "C" int pleas_lsap_batched(const float* const* cost, const int* n, int nprob, int maximize,
                                   int64_t* const* col_ind, void* stream_) {

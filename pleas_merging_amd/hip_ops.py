@@ -263,6 +263,23 @@ def hip_solve_lsa(A: torch.Tensor, maximize: bool = True) -> torch.Tensor:
     return solve_lsa_batched([A], maximize)[0].cpu()
 
 
+def host_solve_lsa(A: torch.Tensor, maximize: bool = True) -> torch.Tensor:
+    """``pleas_lsap_host``: the library's solver on a HOST cost matrix (fp32 / fp64 CPU tensor), synchronous; same
+    ``col_ind`` as scipy.  For callers that keep their data on the host (weight matching of CPU state dicts); device
+    tensors belong to ``hip_solve_lsa`` and are refused here -- nothing falls back from one to the other."""
+    if A.is_cuda:
+        raise PleasHipError("host_solve_lsa takes a CPU tensor; use hip_solve_lsa for device tensors")
+    if A.dim() != 2 or A.shape[0] != A.shape[1] or A.shape[0] < 1:
+        raise PleasHipError("square cost matrix expected, got %s" % (tuple(A.shape),))
+    if A.dtype not in (torch.float32, torch.float64):
+        A = A.double()
+    A = A.contiguous()
+    out = torch.empty(A.shape[0], dtype=torch.int64)
+    check(_lib.lib().pleas_lsap_host(A.data_ptr(), int(A.dtype == torch.float64), A.shape[0], int(bool(maximize)),
+                                     out.data_ptr()), "pleas_lsap_host")
+    return out
+
+
 # ---------------------------------------------------------------------------------------- bn + add + relu
 def bn_act(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, res: Optional[torch.Tensor] = None,
            relu: bool = True) -> torch.Tensor:

@@ -94,13 +94,25 @@ class NormalEqFitter(PleasFitter):
                 self.A[idx].addmm_(U.t(), U)
                 self.Bt[idx].addmm_(Y.t(), U)
             if plan.b is not None:
+                # bias = one more column of ones in U: its normal-equation entries are the column sums of U, the column
+                # sums of the target and the row count
                 s = self.bias_stats[idx]
-                rows_u = ip.reshape(-1, ip.shape[-1]) if not plan.is_conv else None
-                if rows_u is None:
-                    raise NotImplementedError("normal_eq: conv layers with bias")
-                s[0].add_(rows_u.sum(0))
-                s[1].add_(op.reshape(-1, op.shape[-1]).sum(0))
-                s[2].add_(float(rows_u.shape[0]))
+                if plan.is_conv:
+                    kh, kw = mod.kernel_size
+                    st, pd = mod.stride[0], mod.padding[0]
+                    ho, wo = op.shape[2], op.shape[3]
+                    ipp = F.pad(ip, (pd, pd, pd, pd)) if pd else ip
+                    # column sums of im2col(ip) in kernel-position-major order k = (kh * KW + kw) * Cin + ci
+                    cols = [ipp[:, :, a:a + st * (ho - 1) + 1:st, b:b + st * (wo - 1) + 1:st].sum((0, 2, 3))
+                            for a in range(kh) for b in range(kw)]
+                    s[0].add_(torch.cat(cols))
+                    s[1].add_(op.sum((0, 2, 3)))
+                    s[2].add_(float(op.shape[0] * ho * wo))
+                else:
+                    rows_u = ip.reshape(-1, ip.shape[-1])
+                    s[0].add_(rows_u.sum(0))
+                    s[1].add_(op.reshape(-1, op.shape[-1]).sum(0))
+                    s[2].add_(float(rows_u.shape[0]))
         self.merge.flush()
         self.neq.flush()
         self.wgrad.flush()

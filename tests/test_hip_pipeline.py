@@ -719,3 +719,49 @@ def test_train_mode_matching_vs_oracle(fx, modes, request):
     plain = accumulate_costs_fused(t.spec, again[0], again[1], data, 3, hip_ops.EPI_NEG_CDIST, fuse_bn=False)
     for k in t.spec:
         assert _rel(plain[k], costs[k]) < 2e-5, k
+
+
+def test_normal_eq_conv_layers_with_bias(tiny_basic):
+    """solver="normal_eq" on convolutions WITH bias: the bias is one more column of ones in U (column sums of im2col(ip),
+    of the target, and the row count join A and B).  Weight and bias of a 3x3 and a strided 1x1 convolution against the
+    fp64 oracle (normal equations + lstsq) on the same batches."""
+    from pleas.methods.partial_matching import partial_merge
+    from pleas.methods.pleas_merging import train
+
+    t = tiny_basic
+    g = torch.Generator().manual_seed(3)
+    pair = [copy.deepcopy(t.m1), copy.deepcopy(t.m2)]
+    names = ("layer1.0.conv2", "layer2.0.downsample.0")
+    for m in pair:
+        for n in names:
+            conv = orc.get_attr(m, n.split("."))
+            conv.bias = torch.nn.Parameter(0.3 * torch.randn(conv.out_channels, generator=g))
+    perm, costs_c = t.per_key("am_perm"), t.per_key("am_cost")
+    costs = {k: v.cuda() for k, v in costs_c.items()}
+    data = t.batches("xt")[:21]
+    m1, m2 = (copy.deepcopy(m).cuda() for m in pair)
+    m3 = partial_merge(t.spec, m1, m2, perm, costs, 0.0)
+    m3 = train(data, m1, m2, m3, t.spec, perm, costs, 0.0, False, 20, None, num_classes=10, solver="normal_eq")
+    blocks = orc.spread_blocks(t.spec, orc.get_blocks(t.spec, perm, costs_c, 0.0))
+    a1, a2 = {}, {}
+    h = orc._hook_inputs(pair[0], a1) + orc._hook_inputs(pair[1], a2)
+    stacks = {n: ([], []) for n in names}
+    with torch.no_grad():
+        for x, _ in data:
+            pair[0](x)
+            pair[1](x)
+            for n in names:
+                ip, op = orc.layer_targets(orc.get_attr(pair[0], n.split(".")), orc.get_attr(pair[1], n.split(".")), blocks, n,
+                                           a1[n], a2[n], num_classes=10)
+                stacks[n][0].append(ip)
+                stacks[n][1].append(op)
+    for hh in h:
+        hh.remove()
+    for n in names:
+        layer = orc.get_attr(m3, n.split("."))
+        assert layer.bias is not None
+        A, Bm = orc.normal_equations(stacks[n][0], stacks[n][1], layer)
+        sol = orc.solve_normal_equations(A, Bm, ridge=1e-6)              # (K + 1, Cout), last row = bias
+        want_w = sol[:-1].t().reshape(layer.weight.shape)
+        assert _rel(layer.weight, want_w.float()) < 2e-3, (n, _rel(layer.weight, want_w.float()))
+        assert _rel(layer.bias, sol[-1].float()) < 2e-3, (n, _rel(layer.bias, sol[-1].float()))
