@@ -340,9 +340,13 @@ def gradient_masks(perm_blocks, layers: Dict[str, nn.Module]) -> List[torch.Tens
 
 
 def layer_targets(l1, l2, perm_blocks, name, ip1, ip2, num_classes=1000, separate_classifier=False,
-                  model_type="rn50"):
-    """Reference: pleas/methods/pleas_merging.py:63-149 for merging='perm_gradmask':
-    merged-layer input and regression target built from the two source layers."""
+                  model_type="rn50", merging="perm_gradmask"):
+    """Reference: pleas/methods/pleas_merging.py:63-149: merged-layer input and regression target built from the two
+    source layers.  ``merging='perm_gradmask'`` (the drivers' mode, :146-147) merges along the channel axis; the other
+    modes STACK two half-batches along the sample axis (:125-144):
+      reg_mean         [ip1 ; ip2]                                    ->  [o1 ; o2]           (no permutation)
+      perm_separatels  [i11, i1c, 0 ; i22, 0, i2c]                    ->  [o11, o1c, 0 ; o22, 0, o2c]
+      perm_mixedls     [(i11+i22)/2, i1c, 0 ; (i11+i22)/2, 0, i2c]    ->  [o11, o1c, 0 ; o22, 0, o2c]"""
     bo = perm_blocks.get(Axis(name + ".weight", 0))
     if bo is None:
         width = {"rn50": 2048, "rn101": 2048, "rn20": 1024, "rn18": 512}[model_type] if separate_classifier else num_classes
@@ -353,8 +357,18 @@ def layer_targets(l1, l2, perm_blocks, name, ip1, ip2, num_classes=1000, separat
         bi = (torch.arange(c), torch.arange(c), torch.tensor([], dtype=torch.long), torch.tensor([], dtype=torch.long))
     o1, o2 = l1(ip1), l2(ip2)
     sel = lambda t, idx: t.index_select(1, idx.long())
-    ip = torch.cat([(sel(ip1, bi[0]) + sel(ip2, bi[1])) / 2, sel(ip1, bi[2]), sel(ip2, bi[3])], 1)
-    op = torch.cat([(sel(o1, bo[0]) + sel(o2, bo[1])) / 2, sel(o1, bo[2]), sel(o2, bo[3])], 1)
+    if merging == "reg_mean":
+        return torch.cat([ip1, ip2], 0), torch.cat([o1, o2], 0)
+    i11, i22, i1c, i2c = sel(ip1, bi[0]), sel(ip2, bi[1]), sel(ip1, bi[2]), sel(ip2, bi[3])
+    o11, o22, o1c, o2c = sel(o1, bo[0]), sel(o2, bo[1]), sel(o1, bo[2]), sel(o2, bo[3])
+    z = torch.zeros_like
+    if "perm_separatels" in merging or "perm_mixedls" in merging:
+        m1_, m2_ = ((i11 + i22) / 2, (i11 + i22) / 2) if "perm_mixedls" in merging else (i11, i22)
+        ip = torch.cat([torch.cat([m1_, i1c, z(i2c)], 1), torch.cat([m2_, z(i1c), i2c], 1)], 0)
+        op = torch.cat([torch.cat([o11, o1c, z(o2c)], 1), torch.cat([o22, z(o1c), o2c], 1)], 0)
+        return ip, op
+    ip = torch.cat([(i11 + i22) / 2, i1c, i2c], 1)
+    op = torch.cat([(o11 + o22) / 2, o1c, o2c], 1)
     return ip, op
 
 
@@ -368,8 +382,8 @@ def _hook_inputs(model, store):
 
 
 def train(batches, model1, model2, model3, spec, perm, costs, ratios, max_steps: int, num_classes=1000, lr=5e-4,
-          separate_classifier=False, model_type="rn50"):
-    """Reference: pleas/methods/pleas_merging.py:305-405 with merging='perm_gradmask' (step: :234-302).
+          separate_classifier=False, model_type="rn50", merging="perm_gradmask"):
+    """Reference: pleas/methods/pleas_merging.py:305-405 (step: :234-302); ``merging`` as in :func:`layer_targets`.
     Adam + cosine schedule on copies of model3's Conv/Linear layers; ``max_steps + 1`` updates."""
     perm_blocks = spread_blocks(spec, get_blocks(spec, perm, costs, ratios))
     acts1, acts2 = {}, {}
@@ -398,7 +412,7 @@ def train(batches, model1, model2, model3, spec, perm, costs, ratios, max_steps:
             with torch.no_grad():
                 ip, op = layer_targets(get_attr(model1, name.split(".")), get_attr(model2, name.split(".")),
                                        perm_blocks, name, acts1[name], acts2[name], num_classes,
-                                       separate_classifier, model_type)
+                                       separate_classifier, model_type, merging)
             total = total + ((layer(ip) - op) ** 2).mean()
         total.backward()
         for p, m in zip(params, masks):

@@ -202,7 +202,8 @@ def cosine_lrs(base_lr: float, t_max: int, n: int) -> List[float]:
 
 # ------------------------------------------------------------------------------------------ per-layer plan
 class _LayerPlan:
-    __slots__ = ("name", "mod", "is_conv", "w", "b", "gw", "gb", "in_maps", "out_maps", "w_shape", "off_w", "kpos", "bucket")
+    __slots__ = ("name", "mod", "is_conv", "w", "b", "gw", "gb", "gw2", "gb2", "in_maps", "out_maps", "halves", "w_shape",
+                 "off_w", "kpos", "bucket")
 
 
 def _identity_block(n: int):
@@ -217,6 +218,53 @@ def _fallback_out_width(separate_classifier: bool, model_type: str, num_classes:
     if model_type not in widths:
         raise ValueError("Unknown model type: %s" % model_type)
     return widths[model_type]
+
+
+MERGING_MODES = ("perm_gradmask", "reg_mean", "perm_separatels", "perm_mixedls")
+
+
+def merging_mode(merging: str) -> str:
+    """The reference tests ``merging`` with ``==`` for reg_mean and with ``in`` for the two stacked modes
+    (pleas_merging.py:125, :132, :139); everything else is the default channel-merged form (:146-147)."""
+    if merging == "reg_mean":
+        return "reg_mean"
+    if "perm_separatels" in merging:
+        return "perm_separatels"
+    if "perm_mixedls" in merging:
+        return "perm_mixedls"
+    return "perm_gradmask"
+
+
+def half_maps(mode: str, bi, bo, cin: int, cout_src: int, device):
+    """Per HALF-BATCH ``(input maps, output maps)`` -- each ``(row1, row2, n_merged)`` as ``block_maps`` gives them -- of
+    the layer's regression problem (reference :125-147).  ``perm_gradmask`` has one half: the channel-merged input and
+    target.  The other modes stack TWO half-batches along the sample axis, which here are two entries of the grouped
+    launches that share the layer's weights (their gradients are summed):
+      reg_mean         [ip1 ; ip2] -> [o1 ; o2], no permutation (source widths)
+      perm_separatels  [i11, i1c, 0 ; i22, 0, i2c]                 -> [o11, o1c, 0 ; o22, 0, o2c]
+      perm_mixedls     [(i11+i22)/2, i1c, 0 ; (i11+i22)/2, 0, i2c] -> the same targets
+    Absent blocks are -1 rows: the kernels write / gather zeros there."""
+    i32 = lambda t: t.to(device=device, dtype=torch.int32)
+    neg = lambda n: torch.full((int(n),), -1, dtype=torch.int32, device=device)
+    if mode == "perm_gradmask":
+        return [(block_maps(bi, device), block_maps(bo, device))]
+    if mode == "reg_mean":
+        ai, ao = torch.arange(cin, dtype=torch.int32, device=device), torch.arange(cout_src, dtype=torch.int32, device=device)
+        return [((ai, neg(cin), 0), (ao, neg(cout_src), 0)), ((neg(cin), ai, 0), (neg(cout_src), ao, 0))]
+
+    def side(b, which, averaged):
+        b1, b2, b1c, b2c = (i32(t) for t in b)
+        n = b1.numel() + b1c.numel() + b2c.numel()
+        if which == 0:      # [x11 (or the average), x1c, 0]
+            r1 = torch.cat([b1, b1c, neg(b2c.numel())])
+            r2 = torch.cat([b2, neg(b1c.numel() + b2c.numel())]) if averaged else neg(n)
+        else:               # [x22 (or the average), 0, x2c]
+            r2 = torch.cat([b2, neg(b1c.numel()), b2c])
+            r1 = torch.cat([b1, neg(b1c.numel() + b2c.numel())]) if averaged else neg(n)
+        return r1.contiguous(), r2.contiguous(), (int(b1.numel()) if averaged else 0)
+
+    mixed = mode == "perm_mixedls"
+    return [(side(bi, h, mixed), side(bo, h, False)) for h in (0, 1)]
 
 
 def dp_slice(x: torch.Tensor, rank: int, world: int) -> torch.Tensor:
@@ -515,7 +563,7 @@ class PleasFitter:
                  separate_classifier=False, num_classes=1000, model_type="rn50", data_parallel: bool = False,
                  forward: str = "hip", graph_sources: bool = False, fuse_sources: bool = True,
                  overlap_sources: bool = True, fused_sources=None, sources: Optional[FrozenSources] = None,
-                 grad_buckets: int = 1):
+                 grad_buckets: int = 1, merging: str = "perm_gradmask"):
         from .. import hip_ops
 
         self.ops = hip_ops
@@ -526,6 +574,10 @@ class PleasFitter:
             fused=fused_sources)
         self.rank, self.world, self.device = self.sources.rank, self.sources.world, self.sources.device
         self.model1, self.model2, self.model3 = model1, model2, model3
+        self.merging = merging_mode(merging)
+        self.stacked = self.merging != "perm_gradmask"       # two half-batches per layer (reference :125-144)
+        if self.stacked and (forward != "hip" or grad_buckets >= 2):
+            raise NotImplementedError("merging=%r needs forward='hip' and one gradient bucket" % merging)
         blocks = get_blocks(spec, perm, costs, budget_ratios, False)
         self.perm_blocks = spread_blocks(spec, blocks)
         # The update's own launches go to a dedicated stream, not to the caller's: measured on the 401-update job,
@@ -537,8 +589,8 @@ class PleasFitter:
         # Per input shape: the merged inputs and residuals of every layer live in buffers that are kept between updates
         # (written and read on the update stream only), so the item tables of the three grouped launches change between
         # two updates of that shape in the tap addresses alone -- see _step.
-        self._buffers: Dict[tuple, Dict[int, Tuple[torch.Tensor, torch.Tensor]]] = {}
-        self._bufs: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self._buffers: Dict[tuple, Dict[tuple, Tuple[torch.Tensor, torch.Tensor]]] = {}
+        self._bufs: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}      # (layer, half-batch) -> (merged input, residual)
         self._replay = None      # (shape key, names, merge table, forward table, vendor / bias work) of the latest full update
         self.fast_updates = 0    # updates applied by patching the tables (the rest took the layer-by-layer path)
 
@@ -551,6 +603,9 @@ class PleasFitter:
         # the gradient arena carries this update's per-layer losses in its tail: ONE collective per update sums both
         self._g_ext = torch.zeros(total + len(layers), dtype=torch.float32, device=dev)
         self.g = self._g_ext[:total]
+        # stacked modes: the second half-batch's weight gradients land in an arena of their own (two entries of one grouped
+        # launch must not write the same tensor) and are added before the exchange / the optimiser
+        self.g2 = torch.zeros(total, dtype=torch.float32, device=dev) if self.stacked else None
         self.m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.v = torch.zeros(total, dtype=torch.float32, device=dev)
         self.mask = torch.ones(total, dtype=torch.float32, device=dev)   # frozen blocks are zeroed in place below
@@ -559,7 +614,7 @@ class PleasFitter:
         for name, mod in layers.items():
             plan = _LayerPlan()
             plan.name, plan.mod, plan.is_conv = name, mod, isinstance(mod, nn.Conv2d)
-            plan.b = plan.gb = None
+            plan.b = plan.gb = plan.gw2 = plan.gb2 = None
             # k x k convolutions with Cin % 32 == 0 keep their weight (gradient, mask, Adam state) KERNEL-POSITION-MAJOR
             # [Cout][KH][KW][Cin] in the arenas: the fused forward then has one tap per K chunk, the weight-gradient
             # kernel writes that layout directly, and the elementwise optimiser does not care (finish() permutes back)
@@ -581,10 +636,13 @@ class PleasFitter:
                             mview[rows, :, :, cols] = 0.0
                         else:
                             mview[rows, cols] = 0.0
+                g2view = self.g2[off:off + n].view(shape) if self.stacked else None
                 if pname == "weight":
                     plan.w, plan.gw, plan.w_shape, plan.off_w = view, gview, tuple(prm.shape), off
+                    plan.gw2 = g2view
                 else:
                     plan.b, plan.gb = view, gview
+                    plan.gb2 = g2view
                 off += pad4(n)
                 k += 1
             src = get_attr(model1, name.split("."))
@@ -592,7 +650,9 @@ class PleasFitter:
             bi = self.perm_blocks.get(Axis("%s.weight" % name, 1)) or _identity_block(cin)
             bo = self.perm_blocks.get(Axis("%s.weight" % name, 0)) or _identity_block(
                 _fallback_out_width(separate_classifier, model_type, num_classes))
-            plan.in_maps, plan.out_maps = block_maps(bi, dev), block_maps(bo, dev)
+            cout_src = src.out_channels if plan.is_conv else src.out_features
+            plan.halves = half_maps(self.merging, bi, bo, cin, cout_src, dev)
+            plan.in_maps, plan.out_maps = plan.halves[0]
             self.plans.append(plan)
         self.max_steps = max_steps
         self.lrs = cosine_lrs(lr, max_steps, max_steps + 1)
@@ -658,61 +718,65 @@ class PleasFitter:
         ip1, ip2 = self.t1_in[name], self.t2_in[name]
         o1, o2 = self.t1_out[name], self.t2_out[name]
         mod = plan.mod
-        r1, r2, nm = plan.out_maps
         cout = plan.w_shape[0]
-        if cout != r1.numel():
-            raise RuntimeError("layer %s: %d merged outputs vs %d target blocks" % (name, cout, r1.numel()))
         square = plan.is_conv and _square_conv(mod)
         linear = (not plan.is_conv) and ip1.dim() == 2
         geo = (tuple(mod.kernel_size), mod.stride[0], mod.padding[0]) if plan.is_conv else ((1, 1), 1, 0)
         hip_forward = self.forward == "hip" and (square or linear)
-        # merged input: queued for the ONE grouped merge launch that precedes the grouped forward (merge.flush); the
-        # vendor-forward path consumes it right here and takes the single-tensor launch
-        kept = self._bufs.get(idx) if hip_forward else None
-        ip = self.merge.add(ip1, ip2, 1, *plan.in_maps, out=kept[0] if kept else None) if hip_forward \
-            else ops.merge_blocks(ip1, ip2, 1, *plan.in_maps)
-        if hip_forward:
-            resid = kept[1] if kept else torch.empty((ip.shape[0], cout) + tuple(o1.shape[2:]), dtype=torch.float32,
-                                                     device=ip.device)
-            if kept is None:
-                self._bufs[idx] = (ip, resid)
-            n = resid.numel() * self.world           # the mean runs over the full (global) batch
-            self.fwd.add(ip, plan.w, plan.b, o1, o2, r1, r2, nm, resid, 2.0 / n, 1.0 / n, *geo,
-                         flags=ops.FwdBatch.KPOS_MAJOR if plan.kpos else 0)
-            self._fwd_rows.append(idx)
-        else:                                        # vendor forward + fused target/residual (one launch per layer)
-            out = F.conv2d(ip, plan.w, plan.b, mod.stride, mod.padding, mod.dilation, mod.groups) if plan.is_conv \
-                else F.linear(ip, plan.w, plan.b)
-            if out.shape[2:] != o1.shape[2:]:
-                raise RuntimeError("layer %s: merged output %s vs source output %s" % (name, tuple(out.shape), tuple(o1.shape)))
-            n = out.numel() * self.world
-            nparts = ops.target_residual(out, o1, o2, r1, r2, nm, 2.0 / n, self.loss_parts[idx])
-            if self.loss_meta_host[idx] != (nparts, n):
-                self.loss_meta_host[idx] = (nparts, n)
-                self.loss_nparts[idx] = nparts
-                self.loss_scale[idx] = 1.0 / n
-            resid = out
-        if (square and ip.shape[1] >= 16) or linear:
-            (self.wgrad_b if plan.bucket else self.wgrad).add(resid, ip, plan.gw, *geo,
-                                                             flags=ops.WgradBatch.KPOS_MAJOR if plan.kpos else 0)
-        elif plan.is_conv:  # stem (3 input channels) and exotic geometries: vendor weight gradient
-            self._vendor_wgrad.append((resid, ip, plan))
-        else:
-            self._vendor_wgrad.append((resid, ip, plan))
-        if plan.gb is not None:
-            self._bias_grads.append((resid, plan))
+        halves = len(plan.halves)
+        if halves > 1 and not hip_forward:
+            raise NotImplementedError("merging=%r: layer %s has a geometry only the vendor forward takes" % (self.merging, name))
+        for h, (in_maps, (r1, r2, nm)) in enumerate(plan.halves):
+            if cout != r1.numel():
+                raise RuntimeError("layer %s: %d merged outputs vs %d target blocks" % (name, cout, r1.numel()))
+            if in_maps[0].numel() != plan.w_shape[1]:
+                raise RuntimeError("layer %s: %d merged inputs vs %d input blocks" % (name, plan.w_shape[1], in_maps[0].numel()))
+            # merged input: queued for the ONE grouped merge launch that precedes the grouped forward (merge.flush); the
+            # vendor-forward path consumes it right here and takes the single-tensor launch
+            kept = self._bufs.get((idx, h)) if hip_forward else None
+            ip = self.merge.add(ip1, ip2, 1, *in_maps, out=kept[0] if kept else None) if hip_forward \
+                else ops.merge_blocks(ip1, ip2, 1, *in_maps)
+            if hip_forward:
+                resid = kept[1] if kept else torch.empty((ip.shape[0], cout) + tuple(o1.shape[2:]), dtype=torch.float32,
+                                                         device=ip.device)
+                if kept is None:
+                    self._bufs[(idx, h)] = (ip, resid)
+                n = resid.numel() * halves * self.world    # the mean runs over the full (global, stacked) batch
+                self.fwd.add(ip, plan.w, plan.b, o1, o2, r1, r2, nm, resid, 2.0 / n, 1.0 / n, *geo,
+                             flags=ops.FwdBatch.KPOS_MAJOR if plan.kpos else 0)
+                self._fwd_rows.append(idx)
+            else:                                        # vendor forward + fused target/residual (one launch per layer)
+                out = F.conv2d(ip, plan.w, plan.b, mod.stride, mod.padding, mod.dilation, mod.groups) if plan.is_conv \
+                    else F.linear(ip, plan.w, plan.b)
+                if out.shape[2:] != o1.shape[2:]:
+                    raise RuntimeError("layer %s: merged output %s vs source output %s" % (name, tuple(out.shape), tuple(o1.shape)))
+                n = out.numel() * self.world
+                nparts = ops.target_residual(out, o1, o2, r1, r2, nm, 2.0 / n, self.loss_parts[idx])
+                if self.loss_meta_host[idx] != (nparts, n):
+                    self.loss_meta_host[idx] = (nparts, n)
+                    self.loss_nparts[idx] = nparts
+                    self.loss_scale[idx] = 1.0 / n
+                resid = out
+            gw, gb = (plan.gw, plan.gb) if h == 0 else (plan.gw2, plan.gb2)   # second half: its own arena, added in _step
+            if (square and ip.shape[1] >= 16) or linear:
+                (self.wgrad_b if plan.bucket else self.wgrad).add(resid, ip, gw, *geo,
+                                                                 flags=ops.WgradBatch.KPOS_MAJOR if plan.kpos else 0)
+            else:   # stem (3 input channels) and exotic geometries: vendor weight gradient
+                self._vendor_wgrad.append((resid, ip, plan, gw))
+            if gb is not None:
+                self._bias_grads.append((resid, plan, gb))
 
     def _finish_vendor_parts(self) -> None:
-        for resid, ip, plan in self._vendor_wgrad:
+        for resid, ip, plan, gw in self._vendor_wgrad:
             mod = plan.mod
             if plan.is_conv:
-                gw = torch.ops.aten.convolution_backward(resid, ip, plan.w, None, mod.stride, mod.padding, mod.dilation,
-                                                         False, [0, 0], mod.groups, [False, True, False])[1]
-                plan.gw.copy_(gw)
+                g = torch.ops.aten.convolution_backward(resid, ip, plan.w, None, mod.stride, mod.padding, mod.dilation,
+                                                        False, [0, 0], mod.groups, [False, True, False])[1]
+                gw.copy_(g)
             else:
-                torch.mm(resid.reshape(-1, resid.shape[-1]).t(), ip.reshape(-1, ip.shape[-1]), out=plan.gw)
-        for resid, plan in self._bias_grads:
-            plan.gb.copy_(resid.sum((0, 2, 3)) if plan.is_conv else resid.reshape(-1, resid.shape[-1]).sum(0))
+                torch.mm(resid.reshape(-1, resid.shape[-1]).t(), ip.reshape(-1, ip.shape[-1]), out=gw)
+        for resid, plan, gb in self._bias_grads:
+            gb.copy_(resid.sum((0, 2, 3)) if plan.is_conv else resid.reshape(-1, resid.shape[-1]).sum(0))
 
     def _begin_update(self, x: torch.Tensor, next_x: Optional[torch.Tensor]) -> None:
         """Taps of ``x`` become current (running its sources now unless they were prefetched); the sources of
@@ -876,11 +940,15 @@ class PleasFitter:
                     self._fwd_loss = torch.zeros(len(self._fwd_rows), dtype=torch.float32, device=self.device)
                     self._fwd_index = torch.tensor(self._fwd_rows, dtype=torch.long, device=self.device)
                 self.fwd.flush(self._fwd_loss)
-        vendor_rows = len(self._fwd_rows) < len(self.plans)
+        vendor_rows = len(set(self._fwd_rows)) < len(self.plans)
         if vendor_rows:
             self.ops.loss_final(self.loss_parts, self.loss_nparts, self.loss_scale, self.loss_now)
         if self._fwd_rows:
-            self.loss_now.index_copy_(0, self._fwd_index, self._fwd_loss)
+            if self.stacked:        # two entries (half-batches) per layer: their losses add up
+                self.loss_now.zero_()
+                self.loss_now.index_add_(0, self._fwd_index, self._fwd_loss)
+            else:
+                self.loss_now.index_copy_(0, self._fwd_index, self._fwd_loss)
         self._finish_vendor_parts()
         two = self.wgrad_b is not None and self._bucket_cut > 0
         cut = self._bucket_cut
@@ -903,6 +971,8 @@ class PleasFitter:
                 merge_tab, fwd_tab = self.merge.table(), self.fwd.table()
                 if merge_tab is not None and fwd_tab is not None and len(merge_tab) == len(fwd_tab) == len(names):
                     self._replay = (key, names, merge_tab, fwd_tab, self._vendor_wgrad, self._bias_grads)
+        if self.stacked:
+            self.g.add_(self.g2)     # second half-batch's gradients (same launch, own arena)
         lr = self.lrs[min(self.step_count, len(self.lrs) - 1)]
         self.step_count += 1
         if two:
@@ -938,8 +1008,8 @@ def train(dataloader, model1, model2, model3, spec, perm, costs, budget_ratios, 
     single pass over ``dataloader`` and performs ``MAX_STEPS + 1`` updates if it is long enough.
     Puts ``model1``/``model2`` in eval mode (as the reference), mutates and returns ``model3``.
     """
-    if merging != "perm_gradmask":
-        raise NotImplementedError("merging=%r: only 'perm_gradmask' (the drivers' mode) is on the HIP path" % merging)
+    if solver == "normal_eq" and merging_mode(merging) != "perm_gradmask":
+        raise NotImplementedError("solver='normal_eq' fits the channel-merged objective (merging='perm_gradmask') only")
     if solver == "normal_eq":
         from .normal_eq import train_normal_eq
 
@@ -948,7 +1018,7 @@ def train(dataloader, model1, model2, model3, spec, perm, costs, budget_ratios, 
     if solver != "adam":
         raise ValueError("solver must be 'adam' or 'normal_eq'")
     fit = PleasFitter(model1, model2, model3, spec, perm, costs, budget_ratios, MAX_STEPS, lr, separate_classifier,
-                      num_classes, model_type)
+                      num_classes, model_type, merging=merging)
     names = [p.name for p in fit.plans]
 
     def inputs():

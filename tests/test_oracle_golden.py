@@ -164,3 +164,23 @@ def test_reference_disagrees_with_itself_on_the_stem_only(tiny_basic, ratio, ste
     m3 = orc.partial_merge(t.spec, t.m1, t.m2, perm, costs, ratio)
     m3, _ = orc.train(t.batches("xt"), t.m1, t.m2, m3, t.spec, perm, costs, ratio, steps, num_classes=10)
     gate_stem(m3.state_dict()["conv1.weight"], init, refs, obj, what="oracle")
+
+
+# ------------------------------------------------------------------ the other merging modes (pleas_merging.py:125-144)
+@pytest.mark.parametrize("mode,ratio", [("reg_mean", 0.0), ("perm_separatels", 0.5), ("perm_mixedls", 0.5)])
+@pytest.mark.parametrize("steps", [5, 20])
+def test_train_other_merging_modes(tiny_basic, mode, ratio, steps):
+    """tests/golden/tiny_modes.npz (make_golden_modes.py: the reference's train(merging=...)): the two half-batches
+    stacked along the sample axis, zeros in the absent blocks."""
+    t = tiny_basic
+    z = np.load(os.path.join(GOLDEN, "tiny_modes.npz"))
+    perm, costs = t.per_key("am_perm"), t.per_key("am_cost")
+    m3 = orc.partial_merge(t.spec, t.m1, t.m2, perm, costs, ratio)
+    m3, _ = orc.train(t.batches("xt"), t.m1, t.m2, m3, t.spec, perm, costs, ratio, steps, num_classes=10, merging=mode)
+    tag = "trained_%s_r%03d_s%d/" % (mode, int(ratio * 100), steps)
+    got = m3.state_dict()
+    for k in got:
+        want = torch.from_numpy(z[tag + k])
+        if want.dtype.is_floating_point and k != "conv1.weight":
+            rel = (got[k].float() - want.float()).norm() / (want.float().norm() + 1e-12)
+            assert rel < 1e-5, (k, float(rel))
