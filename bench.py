@@ -66,6 +66,8 @@ def parse(argv=None):
                          "default of 2; the prefetch takes --prefetch-groups forwards of that size")
     ap.add_argument("--grad-buckets", type=int, default=1, help="data parallel: 1 (default) = one all-reduce per update; "
                     "2 = the gradient arena is all-reduced in two halves, each beside the other half's kernels")
+    ap.add_argument("--shard-optimizer", action="store_true", help="data parallel: reduce-scatter the gradient arena, Adam on "
+                    "this rank's 1/world slice, all-gather the parameters (instead of all-reduce + full Adam on every rank)")
     ap.add_argument("--prefetch-memory", type=float, default=0.7, help="share of the free HBM the prefetched taps may take")
     ap.add_argument("--emulate-allreduce-us", type=float, default=0.0,
                     help="with --emulate-world: hold the update stream this long where the gradient all-reduce would run")
@@ -213,7 +215,7 @@ def run_job(cfg, spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, phases
     # Data parallel: each rank's share of an update is small (batch / world samples); the frozen sources therefore forward
     # 2 * world updates' samples at once (steps() default), which keeps their host dispatch off the per-update path.
     fit = PleasFitter(m1, m2, m3, spec, perm, costs, cfg["ratio"], n_pleas_sched, data_parallel=dp,
-                      sources=early.get("sources"), grad_buckets=cfg["grad_buckets"])
+                      sources=early.get("sources"), grad_buckets=cfg["grad_buckets"], shard_optimizer=cfg["shard_optimizer"])
     phases.mark("merge_and_setup")
     first = None
     for i in fit.steps(inputs, lookahead=cfg["lookahead"], sources_per_forward=cfg["sources_per_forward"]):
@@ -412,7 +414,7 @@ def main():
         os.environ["PLEAS_EMULATE_ALLREDUCE_US"] = str(args.emulate_allreduce_us)
         dp = True
     cfg = {"dp": dp, "ratio": args.ratio, "prefetch_groups": args.prefetch_groups, "prefetch_memory": args.prefetch_memory,
-           "grad_buckets": args.grad_buckets, "sources_per_forward": (args.sources_per_forward * ranks) or None, "lookahead": None if args.lookahead < 0 else bool(args.lookahead)}
+           "grad_buckets": args.grad_buckets, "shard_optimizer": args.shard_optimizer, "sources_per_forward": (args.sources_per_forward * ranks) or None, "lookahead": None if args.lookahead < 0 else bool(args.lookahead)}
     log("spec (%d groups, %.2f s on the host, outside `value`) + %d synthetic batches resident" % (len(spec), spec_s, len(pool.items)))
 
     def job(phases=None):

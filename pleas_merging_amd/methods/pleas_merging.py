@@ -289,6 +289,35 @@ def dp_sum_(flat: torch.Tensor, world: int, share: float = 1.0) -> torch.Tensor:
     return flat
 
 
+def dp_reduce_scatter_(flat: torch.Tensor, mine: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    """Sum of ``flat`` over ranks, of which this rank needs only its ``rank``-th 1/world slice: ONE reduce-scatter into
+    ``mine`` (RCCL); backends without it (gloo, the single-GPU rehearsals) all-reduce and take the slice."""
+    import torch.distributed as dist
+
+    n = flat.numel() // world
+    if not dist.is_initialized():              # PLEAS_EMULATE_WORLD: no peers
+        return flat[rank * n:(rank + 1) * n]
+    if dist.get_backend() == "nccl":
+        dist.reduce_scatter_tensor(mine, flat, op=dist.ReduceOp.SUM)
+        return mine
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return flat[rank * n:(rank + 1) * n]
+
+
+def dp_all_gather_(flat: torch.Tensor, rank: int, world: int) -> None:
+    """Every rank's updated 1/world slice of ``flat`` to all ranks, in place (ONE all-gather)."""
+    import torch.distributed as dist
+
+    if not dist.is_initialized():
+        return
+    n = flat.numel() // world
+    mine = flat[rank * n:(rank + 1) * n].clone()       # the collective must not read from its own output
+    if dist.get_backend() == "nccl":
+        dist.all_gather_into_tensor(flat, mine)
+    else:
+        dist.all_gather(list(flat.chunk(world)), mine)
+
+
 class _Pending:
     """An all-reduce in flight (``dist.all_reduce(..., async_op=True)``, or its emulation on a stream of its own);
     ``wait()`` orders the current stream after it."""
@@ -563,7 +592,7 @@ class PleasFitter:
                  separate_classifier=False, num_classes=1000, model_type="rn50", data_parallel: bool = False,
                  forward: str = "hip", graph_sources: bool = False, fuse_sources: bool = True,
                  overlap_sources: bool = True, fused_sources=None, sources: Optional[FrozenSources] = None,
-                 grad_buckets: int = 1, merging: str = "perm_gradmask"):
+                 grad_buckets: int = 1, merging: str = "perm_gradmask", shard_optimizer: bool = False):
         from .. import hip_ops
 
         self.ops = hip_ops
@@ -598,6 +627,15 @@ class PleasFitter:
         self.layer_modules = layers
         pad4 = lambda n: (n + 3) // 4 * 4   # every tensor starts 16-byte aligned inside the arenas (vector loads)
         total = sum(pad4(p.numel()) for m in layers.values() for p in m.parameters())
+        # shard_optimizer (option, data parallel): rank r keeps the Adam moments of -- and applies the update to -- the r-th
+        # 1/world slice of the flat arena only: reduce-scatter of the gradients, Adam on the slice, all-gather of the
+        # parameters.  Same bytes on the links as the all-reduce, 1/world of the optimiser's work and state per rank.
+        self.shard_optimizer = bool(shard_optimizer) and self.world > 1
+        if self.shard_optimizer:
+            if grad_buckets >= 2:
+                raise ValueError("shard_optimizer and grad_buckets >= 2 are alternatives")
+            total = (total + 4 * self.world - 1) // (4 * self.world) * (4 * self.world)    # equal, 16-byte aligned slices
+        self._shard = total // self.world if self.shard_optimizer else total
         dev = self.device
         self.p = torch.zeros(total, dtype=torch.float32, device=dev)
         # the gradient arena carries this update's per-layer losses in its tail: ONE collective per update sums both
@@ -606,8 +644,9 @@ class PleasFitter:
         # stacked modes: the second half-batch's weight gradients land in an arena of their own (two entries of one grouped
         # launch must not write the same tensor) and are added before the exchange / the optimiser
         self.g2 = torch.zeros(total, dtype=torch.float32, device=dev) if self.stacked else None
-        self.m = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.v = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(self._shard, dtype=torch.float32, device=dev)     # this rank's slice only when sharded
+        self.v = torch.zeros(self._shard, dtype=torch.float32, device=dev)
+        self._g_shard = torch.zeros(self._shard, dtype=torch.float32, device=dev) if self.shard_optimizer else None
         self.mask = torch.ones(total, dtype=torch.float32, device=dev)   # frozen blocks are zeroed in place below
         self.plans: List[_LayerPlan] = []
         off, k = 0, 0
@@ -982,6 +1021,13 @@ class PleasFitter:
                     pending[half].wait()
                 self.ops.masked_adam(self.p[sl], self.g[sl], self.mask[sl], self.m[sl], self.v[sl], lr, self.step_count)
             self.loss_sum.add_(self.loss_now)
+        elif self.shard_optimizer:
+            lo, hi = self.rank * self._shard, (self.rank + 1) * self._shard
+            g_mine = dp_reduce_scatter_(self.g, self._g_shard, self.rank, self.world)
+            dp_sum_(self.loss_now, self.world)
+            self.loss_sum.add_(self.loss_now)
+            self.ops.masked_adam(self.p[lo:hi], g_mine, self.mask[lo:hi], self.m, self.v, lr, self.step_count)
+            dp_all_gather_(self.p, self.rank, self.world)
         else:
             dp_sum_(self._g_ext, self.world)     # gradients + losses
             self.loss_sum.add_(self.loss_now)
