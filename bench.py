@@ -76,7 +76,7 @@ def parse(argv=None):
                     "one GPU, 1 under data parallelism (fills the all-reduce gaps)")
     ap.add_argument("--profile-all", action="store_true", help="also bracket the many-launch elementwise kernel "
                     "(bn_act) with events: complete kernels_ms, slightly slower timed region")
-    ap.add_argument("--cpu-sample-batch", type=int, default=4)
+    ap.add_argument("--cpu-sample-batch", type=int, default=8)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                                                       "the multi-rank logic on a single GPU)")
     ap.add_argument("--all-ranks-on-gpu0", action="store_true", help="rehearsal only: every rank uses cuda:0")
@@ -308,7 +308,7 @@ def time_sources_alone(m1, m2, pool, n_updates, per=2, groups=4):
 
 def cpu_baseline(spec, arch, batch_full, sample_batch, n_match, n_pleas, ratio):
     """Oracle (CPU restatement of the reference path) on this box's host cores, bounded sample:
-    2 matching batches + 2 PLeaS updates at a reduced batch size, all LAPs, the merge; extrapolated linearly
+    3 matching batches + 3 PLeaS updates at a reduced batch size (~10-15 s of CPU work), all LAPs, the merge; extrapolated linearly
     in samples to the job that the GPU ran."""
     from oracle import pleas_oracle as orc
     from pleas_merging_amd import resnet as zoo
@@ -325,10 +325,10 @@ def cpu_baseline(spec, arch, batch_full, sample_batch, n_match, n_pleas, ratio):
         models.append(m)
     m1, m2 = models
     g = torch.Generator().manual_seed(1000)
-    data = [(torch.randn(sample_batch, 3, 224, 224, generator=g), None) for _ in range(4)]
+    data = [(torch.randn(sample_batch, 3, 224, 224, generator=g), None) for _ in range(6)]
     t0 = time.time()
-    costs = orc.matching_costs(spec, m1, m2, data[:2], 2, accumulate=True)
-    t_match = (time.time() - t0) / 2
+    costs = orc.matching_costs(spec, m1, m2, data[:3], 3, accumulate=True)
+    t_match = (time.time() - t0) / 3
     log("cpu: matching batch %.1fs" % t_match)
     t0 = time.time()
     perm = {k: orc.solve_lsa(v) for k, v in costs.items()}
@@ -337,14 +337,14 @@ def cpu_baseline(spec, arch, batch_full, sample_batch, n_match, n_pleas, ratio):
     m3 = orc.partial_merge(spec, m1, m2, perm, costs, ratio)
     t_merge = time.time() - t0
     t0 = time.time()
-    orc.train(data[2:4], m1, m2, m3, spec, perm, costs, ratio, 1)
-    t_step = (time.time() - t0) / 2
+    orc.train(data[3:6], m1, m2, m3, spec, perm, costs, ratio, 2)
+    t_step = (time.time() - t0) / 3
     log("cpu: PLeaS update %.1fs" % t_step)
     scale = batch_full / sample_batch
     total = n_match * t_match * scale + t_lap + t_merge + n_pleas * t_step * scale
     return {
         "value": round(total, 1), "unit": "s", "cores": cores, "kind": "port",
-        "sample": "oracle on %s pair: 2 matching batches (%.1fs each) + 2 PLeaS updates (%.1fs each) at batch %d, all %d "
+        "sample": "oracle on %s pair: 3 matching batches (%.1fs each) + 3 PLeaS updates (%.1fs each) at batch %d, all %d "
                   "LAPs (%.2fs), merge (%.2fs); batches scaled x%.0f to batch %d, then x%d matching + x%d updates"
                   % (arch, t_match, t_step, sample_batch, len(perm), t_lap, t_merge, scale, batch_full, n_match, n_pleas),
     }
