@@ -238,7 +238,10 @@ int pleas_sqerr(const float* a, const float* b, int64_t n, float scale, int accu
  *   tgt   = coef(co) * ([row1[co]>=0] o1[n][row1[co]] + [row2[co]>=0] o2[n][row2[co]]),  coef = 0.5 for co < n_merged
  *   resid = dscale * (out - tgt)      -> layers[i].resid  (the input of pleas_wgrad_batch)
  *   loss[i] = loss_scale * sum (out - tgt)^2           (DEVICE float[n_layers], fixed summation order)
- * A Linear layer is Hin = Win = KH = KW = 1.  w must be 16-byte aligned.  ws / ws_fresh as in pleas_gram_batch.
+ * A Linear layer is Hin = Win = KH = KW = 1.  w and ip must be 16-byte aligned.  ws / ws_fresh as in pleas_gram_batch.
+ * Stride-1 "same" convolutions with Cin % 32 == 0 (k x k: with PLEAS_FWD_KPOS_MAJOR) take the flat-shift tile forms; the
+ * forms of a call run as separate grids on the caller's stream and up to three side streams of the library, joined
+ * before the call's last kernel (fwd_loss) is enqueued on `stream`.
  */
 typedef struct pleas_fwd_layer {
     const float* ip;     /* [N][Cin][Hin][Win] merged input */

@@ -696,10 +696,18 @@ struct FwdSideStreams {
     bool ok = false;
 };
 static FwdSideStreams& fwd_side_streams() {
-    static FwdSideStreams s;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
+    // one set per device (streams belong to the device that was current when they were created)
+    constexpr int kMaxDev = 16;
+    static FwdSideStreams sets[kMaxDev];
+    static bool tried[kMaxDev] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) {
+        static FwdSideStreams none;      // ok == false: the forms go back to back on the caller's stream
+        return none;
+    }
+    FwdSideStreams& s = sets[dev];
+    if (!tried[dev]) {
+        tried[dev] = true;
         bool ok = hipEventCreateWithFlags(&s.forked, hipEventDisableTiming) == hipSuccess;
         for (int i = 0; ok && i < fLanes; ++i)
             ok = hipStreamCreateWithFlags(&s.streams[i], hipStreamNonBlocking) == hipSuccess &&
@@ -936,6 +944,7 @@ extern "C" int pleas_fwd_batch(const pleas_fwd_layer* layers, int n_layers, floa
         const pleas_fwd_layer& l = layers[i];
         if (!l.ip || !l.w || !l.o1 || !l.o2 || !l.row1 || !l.row2 || !l.resid) return bad_arg("conv_fwd: null pointer");
         if (((uintptr_t)l.w & 15) != 0) return bad_arg("conv_fwd: weights must be 16-byte aligned");
+        if (((uintptr_t)l.ip & 15) != 0) return bad_arg("conv_fwd: the merged input must be 16-byte aligned");
     }
     hipStream_t stream = (hipStream_t)stream_;
     std::lock_guard<std::mutex> lk(g_fplan_mu);
