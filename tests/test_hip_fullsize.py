@@ -254,6 +254,20 @@ def test_rn50_full_merge_pleas_vs_oracle(rn50):
     assert widths["layer4.2.conv3.weight"] == 2048
 
 
+def test_rn18_config1_matching_and_pleas_vs_oracle():
+    """configs[1]: ResNet-18 pair (BasicBlock: 3x3 layers only, 12 groups), activation matching + PLeaS at 224 x 224,
+    full merge: matching (near-tie rule), merged state dict bit-equal, PLeaS updates by the gate of _merge_and_train."""
+    from pleas.methods.activation_matching import activation_matching
+
+    p = Pair("resnet18")
+    m1, m2 = p.gpu()
+    assert len(p.spec) == 12
+    perm, costs = activation_matching(p.spec, m1, m2, p.data, 2, output_costs=True)
+    _check_matching(p, perm, costs)
+    widths, _, _ = _merge_and_train(p, 0.0, 3)
+    assert widths["layer4.1.conv2.weight"] == 512
+
+
 def test_rn101_mixed_ratio_masks_and_frozen_blocks(rn101):
     """Ratio 0.5 in every group: every layer has merged AND separate units (n_merged < Cout), so the transposed
     gradient-mask blocks (reference pleas_merging.py:57-58) are exercised at full size.  3 updates vs the oracle."""

@@ -655,3 +655,47 @@ def test_bn_train_fold_equals_train_mode_batchnorm(shape, momentum):
     assert _rel(hip_ops.bn_act(x.cuda(), scale, shift, None, relu=False).cpu(), want) < 1e-6
     with pytest.raises(ValueError):
         hip_ops.bn_train_fold(dev, torch.randn(1, C, 1, 1).cuda())
+
+
+def test_fwd_batch_flat_forms_random_geometries(ops):
+    """Property test of the flat-shift tile forms over random stride-1 "same" geometries (image sizes from 1x1 to 30x30,
+    tiles that straddle up to 128 samples, ragged channel tiles, 1x1 / 3x3 / 5x5, with and without bias): every layer of
+    ONE grouped launch against fp64 convolution + block-merged target, forms mixed in the launch as in a real update."""
+    import torch.nn.functional as F
+    from pleas_merging_amd.methods.partial_matching import block_maps
+
+    g = torch.Generator().manual_seed(1234)
+    rnd = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    batch = ops.FwdBatch(torch.device("cuda"))
+    cases = []
+    for i in range(24):
+        k = (1, 3, 5, 1, 3, 3)[i % 6]
+        pad = k // 2
+        H, W = (1, 1) if i == 3 else (rnd(2, 30), rnd(2, 30))
+        if k == 5:
+            H, W = min(H, 12), min(W, 12)           # halo 2 * (W + 1) must fit the image rows of the k x k form
+        N, Cin, Cout = rnd(1, 9), 32 * rnd(1, 4), rnd(8, 200)
+        ip = torch.randn(N, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+        b = torch.randn(Cout, generator=g) if i % 4 == 1 else None
+        ns = Cout // 4
+        nm = Cout - 2 * ns
+        Csrc = nm + ns
+        pm = torch.randperm(Csrc, generator=g)
+        blk = (torch.arange(nm), pm[:nm], torch.arange(nm, Csrc), pm[nm:])
+        o1, o2 = torch.randn(N, Csrc, H, W, generator=g), torch.randn(N, Csrc, H, W, generator=g)
+        target = torch.cat([(o1[:, blk[0]] + o2[:, blk[1]]) / 2, o1[:, blk[2]], o2[:, blk[3]]], 1)
+        out = F.conv2d(ip.double(), w.double(), b.double() if b is not None else None, 1, pad)
+        numel = out.numel()
+        r1, r2, nmerged = block_maps(blk, "cuda")
+        resid = torch.full((N, Cout, H, W), float("nan"), device="cuda")
+        wk = w.permute(0, 2, 3, 1).contiguous().cuda() if k > 1 else w.cuda().contiguous()
+        keep = (ip.cuda(), wk, b.cuda() if b is not None else None, o1.cuda(), o2.cuda(), r1, r2, resid)
+        batch.add(keep[0], wk, keep[2], keep[3], keep[4], r1, r2, nmerged, resid, 2.0 / numel, 1.0 / numel, (k, k), 1, pad,
+                  flags=ops.FwdBatch.KPOS_MAJOR if k > 1 else 0)
+        cases.append((keep, 2 * (out - target.double()) / numel, float(((out - target.double()) ** 2).mean()), (N, Cout, Cin, H, W, k)))
+    loss = torch.zeros(len(cases), device="cuda")
+    batch.flush(loss)
+    for i, (keep, want, want_loss, geo) in enumerate(cases):
+        assert _rel(keep[7].cpu(), want) < 5e-6, (geo, _rel(keep[7].cpu(), want))
+        assert abs(float(loss[i]) - want_loss) < 1e-5 * max(1.0, want_loss), geo
