@@ -516,6 +516,8 @@ def main():
             if os.path.exists(tpath) and args.arch == "resnet101" and args.batch == 16 and world == 1:
                 roofs[key]["traffic"] = json.load(open(tpath)).get("hbm_bytes_per_launch")
                 roofs[key]["traffic_source"] = "profiles/" + fname
+                if roofs[key]["traffic"] and roofs[key]["avg_launch_us"]:    # north_star: rocprof HBM GB/s of the accumulation
+                    roofs[key]["hbm_gbps"] = round(roofs[key]["traffic"] / (roofs[key]["avg_launch_us"] * 1e-6) / 1e9, 1)
         dominant = max(roofs, key=lambda k: roofs[k]["total_ms"])   # own kernel with the most time in the timed region
         roofline = roofs[dominant]
         other = {k: v for k, v in roofs.items() if k != dominant}
