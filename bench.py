@@ -66,6 +66,9 @@ def parse(argv=None):
                          "default of 2; the prefetch takes --prefetch-groups forwards of that size")
     ap.add_argument("--grad-buckets", type=int, default=1, help="data parallel: 1 (default) = one all-reduce per update; "
                     "2 = the gradient arena is all-reduced in two halves, each beside the other half's kernels")
+    ap.add_argument("--miopen-find", type=int, default=0, help="1: torch.backends.cudnn.benchmark = True, i.e. the vendor "
+                    "library times its candidate convolution kernels per configuration (Find mode) instead of taking the "
+                    "immediate-mode pick; costs seconds per new configuration in the first warm-up job")
     ap.add_argument("--shard-optimizer", action="store_true", help="data parallel: reduce-scatter the gradient arena, Adam on "
                     "this rank's 1/world slice, all-gather the parameters (instead of all-reduce + full Adam on every rank)")
     ap.add_argument("--prefetch-memory", type=float, default=0.7, help="share of the free HBM the prefetched taps may take")
@@ -386,6 +389,7 @@ def main():
         else:
             dist.init_process_group(args.backend)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 
