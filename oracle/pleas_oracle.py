@@ -382,9 +382,11 @@ def _hook_inputs(model, store):
 
 
 def train(batches, model1, model2, model3, spec, perm, costs, ratios, max_steps: int, num_classes=1000, lr=5e-4,
-          separate_classifier=False, model_type="rn50", merging="perm_gradmask"):
+          separate_classifier=False, model_type="rn50", merging="perm_gradmask", on_update=None):
     """Reference: pleas/methods/pleas_merging.py:305-405 (step: :234-302); ``merging`` as in :func:`layer_targets`.
-    Adam + cosine schedule on copies of model3's Conv/Linear layers; ``max_steps + 1`` updates."""
+    Adam + cosine schedule on copies of model3's Conv/Linear layers; ``max_steps + 1`` updates.
+    ``on_update(idx, layers, per_layer_losses)`` (test aid, not in the reference): called after update ``idx`` with the
+    layers being trained and this update's loss per layer, so that a trajectory can be recorded."""
     perm_blocks = spread_blocks(spec, get_blocks(spec, perm, costs, ratios))
     acts1, acts2 = {}, {}
     handles = _hook_inputs(model1, acts1) + _hook_inputs(model2, acts2)
@@ -408,18 +410,23 @@ def train(batches, model1, model2, model3, spec, perm, costs, ratios, max_steps:
             model2(x)
         opt.zero_grad()
         total = 0.0
+        per_layer = []
         for name, layer in layers.items():
             with torch.no_grad():
                 ip, op = layer_targets(get_attr(model1, name.split(".")), get_attr(model2, name.split(".")),
                                        perm_blocks, name, acts1[name], acts2[name], num_classes,
                                        separate_classifier, model_type, merging)
-            total = total + ((layer(ip) - op) ** 2).mean()
+            loss = ((layer(ip) - op) ** 2).mean()
+            per_layer.append(float(loss.detach()))
+            total = total + loss
         total.backward()
         for p, m in zip(params, masks):
             p.grad *= m
         opt.step()
         sched.step()
         losses.append(float(total.detach()))
+        if on_update is not None:
+            on_update(idx, layers, per_layer)
         acts1.clear()
         acts2.clear()
     sd = model3.state_dict()

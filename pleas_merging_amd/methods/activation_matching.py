@@ -409,6 +409,14 @@ def _collectives_on() -> bool:
     return dist.is_available() and dist.is_initialized()
 
 
+def _force_collectives() -> bool:
+    """PLEAS_FORCE_COLLECTIVES=1 with ``torch.distributed`` initialised: the path's exchange steps are issued even when
+    the group has ONE rank (where a sum over ranks is the identity), so that the very calls an N-rank job makes --
+    ``all_reduce`` of the cost arena and of the gradient arena, ``reduce_scatter_tensor`` / ``all_gather_into_tensor``
+    under ``shard_optimizer`` -- go through RCCL on a one-GPU box and can be timed there."""
+    return os.environ.get("PLEAS_FORCE_COLLECTIVES", "0") not in ("", "0") and _collectives_on()
+
+
 def _model_device(model: nn.Module) -> torch.device:
     return next(iter(model.parameters())).device
 
@@ -425,7 +433,7 @@ def shard_batches(dataloader, num_batches: int, rank: int, world: int):
 def allreduce_sum_(flat: torch.Tensor, world: int) -> torch.Tensor:
     """The one exchange step of the matching path: sum the flat cost arena over ranks
     (RCCL over xGMI under the ``nccl`` backend; gloo in the CPU tests)."""
-    if world > 1 and _collectives_on():
+    if (world > 1 and _collectives_on()) or _force_collectives():
         import torch.distributed as dist
 
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)

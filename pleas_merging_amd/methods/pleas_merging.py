@@ -279,7 +279,9 @@ def dp_slice(x: torch.Tensor, rank: int, world: int) -> torch.Tensor:
 def dp_sum_(flat: torch.Tensor, world: int, share: float = 1.0) -> torch.Tensor:
     """Sum of the flat gradient arena over ranks (ONE collective per update).  Each rank scales its
     residual by 2 / (local numel * world), so the sum IS the gradient of the full-batch mean."""
-    if world > 1:
+    from .activation_matching import _force_collectives
+
+    if world > 1 or _force_collectives():
         import torch.distributed as dist
 
         if dist.is_initialized():
@@ -630,7 +632,9 @@ class PleasFitter:
         # shard_optimizer (option, data parallel): rank r keeps the Adam moments of -- and applies the update to -- the r-th
         # 1/world slice of the flat arena only: reduce-scatter of the gradients, Adam on the slice, all-gather of the
         # parameters.  Same bytes on the links as the all-reduce, 1/world of the optimiser's work and state per rank.
-        self.shard_optimizer = bool(shard_optimizer) and self.world > 1
+        from .activation_matching import _force_collectives
+
+        self.shard_optimizer = bool(shard_optimizer) and (self.world > 1 or _force_collectives())
         if self.shard_optimizer:
             if grad_buckets >= 2:
                 raise ValueError("shard_optimizer and grad_buckets >= 2 are alternatives")

@@ -73,6 +73,36 @@ class Tiny:
         return {k: torch.from_numpy(self.z["%s/%s" % (prefix, k)]) for k in self.spec}
 
 
+class LongTrain:
+    """tests/golden/tiny_bottleneck_train.npz: weights trained BY THE REFERENCE on the two tiny fixtures for 6 / 21 / 401
+    updates (make_golden_bottleneck_train.py).  The training batches are regenerated from their seeds and checked against
+    the SHA-256 the generator stored, so the comparison is on the reference's own inputs."""
+
+    def __init__(self):
+        self.z = np.load(os.path.join(GOLDEN, "tiny_bottleneck_train.npz"))
+        self.n = int(self.z["n_long"])
+        self._data = None
+
+    def batches(self, n=None):
+        import hashlib
+
+        if self._data is None:
+            data = [torch.randn(4, 3, 32, 32, generator=torch.Generator().manual_seed(900 + i)) for i in range(self.n)]
+            digest = hashlib.sha256(b"".join(x.numpy().tobytes() for x in data)).hexdigest()
+            if digest != str(self.z["xt_sha256"]):
+                pytest.skip("torch.randn no longer reproduces the reference run's training batches on this build")
+            self._data = [(x, torch.zeros(4, dtype=torch.long)) for x in data]
+        return self._data[:n] if n is not None else self._data
+
+    def state(self, prefix):
+        return {k[len(prefix) + 1:]: torch.from_numpy(self.z[k]) for k in self.z.files if k.startswith(prefix + "/")}
+
+
+@pytest.fixture(scope="session")
+def long_train():
+    return LongTrain()
+
+
 @pytest.fixture(scope="session")
 def tiny_basic():
     return Tiny("tiny_basic.npz")

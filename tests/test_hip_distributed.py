@@ -11,6 +11,7 @@ import torch
 import torch.multiprocessing as mp
 
 from conftest import REPO
+from stem_gate import gate_stem, stem_objective
 
 pytestmark = pytest.mark.gpu
 
@@ -30,14 +31,16 @@ def _job(t, data_parallel, buckets=1, shard=False):
     m1, m2 = copy.deepcopy(t.m1).cuda(), copy.deepcopy(t.m2).cuda()
     perm, costs = activation_matching(t.spec, m1, m2, t.batches(), N_MATCH, output_costs=True)
     m3 = partial_merge(t.spec, m1, m2, perm, costs, 0.5)
+    merged_stem = m3.state_dict()["conv1.weight"].detach().cpu().clone()
     fit = PleasFitter(m1, m2, m3, t.spec, perm, costs, 0.5, N_UPDATES - 1, num_classes=10, data_parallel=data_parallel,
                       grad_buckets=buckets, shard_optimizer=shard)
     assert fit.shard_optimizer == (shard and fit.world > 1) and fit.m.numel() * (fit.world if fit.shard_optimizer else 1) == fit.p.numel()
     assert list(fit.steps(_batches(t))) == list(range(N_UPDATES))
     loss = fit.loss_sum.clone()
     torch.cuda.synchronize()
-    return ({k: v.cpu() for k, v in perm.items()}, {k: v.cpu() for k, v in costs.items()},
-            {k: v.cpu() for k, v in fit.finish().state_dict().items()}, loss.cpu(), fit.world)
+    sd = {k: v.cpu() for k, v in fit.finish().state_dict().items()}
+    sd["__merged_stem"] = merged_stem
+    return ({k: v.cpu() for k, v in perm.items()}, {k: v.cpu() for k, v in costs.items()}, sd, loss.cpu(), fit.world)
 
 
 def _job_normal_eq(t):
@@ -120,8 +123,12 @@ def test_two_rank_job_equals_single_process_job(tiny_bottleneck, buckets):    # 
         for k, v in want_sd.items():
             if not v.dtype.is_floating_point:
                 continue
-            if k == "conv1.weight":   # degenerate stem: sign-like Adam steps amplify rounding
-                assert torch.allclose(sd[k], v, atol=2 * 5e-4 * N_UPDATES), (rank, k)
+            if k == "conv1.weight":   # degenerate stem: its residual is rounding noise -- travel from
+                # the merged value within 1.5x the single-process run's own, and the same layer objective (tests/stem_gate.py)
+                t = tiny_bottleneck
+                gate_stem(sd[k], want_sd["__merged_stem"], [v],
+                          lambda w: stem_objective(t.m1, t.m2, w, t.spec, want_perm, want_costs, 0.5,
+                                                   [(x, None) for x in _batches(t)], 10), what="rank %d stem" % rank)
             else:
                 assert _rel(sd[k], v) < 2e-5, (rank, k, _rel(sd[k], v))
     # both ranks hold the same model, bit for bit (every rank applies the same all-reduced update)

@@ -92,7 +92,7 @@ def test_rn101_train_mode_matching_vs_oracle(rn101):
         spec, want_perm, want_costs = rn101.spec, None, None
 
     Want.want_perm, Want.want_costs = want_perm, want_costs
-    flips = _check_matching(Want, perm, costs, max_flipped_groups=10)
+    flips = _check_matching(Want, perm, costs)
     worst = 0.0
     for g, c in zip(gpu, cpu):
         assert g.training
@@ -109,7 +109,10 @@ def _value(cost, perm):
     return float(cost.double().cpu()[torch.arange(len(perm)), perm].sum())
 
 
-def _check_matching(p, perm, costs, max_flipped_groups=8):
+MAX_FLIPPED_GROUPS = 4      # observed on the MI355X: 2 groups (8 and 9 units, gap <= 1e-7) of 71; + 2 of margin
+
+
+def _check_matching(p, perm, costs, max_flipped_groups=MAX_FLIPPED_GROUPS):
     """Costs within 1e-4 rel-fro of the oracle's in every group.  Assignments: IDENTICAL to the oracle's, except in
     groups where the optimum is a near-tie that fp32 rounding of the cost matrix decides -- there (i) the HIP assignment
     is exactly what the oracle's LAP (scipy's algorithm) returns on the HIP cost matrix, i.e. the integer path is exact,
@@ -127,7 +130,8 @@ def _check_matching(p, perm, costs, max_flipped_groups=8):
             gap = (best - mine) / abs(best)
             assert 0 <= gap < 1e-6, (k, n, gap)
             flips[str(k)] = (n, gap)
-    assert len(flips) <= max_flipped_groups, flips
+    print("groups with a near-tie assignment flip (units, optimality gap under the oracle's costs):", flips)
+    assert len(flips) <= max_flipped_groups, ("flipped groups: %d observed, %d allowed" % (len(flips), max_flipped_groups), flips)
     return flips
 
 

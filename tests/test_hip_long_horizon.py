@@ -1,0 +1,131 @@
+"""LONG-HORIZON parity: the drivers' full 401 PLeaS updates (reference pleas_merging.py:367-375), not the first few.
+
+(1) Weights trained BY THE REFERENCE for 6 / 21 / 401 updates on the two tiny fixtures (tests/golden/
+    tiny_bottleneck_train.npz, make_golden_bottleneck_train.py) against the HIP path: the north-star gate, 1e-4 rel-fro
+    per tensor; the Bottleneck fixture had no reference-trained golden before.
+(2) A ResNet-50 pair at 224 x 224, batch 2, 401 updates: HIP path against the oracle (which follows the reference to
+    1e-5 over 401 updates on the tiny fixtures), snapshots after 1 / 3 / 21 / 101 / 401 updates.  Gate per layer at
+    update 401: objective within 1 %, weights within max(1e-4, 3 x the oracle's disagreement with ITSELF at that
+    update) (tests/golden/long_horizon_resnet50_spread.json: same run with oneDNN convolutions off).  The trajectory of
+    the worst tensor is printed and, when gpurun_out/ exists, written to gpurun_out/r03_long_horizon_rn50.json.
+"""
+import copy
+import json
+import os
+
+import pytest
+import torch
+
+from conftest import GOLDEN, REPO
+from stem_gate import gate_stem, stem_objective
+import long_horizon as lh
+
+pytestmark = pytest.mark.gpu
+
+DEGENERATE = "conv1.weight"
+TOL = 1e-4
+
+
+@pytest.mark.parametrize("fx,ratio,steps", [("tiny_bottleneck", 0.0, 5), ("tiny_bottleneck", 0.5, 5),
+                                            ("tiny_bottleneck", 0.0, 20), ("tiny_bottleneck", 0.5, 20),
+                                            ("tiny_bottleneck", 0.0, 400), ("tiny_bottleneck", 0.5, 400),
+                                            ("tiny_basic", 0.0, 400), ("tiny_basic", 0.5, 400)])
+def test_train_vs_reference_trained_weights(fx, ratio, steps, long_train, request):
+    from pleas.methods.partial_matching import partial_merge
+    from pleas.methods.pleas_merging import train
+
+    t = request.getfixturevalue(fx)
+    perm = t.per_key("am_perm")
+    costs_c = t.per_key("am_cost")
+    costs = {k: v.cuda() for k, v in costs_c.items()}
+    m1, m2 = copy.deepcopy(t.m1).cuda(), copy.deepcopy(t.m2).cuda()
+    tag = "%s_r%03d" % (t.block, int(ratio * 100))
+    m3 = partial_merge(t.spec, m1, m2, perm, costs, ratio)
+    init = m3.state_dict()[DEGENERATE].clone()
+    if t.block == "bottleneck":
+        want = long_train.state("merged_" + tag)
+        for k, v in m3.state_dict().items():
+            assert torch.equal(v.cpu(), want[k]), k
+    data = long_train.batches()
+    m3 = train(data, m1, m2, m3, t.spec, perm, costs, ratio, False, steps, None, num_classes=10)
+    want = long_train.state("trained_%s_s%d" % (tag, steps))
+    got = m3.state_dict()
+    rels = {k: lh.rel(got[k], want[k]) for k in want if want[k].dtype.is_floating_point and k != DEGENERATE}
+    worst = max(rels, key=rels.get)
+    print("%s ratio %.1f, %d updates: worst tensor %s %.2e" % (fx, ratio, steps + 1, worst, rels[worst]))
+    assert rels[worst] < TOL, (worst, rels[worst])
+    gate_stem(got[DEGENERATE], init, [want[DEGENERATE]],
+              lambda w: stem_objective(t.m1, t.m2, w, t.spec, perm, costs_c, ratio, data[:steps + 1], 10),
+              what="%s ratio %.1f, %d updates" % (fx, ratio, steps + 1))
+
+
+def _fit_weights(fit):
+    out = {}
+    for plan in fit.plans:
+        out["%s.weight" % plan.name] = (plan.w.detach().permute(0, 3, 1, 2) if plan.kpos else plan.w.detach()).cpu().clone()
+        if plan.b is not None:
+            out["%s.bias" % plan.name] = plan.b.detach().cpu().clone()
+    return out
+
+
+def test_rn50_401_updates_vs_oracle():
+    from oracle import pleas_oracle as orc
+    from pleas.methods.partial_matching import partial_merge
+    from pleas.methods.pleas_merging import PleasFitter
+
+    spread = json.load(open(os.path.join(GOLDEN, "long_horizon_resnet50_spread.json")))
+    assert spread["batch"] == lh.BATCH and tuple(spread["snapshots"]) == lh.SNAPSHOTS
+    m1, m2, spec, match, train = lh.build_pair("resnet50")
+    perm, costs = orc.activation_matching(spec, m1, m2, match, 2, accumulate=True)
+
+    # ---- HIP path (from the ORACLE's permutation and costs, so that both sides merge the same blocks)
+    g1, g2 = copy.deepcopy(m1).cuda(), copy.deepcopy(m2).cuda()
+    gcosts = {k: v.cuda() for k, v in costs.items()}
+    m3 = partial_merge(spec, g1, g2, perm, gcosts, 0.0)
+    fit = PleasFitter(g1, g2, m3, spec, perm, gcosts, 0.0, lh.N_UPDATES - 1)
+    names = [p.name for p in fit.plans]
+    got, got_loss = {}, {}
+    for idx in fit.steps([x for x, _ in train]):
+        if idx + 1 in lh.SNAPSHOTS:
+            got[idx + 1] = _fit_weights(fit)
+            got_loss[idx + 1] = fit.loss_now.double().cpu().tolist()
+    fit.finish()
+    assert sorted(got) == list(lh.SNAPSHOTS)
+
+    # ---- oracle, same inputs
+    want, want_loss = {}, {}
+
+    def on_update(idx, layers, per_layer):
+        if idx + 1 in lh.SNAPSHOTS:
+            want[idx + 1] = lh.layer_weights(layers)
+            want_loss[idx + 1] = list(per_layer)
+
+    o3 = orc.partial_merge(spec, m1, m2, perm, costs, 0.0)
+    merged_stem = o3.state_dict()[DEGENERATE].clone()
+    orc.train(train, m1, m2, o3, spec, perm, costs, 0.0, lh.N_UPDATES - 1, on_update=on_update)
+
+    trajectory = []
+    for k in lh.SNAPSHOTS:
+        yard = spread["spread"][str(k)]
+        rels = {n: lh.rel(got[k][n], want[k][n]) for n in want[k] if n != DEGENERATE}
+        worst = max(rels, key=rels.get)
+        over = {n: (r, yard[n]) for n, r in rels.items() if r > max(TOL, 3 * yard[n])}
+        loss_rel = max(abs(a - b) / max(abs(b), 1e-30) for a, b, n in zip(got_loss[k], want_loss[k], names) if n != "conv1")
+        trajectory.append({"updates": k, "worst_tensor": worst, "worst_rel_fro": rels[worst],
+                           "oracle_self_spread_of_that_tensor": yard[worst],
+                           "oracle_self_spread_worst": max(v for n, v in yard.items() if n != DEGENERATE),
+                           "tensors_above_1e-4": sum(1 for r in rels.values() if r > TOL),
+                           "tensors_above_gate": len(over), "worst_layer_objective_rel": loss_rel})
+        print("after %3d updates: worst %s %.2e (oracle vs itself there %.2e, anywhere %.2e); %d tensors > 1e-4; "
+              "worst layer objective rel %.2e" % (k, worst, rels[worst], yard[worst], trajectory[-1]["oracle_self_spread_worst"],
+                                                  trajectory[-1]["tensors_above_1e-4"], loss_rel))
+    out_dir = os.path.join(REPO, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "r03_long_horizon_rn50.json"), "w") as f:
+            json.dump({"arch": "resnet50", "batch": lh.BATCH, "trajectory": trajectory}, f, indent=1)
+    # ---- the gate, at the end of the drivers' horizon
+    last = trajectory[-1]
+    assert last["tensors_above_gate"] == 0, (last, over)
+    assert last["worst_layer_objective_rel"] < 1e-2, last
+    gate_stem(got[lh.N_UPDATES][DEGENERATE], merged_stem, [want[lh.N_UPDATES][DEGENERATE]],
+              lambda w: stem_objective(m1, m2, w, spec, perm, costs, 0.0, train[:8], 1000), what="rn50 stem, 401 updates")

@@ -135,6 +135,29 @@ def test_train_adam(tiny_basic, ratio, steps):
         assert rel < 1e-5, (k, float(rel))
 
 
+@pytest.mark.parametrize("fx,ratio,steps", [("tiny_bottleneck", 0.0, 5), ("tiny_bottleneck", 0.5, 20),
+                                            ("tiny_bottleneck", 0.0, 400), ("tiny_bottleneck", 0.5, 400),
+                                            ("tiny_basic", 0.0, 400), ("tiny_basic", 0.5, 400)])
+def test_train_adam_bottleneck_and_long_horizon(fx, ratio, steps, long_train, request):
+    """G6 / G7 on the Bottleneck fixture and the drivers' FULL horizon (401 updates, pleas_merging.py:367-375) on both
+    fixtures: weights trained by the reference (tiny_bottleneck_train.npz) vs the oracle on the regenerated batches."""
+    t = request.getfixturevalue(fx)
+    perm, costs = t.per_key("am_perm"), t.per_key("am_cost")
+    tag = "%s_r%03d" % (t.block, int(ratio * 100))
+    m3 = orc.partial_merge(t.spec, t.m1, t.m2, perm, costs, ratio)
+    if t.block == "bottleneck":
+        want = long_train.state("merged_" + tag)
+        for k, v in m3.state_dict().items():
+            assert torch.equal(v, want[k]), k
+    m3, losses = orc.train(long_train.batches(), t.m1, t.m2, m3, t.spec, perm, costs, ratio, steps, num_classes=10)
+    assert len(losses) == steps + 1
+    want = long_train.state("trained_%s_s%d" % (tag, steps))
+    got = m3.state_dict()
+    for k in want:
+        rel = (got[k].float() - want[k].float()).norm() / (want[k].float().norm() + 1e-12)
+        assert rel < 1e-5, (k, float(rel))
+
+
 # ------------------------------------------------------------------ degenerate stem: the reference against itself
 @pytest.mark.parametrize("ratio,steps", [(0.0, 5), (0.0, 20), (0.5, 5), (0.5, 20)])
 def test_reference_disagrees_with_itself_on_the_stem_only(tiny_basic, ratio, steps):
