@@ -289,7 +289,8 @@ int pleas_wgrad_batch(const pleas_wgrad_layer* layers, int n_layers, void* ws, s
  *   A = sum_batches U^T U   (K x K, K = KH*KW*Cin, index k = (kh*KW + kw)*Cin + ci)
  *   B^T = sum_batches op . U  -> pleas_wgrad_batch(resid := op, flags = ACCUMULATE | KPOS_MAJOR).
  * pleas_normal_eq_accum adds one batch's U^T U of EVERY listed layer into its A (LOWER triangle of
- * 64/128-wide block tiles only; the strict upper part of A is left untouched), one grouped
+ * 64/128-wide block tiles only -- see pleas_normal_eq_finalize for the blocks it leaves to that call; the strict
+ * upper part of A is left untouched), one grouped
  * fp32-MFMA launch, U = im2col(ip) never materialised.  ws / ws_fresh as in pleas_gram_batch.
  */
 typedef struct pleas_neq_layer {
@@ -300,6 +301,15 @@ typedef struct pleas_neq_layer {
 size_t pleas_normal_eq_ws_bytes(const pleas_neq_layer* layers, int n_layers);
 int pleas_normal_eq_accum(const pleas_neq_layer* layers, int n_layers, void* ws, size_t ws_bytes, int ws_fresh,
                           void* stream);
+/* Stride-1 "same" k x k layers: the block of A between two kernel positions depends only on their LAG and on which
+ * border rows / columns the pair can reach, so the 45 lower-triangle blocks of a 3x3 layer hold 29 distinct matrices
+ * (up to transposition).  pleas_normal_eq_accum contracts only those; pleas_normal_eq_finalize copies / transposes
+ * them into the remaining blocks of the lower triangle.  Call it ONCE after the last batch (after the all-reduce of A
+ * in a multi-GPU run) and before the solve; it overwrites (idempotent).  Layers of other geometries are left alone.
+ * pleas_normal_eq_plan_info (host only, no GPU): info[0] = the path's flops per call (K^2 * N*HWo per layer),
+ * info[1] = flops the grid executes, info[2] = work items, info[3] = blocks left to finalize. */
+int pleas_normal_eq_finalize(const pleas_neq_layer* layers, int n_layers, void* stream);
+int pleas_normal_eq_plan_info(const pleas_neq_layer* layers, int n_layers, double* info);
 
 /* Batched SPD solve of the normal equations (blocked Cholesky + forward/back substitution, panel 64,
  * trailing updates on fp32 MFMA tiles).  For every problem p:  X (A_p + lambda*mean(diag A_p) I) = Bt_p,

@@ -55,6 +55,8 @@ SIGNATURES = {
                                              c_float, c_void_p, c_void_p]),
     "pleas_normal_eq_ws_bytes": (c_size_t, [c_void_p, c_int]),
     "pleas_normal_eq_accum": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p]),
+    "pleas_normal_eq_finalize": (c_int, [c_void_p, c_int, c_void_p]),
+    "pleas_normal_eq_plan_info": (c_int, [c_void_p, c_int, c_void_p]),
     "pleas_fwd_batch_ws_bytes": (c_size_t, [c_void_p, c_int]),
     "pleas_fwd_batch": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "pleas_wgrad_batch_ws_bytes": (c_size_t, [c_void_p, c_int]),

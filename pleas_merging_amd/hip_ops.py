@@ -688,6 +688,7 @@ class NormalEqBatch:
         self._arr = None
         self._ws = None
         self._fresh = 1
+        self._seen: dict = {}      # A's address -> (A, geometry): every matrix this object has accumulated into
 
     def add(self, ip: torch.Tensor, A: torch.Tensor, kernel=(1, 1), stride: int = 1, pad: int = 0) -> None:
         if not (ip.is_contiguous() and A.is_contiguous()):
@@ -699,6 +700,30 @@ class NormalEqBatch:
             raise PleasHipError("NormalEqBatch.add: A must be (%d, %d)" % (K, K))
         self._keep.append((ip, A))
         self._geo.append((N, Cin, Hin, Win, kernel[0], kernel[1], stride, pad))
+        self._seen[A.data_ptr()] = (A, self._geo[-1])
+
+    def _layer_array(self, pairs):
+        arr = (_lib.NeqLayer * len(pairs))()
+        for a, (A, geo) in zip(arr, pairs):
+            a.ip, a.A = 0, A.data_ptr()
+            a.N, a.Cin, a.Hin, a.Win, a.KH, a.KW, a.stride, a.pad = geo
+        return arr
+
+    def finalize(self) -> None:
+        """Fill the blocks ``flush`` leaves to the end (``pleas_normal_eq_finalize``: stride-1 k x k layers contract one
+        block per lag class only).  Once, after the last batch -- and after the all-reduce of a multi-GPU run."""
+        pairs = list(self._seen.values())
+        if pairs:
+            check(_lib.lib().pleas_normal_eq_finalize(self._layer_array(pairs), len(pairs), _stream()),
+                  "pleas_normal_eq_finalize")
+
+    def plan_info(self) -> dict:
+        """Host-side facts about the grouped launch of the matrices seen so far (no GPU work)."""
+        pairs = list(self._seen.values())
+        info = (ctypes.c_double * 4)()
+        if pairs:
+            check(_lib.lib().pleas_normal_eq_plan_info(self._layer_array(pairs), len(pairs), info), "pleas_normal_eq_plan_info")
+        return {"flops": info[0], "flops_executed": info[1], "items": int(info[2]), "blocks_to_finalize": int(info[3])}
 
     def flush(self) -> None:
         n = len(self._keep)

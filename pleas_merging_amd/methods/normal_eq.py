@@ -129,6 +129,7 @@ class NormalEqFitter(PleasFitter):
         for s in self.bias_stats.values():
             for t in s:
                 dp_sum_(t, self.world)
+        self.neq.finalize()      # blocks of stride-1 k x k layers that are copies of contracted ones (lag classes)
         info: Dict[str, float] = {}
         jobs, finals = [], []   # (W, rows, free, A_FF, rhs, A_FF backup) per solve; (plan, W, layout) per layer
         for idx, plan in enumerate(self.plans):

@@ -479,10 +479,16 @@ NEQ_CASES = [
     (4, 64, 14, 14, 1, 1, 0),      # direct loader, one 64-tile
     (4, 200, 14, 14, 1, 1, 0),     # 2x2 block tiles, ragged
     (3, 40, 7, 7, 1, 1, 0),        # HW = 49 scalar loads
-    (4, 48, 10, 10, 3, 1, 1),      # 3x3 shifted loader: 9x9 blocks of kernel positions
-    (2, 130, 12, 12, 3, 2, 1),     # stride 2, two tiles per position
+    (4, 48, 10, 10, 3, 1, 1),      # 3x3 stride 1: lag classes (29 of 45 blocks contracted), 64-tile, 16-byte loads
+    (2, 130, 12, 12, 3, 2, 1),     # stride 2 (shifted loader, every block contracted), two tiles per position
     (2, 64, 56, 56, 1, 1, 0),      # long pixel axis -> slabs + reduce
     (16, 96, 1, 1, 1, 1, 0),       # linear-like
+    (2, 256, 14, 14, 3, 1, 1),     # K = 2304 (ResNet-101 layer3 conv2): lag classes, 128-tiles, W = 14 -> shifts 0..3
+    (2, 512, 7, 7, 3, 1, 1),       # K = 4608 (layer4 conv2): lag classes with scalar loads (HW = 49)
+    (3, 200, 6, 10, 3, 1, 1),      # ragged 128-tiles, H != W
+    (2, 32, 56, 56, 3, 1, 1),      # lag classes through slabs + reduce (196 chunks of the pixel axis)
+    (5, 24, 8, 8, 5, 1, 2),        # 5x5 "same": 157 of 325 blocks contracted
+    (2, 20, 2, 3, 3, 1, 1),        # image smaller than the kernel: empty windows
 ]
 
 
@@ -502,6 +508,11 @@ def test_normal_eq_accum_matches_unfold(ops, N, Cin, H, W, k, stride, pad):
         want += U.t() @ U
         batch.add(ip.cuda(), A, (k, k), stride, pad)
         batch.flush()
+    info = batch.plan_info()
+    lag = k > 1 and stride == 1 and 2 * pad == k - 1
+    assert info["blocks_to_finalize"] == ({3: 16, 5: 168}[k] if lag else 0)
+    batch.finalize()                  # copies / transposes of the contracted lag-class blocks (once, after the last batch)
+    batch.finalize()                  # idempotent
     got = A.cpu().double()
     T = 128 if Cin > 64 else 64
     tiles = -(-Cin // T)

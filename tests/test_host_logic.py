@@ -156,6 +156,34 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in handle.pleas_version()
 
 
+def test_normal_eq_plan_contracts_one_block_per_lag_class():
+    """Host side of pleas_normal_eq_accum (no GPU): a stride-1 3x3 layer contracts 29 of the 45 blocks of its lower
+    triangle -- one per lag class up to transposition -- and leaves 16 to pleas_normal_eq_finalize; 1x1 and strided
+    layers contract every block.  ResNet-101's layer3 conv2 (K = 2304) executes 0.66 of the triangle's flops."""
+    from pleas_merging_amd import _lib
+
+    lib = _lib.lib()
+    info = (ctypes.c_double * 4)()
+
+    def plan(N, C, H, W, k, stride, pad):
+        arr = (_lib.NeqLayer * 1)()
+        arr[0].N, arr[0].Cin, arr[0].Hin, arr[0].Win, arr[0].KH, arr[0].KW, arr[0].stride, arr[0].pad = N, C, H, W, k, k, stride, pad
+        assert lib.pleas_normal_eq_plan_info(arr, 1, info) == 0
+        return list(info)
+
+    flops, executed, items, copies = plan(16, 256, 14, 14, 3, 1, 1)
+    assert flops == 2304.0 ** 2 * 16 * 196 and copies == 16 and items == 9 * 3 + 20 * 4
+    assert abs(executed / flops - 107 * 2 * 128 * 128 * 98 * 32 / flops) < 1e-9 and 0.65 < executed / flops < 0.67
+    assert plan(16, 1024, 14, 14, 1, 1, 0)[3] == 0 and plan(16, 128, 56, 56, 3, 2, 1)[3] == 0
+    assert plan(4, 24, 8, 8, 5, 1, 2)[3] == 168
+    os.environ["PLEAS_NEQ_LAG"] = "0"
+    try:
+        assert plan(16, 256, 14, 14, 3, 1, 1)[3] == 0
+    finally:
+        del os.environ["PLEAS_NEQ_LAG"]
+    assert lib.pleas_normal_eq_plan_info(None, 0, info) == -22 and lib.pleas_normal_eq_finalize(None, 0, None) == -22
+
+
 def test_argument_errors_without_gpu():
     """Host-side validation returns error codes before anything touches a device."""
     from pleas_merging_amd import _lib
