@@ -279,15 +279,34 @@ def time_normal_eq(spec, m1, m2, perm, costs, loader, ratio, sources_per_forward
     t2 = time.perf_counter()
     hip_ops.profile_enable(False)
     p = hip_ops.profile_collect()
+    plan = fit.neq.plan_info()
     fit.finish()
     rec = p.get("normal_eq", (0, 0.0, 0.0, 0.0))
     ach = rec[2] / (rec[1] * 1e-3) / 1e12 if rec[1] > 0 else 0.0
+    executed = plan["flops_executed"] * rec[0] / (rec[1] * 1e-3) / 1e12 if rec[1] > 0 else 0.0
+    # systems for the CPU leg (fp64 lstsq on the SAME accumulated A / B): the smallest, the most common and the largest
+    # 3x3 layer; fit.A keeps the accumulated lower triangle (the solve factorises copies)
+    samples, seen = [], set()
+    for idx, pl in enumerate(fit.plans):
+        k = fit.K[idx]
+        if ratio == 0.0 and k in (576, 2304, 4608) and k not in seen and len(pl.w_shape) == 4 and pl.w_shape[2] == 3 \
+                and pl.b is None:
+            seen.add(k)
+            A = fit.A[idx]
+            w = pl.w.detach().reshape(pl.w_shape[0], k)        # kernel-position-major rows, as B^T is
+            samples.append({"name": pl.name, "K": k, "cout": pl.w_shape[0], "ridge": fit.ridge,
+                            "A": (torch.tril(A) + torch.tril(A, -1).t()).cpu(), "Bt": fit.Bt[idx].cpu(), "W_hip": w.cpu()})
     return {"solver": "normal_eq", "batches": len(loader), "accumulate_s": round(t1 - t0, 3), "solve_s": round(t2 - t1, 3),
             "neq_batch_kernel": {"bound": "mfma", "launches": rec[0], "avg_launch_us": round(rec[1] * 1e3 / max(rec[0], 1), 1),
                                  "achieved": round(ach, 1), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                                  "frac": round(ach / FP32_MATRIX_PEAK_TFLOPS, 3),
-                                 "note": "MFMA utilisation of the normal-equations GEMMs; flops counted for the lower "
-                                         "block triangle only (K^2 * N*HWo per layer)"}}
+                                 "algorithmic_flop_per_launch": plan["flops"], "executed_flop_per_launch": plan["flops_executed"],
+                                 "executed_tflops": round(executed, 1), "executed_frac": round(executed / FP32_MATRIX_PEAK_TFLOPS, 3),
+                                 "note": "`achieved` = the path's flops (lower block triangle, K^2 * N*HWo per layer) / time; "
+                                         "`executed_*` = what the grid really multiplies: stride-1 3x3 layers contract one "
+                                         "block per lag class (29 of 45, the rest are copies made once at the end), whole "
+                                         "tiles counted -- that one is the MFMA utilisation"},
+            "_samples": samples, "_K": list(fit.K)}
 
 
 def time_sources_alone(m1, m2, pool, n_updates, per=2, groups=4):
@@ -351,6 +370,60 @@ def cpu_baseline(spec, arch, batch_full, sample_batch, n_match, n_pleas, ratio):
                   "LAPs (%.2fs), merge (%.2fs); batches scaled x%.0f to batch %d, then x%d matching + x%d updates"
                   % (arch, t_match, t_step, sample_batch, len(perm), t_lap, t_merge, scale, batch_full, n_match, n_pleas),
     }
+
+
+def cpu_reference_legs(costs, hip_perm, alt):
+    """north_star's CPU path as worded -- "scipy LAP + torch.linalg.lstsq" -- on this box's host cores:
+    * ``scipy.optimize.linear_sum_assignment(maximize=True)`` (the reference's solver, core/solvers.py:29-31) on the 71 cost
+      matrices the GPU job itself produced, and whether the HIP assignments equal scipy's;
+    * fp64 ``torch.linalg.lstsq`` on the accumulated (A, B) of three 3x3 layers (K = 576 / 2304 / 4608) from the closed-form
+      leg, scaled to all layers by sum K^3, and how far the HIP Cholesky solution is from it."""
+    from scipy.optimize import linear_sum_assignment
+
+    out = {}
+    mats = {k: v.detach().cpu().numpy() for k, v in costs.items()}
+    t0 = time.time()
+    equal = 0
+    for k, a in mats.items():
+        rows, cols = linear_sum_assignment(a, maximize=True)
+        equal += int((torch.from_numpy(cols) == hip_perm[k]).all())
+    out["scipy_lap_s"] = round(time.time() - t0, 3)
+    out["scipy_lap"] = "scipy.optimize.linear_sum_assignment on the job's %d cost matrices (n up to %d), one thread; " \
+                       "HIP assignments identical in %d / %d groups" % (len(mats), max(a.shape[0] for a in mats.values()), equal, len(mats))
+    if alt is not None and alt.get("_samples"):
+        t_sum = k3_sum = 0.0
+        detail = []
+        for smp in alt["_samples"]:
+            A, Bt = smp["A"].double(), smp["Bt"].double()
+            t0 = time.time()
+            A.diagonal().add_(smp["ridge"] * float(A.diagonal().mean()))
+            W = torch.linalg.lstsq(A, Bt.t()).solution.t()          # (Cout, K), kernel-position-major like W_hip
+            dt = time.time() - t0
+            rel = float((smp["W_hip"].double() - W).norm() / W.norm().clamp_min(1e-30))
+            detail.append("%s K=%d: %.2fs, HIP Cholesky vs lstsq rel-fro %.1e" % (smp["name"], smp["K"], dt, rel))
+            t_sum += dt
+            k3_sum += float(smp["K"]) ** 3
+        total = t_sum / k3_sum * sum(float(k) ** 3 for k in alt["_K"])
+        out["lstsq_fp64_s"] = round(total, 2)
+        out["lstsq_fp64"] = "torch.linalg.lstsq (fp64) on the accumulated A, B of %s; scaled by sum K^3 over all %d layers" \
+                            % ("; ".join(detail), len(alt["_K"]))
+    return out
+
+
+def stale_sources(blob):
+    """Files of ``blob["source_sha256"]`` (kernel sources a traffic measurement was taken on, stamped by
+    tools/make_traffic_json.py) whose content is no longer what it was; a file without stamps is stale by definition."""
+    import hashlib
+
+    stamps = blob.get("source_sha256")
+    if not stamps:
+        return ["(no source stamp)"]
+    bad = []
+    for rel, want in stamps.items():
+        path = os.path.join(ROOT, rel)
+        if not os.path.exists(path) or hashlib.sha256(open(path, "rb").read()).hexdigest() != want:
+            bad.append(rel)
+    return bad
 
 
 def gram_flops_per_sample(spec, m1):
@@ -518,7 +591,12 @@ def main():
                            ("conv_wgrad", "wgrad_traffic.json")):
             tpath = os.path.join(ROOT, "profiles", fname)
             if os.path.exists(tpath) and args.arch == "resnet101" and args.batch == 16 and world == 1:
-                roofs[key]["traffic"] = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                blob = json.load(open(tpath))
+                stale = stale_sources(blob)
+                if stale:       # measured on another version of the kernel's source: not this kernel's traffic
+                    roofs[key]["traffic_refused"] = "profiles/%s was measured on another version of %s" % (fname, ", ".join(stale))
+                    continue
+                roofs[key]["traffic"] = blob.get("hbm_bytes_per_launch")
                 roofs[key]["traffic_source"] = "profiles/" + fname
                 if roofs[key]["traffic"] and roofs[key]["avg_launch_us"]:    # north_star: rocprof HBM GB/s of the accumulation
                     roofs[key]["hbm_gbps"] = round(roofs[key]["traffic"] / (roofs[key]["avg_launch_us"] * 1e-6) / 1e9, 1)
@@ -554,12 +632,26 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.emulate_world <= 1:
             out["cpu_baseline"] = cpu_baseline(spec, args.arch, args.batch, args.cpu_sample_batch, n_match, n_pleas,
                                                args.ratio)
+            out["cpu_baseline"]["reference_legs"] = cpu_reference_legs(res["costs"], res["perm"], alt)
         if phases is not None:
             phases = {"spec": round(spec_s, 4), **phases,
                       "note": "one extra job with a device synchronisation at every boundary (phases cannot overlap "
                               "there, so they add up to a little more than `value`); spec is outside `value`"}
             out["phases_s"] = phases
         if alt is not None:
+            alt = {k: v for k, v in alt.items() if not k.startswith("_")}
+            tpath = os.path.join(ROOT, "profiles", "neq_traffic.json")
+            if os.path.exists(tpath) and args.arch == "resnet101" and args.batch == 16:
+                blob = json.load(open(tpath))
+                stale = stale_sources(blob)
+                if stale:
+                    alt["neq_batch_kernel"]["traffic_refused"] = "profiles/neq_traffic.json was measured on another version of %s" % ", ".join(stale)
+                else:
+                    alt["neq_batch_kernel"]["traffic"] = blob.get("hbm_bytes_per_launch")
+                    alt["neq_batch_kernel"]["traffic_source"] = "profiles/neq_traffic.json"
+            if phases is not None:      # the job with the closed form in place of the 401 Adam updates (synchronised phases)
+                alt["job_s_if_closed_form"] = round(phases["matching"] + phases["lap"] + phases["merge_and_setup"]
+                                                    + alt["accumulate_s"] + alt["solve_s"], 3)
             out["alt_solver"] = alt
         if vendor is not None:
             out["vendor"] = vendor

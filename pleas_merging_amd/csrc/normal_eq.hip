@@ -343,6 +343,7 @@ __global__ __launch_bounds__(nThreads) void neq_batch_kernel(const NeqLayerDev* 
                                                              const NeqItemDev* __restrict__ items) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const NeqItemDev it = items[blockIdx.x];
+    if (it.layer < 0) return;   // padding of the XCD-aware item order
     const NeqLayerDev L = layers[it.layer];
     switch (L.variant) {
         case 0: neq_tile<128, 4, false>(L, it, smem); break;
@@ -362,17 +363,18 @@ __global__ __launch_bounds__(nThreads) void neq_batch_kernel(const NeqLayerDev* 
 struct NeqReduceDev {
     int layer, tm, tn, rx, ry, slot, T, pad;
 };
+constexpr int nRedParts = 16;   // workgroups per tile: a tile's T*T elements are independent
 __global__ __launch_bounds__(256) void neq_reduce_kernel(const NeqLayerDev* __restrict__ layers,
                                                          const NeqReduceDev* __restrict__ red) {
-    const NeqReduceDev rd = red[blockIdx.x];
+    const NeqReduceDev rd = red[blockIdx.x / nRedParts];
     const NeqLayerDev L = layers[rd.layer];
-    const int TT = rd.T * rd.T;
-    for (int e = threadIdx.x; e < TT; e += blockDim.x) {
+    const int TT = rd.T * rd.T, part = blockIdx.x % nRedParts, per = TT / nRedParts;
+    for (int e = part * per + threadIdx.x; e < (part + 1) * per; e += blockDim.x) {
         const int li = e / rd.T, lj = e - li * rd.T;
         const int gi = rd.tm * rd.T + li, gj = rd.tn * rd.T + lj;
         if (gi >= L.Cin || gj >= L.Cin) continue;
         float s = 0.f;
-        for (int k = 0; k < L.S; ++k) s += L.slab[((size_t)rd.slot * L.S + k) * TT + e];
+        for (int k = 0; k < L.S; ++k) s += PLEAS_GLOBAL(L.slab)[((size_t)rd.slot * L.S + k) * TT + e];   // fixed order
         L.A[((size_t)rd.rx * L.Cin + gi) * L.K + (size_t)rd.ry * L.Cin + gj] += s;
     }
 }
@@ -486,8 +488,10 @@ static int build_neq_plan(NeqPlan& P, const pleas_neq_layer* ly, int n) {
     P.lds = 0;
     std::vector<size_t> slab_off(n, 0);
     size_t slabs = 0;
-    struct Work { double w; NeqItemDev it; };
-    std::vector<Work> work;
+    // XCD-aware order (common.hpp): every item of one (layer, K range) reads the same pixel range of the SAME input tensor
+    // -- operand rows differ, but a whole range (ResNet-101: 0.9 - 3.2 MB) fits the 4 MB L2 of one XCD -- so they all go
+    // to one XCD.  Measured before (round 3, rocprofv3 FETCH_SIZE x 2): 8.8 GB per batch against 1.0 GB of inputs.
+    std::vector<XcdWork<NeqItemDev>> work;
     for (int i = 0; i < n; ++i) {
         const pleas_neq_layer& l = ly[i];
         if (l.N <= 0 || l.Cin <= 0 || l.Hin <= 0 || l.Win <= 0 || l.KH <= 0 || l.KW <= 0 || l.stride <= 0 || l.pad < 0)
@@ -533,9 +537,10 @@ static int build_neq_plan(NeqPlan& P, const pleas_neq_layer* ly, int n) {
                         if (ry * tiles + tn > rx * tiles + tm) continue;  // lower triangle of block tiles only
                         if (!contracted(rx, ry)) continue;
                         for (int s = 0; s < S; ++s) {
-                            Work w;
+                            XcdWork<NeqItemDev> w;
                             w.it = NeqItemDev{i, tm, tn, rx, ry, s, s * cps, std::min((s + 1) * cps, nchunks), slot, 0};
                             w.w = (double)(w.it.c_end - w.it.c_begin) * T * T;
+                            w.key = (int64_t)i * 4096 + s;
                             work.push_back(w);
                         }
                         if (S > 1) P.red.push_back(NeqReduceDev{i, tm, tn, rx, ry, slot, T, 0});
@@ -548,9 +553,7 @@ static int build_neq_plan(NeqPlan& P, const pleas_neq_layer* ly, int n) {
         P.flops_exec += 2.0 * (double)tiles_done * T * T * (double)nchunks * nBK;
         P.bytes += (double)l.Cin * l.N * l.Hin * l.Win * sizeof(float);
     }
-    std::stable_sort(work.begin(), work.end(), [](const Work& a, const Work& b) { return a.w > b.w; });
-    P.items.reserve(work.size());
-    for (auto& w : work) P.items.push_back(w.it);
+    P.items = xcd_order_items(work, NeqItemDev{-1, 0, 0, 0, 0, 0, 0, 0, 0, 0});
     size_t off = 0;
     P.off_layers = off;
     off = nalign(off + P.layers.size() * sizeof(NeqLayerDev));
@@ -583,7 +586,7 @@ extern "C" int pleas_normal_eq_plan_info(const pleas_neq_layer* layers, int n_la
     if (rc != PLEAS_OK) return rc;
     info[0] = tmp.flops;
     info[1] = tmp.flops_exec;
-    info[2] = (double)tmp.items.size();
+    info[2] = (double)std::count_if(tmp.items.begin(), tmp.items.end(), [](const NeqItemDev& it) { return it.layer >= 0; });
     info[3] = (double)tmp.n_copies;
     return PLEAS_OK;
 }
@@ -675,7 +678,7 @@ extern "C" int pleas_normal_eq_accum(const pleas_neq_layer* layers, int n_layers
                        reinterpret_cast<const NeqItemDev*>(base + P.off_items));
     PLEAS_LAUNCH_CHECK("neq_batch_kernel");
     if (!P.red.empty()) {
-        hipLaunchKernelGGL(neq_reduce_kernel, dim3((unsigned)P.red.size()), dim3(256), 0, stream, dl,
+        hipLaunchKernelGGL(neq_reduce_kernel, dim3((unsigned)P.red.size() * nRedParts), dim3(256), 0, stream, dl,
                            reinterpret_cast<const NeqReduceDev*>(base + P.off_red));
         PLEAS_LAUNCH_CHECK("neq_reduce_kernel");
     }

@@ -26,9 +26,25 @@ from torch import nn
 from ..core.utils import Axis, Permutation, PermutationSpec
 
 
+def _bn_reset_runner(model: nn.Module, fused: bool):
+    """What the pass forwards: on the GPU, an fx copy of ``model`` (same submodules, same buffers) whose train-mode
+    ``BatchNorm2d -> [+ identity] -> [ReLU]`` chains are ``pleas_bn_train_fold`` + ONE ``pleas_bn_act`` pass each -- the
+    statistics kernel moves the module's running statistics and counter as the module would; on the CPU, or when the
+    model cannot be traced, the model itself (vendor modules)."""
+    if fused and next(iter(model.parameters())).is_cuda:
+        from .source_forward import fuse_bn_act
+
+        return fuse_bn_act(model, train_stats=True) or model
+    return model
+
+
 @torch.no_grad()
-def reset_bn_stats(model: nn.Module, dataloader: Iterable, num_batches: int = 101, device=None, shard: bool = True) -> nn.Module:
+def reset_bn_stats(model: nn.Module, dataloader: Iterable, num_batches: int = 101, device=None, shard: bool = True,
+                   fused: bool = True) -> nn.Module:
     """Recompute BatchNorm running statistics of a (merged) model on data.
+
+    ``fused=True`` (default): a model on the GPU is forwarded through the HIP BatchNorm path (``_bn_reset_runner``);
+    ``fused=False`` runs the vendor modules (what the reference's loop does, kept for A/B).
 
     Same procedure as the reference drivers: ``model.train()``, ``reset_running_stats()`` on every
     ``BatchNorm2d``, ``num_batches`` forward passes without gradients (the drivers break after 101),
@@ -49,11 +65,12 @@ def reset_bn_stats(model: nn.Module, dataloader: Iterable, num_batches: int = 10
     bns = [m for m in model.modules() if isinstance(m, nn.BatchNorm2d)]
     for m in bns:
         m.reset_running_stats()
+    runner = _bn_reset_runner(model, fused)        # built AFTER model.train(): the rewrite folds what is in train mode
     if world == 1:
         for i, batch in enumerate(dataloader):
             if i >= num_batches:
                 break
-            model(batch[0].to(device).float())
+            runner(batch[0].to(device).float())
         return model
 
     import torch.distributed as dist
@@ -74,7 +91,7 @@ def reset_bn_stats(model: nn.Module, dataloader: Iterable, num_batches: int = 10
             n = i + 1
             if i % world != rank:
                 continue
-            model(batch[0].to(device).float())
+            runner(batch[0].to(device).float())
             off = 0
             for m, mom, c in zip(tracked, saved, sizes):
                 wgt = (1.0 - mom) ** (-i)                                    # common factor m (1-m)^(n-1) applied at the end

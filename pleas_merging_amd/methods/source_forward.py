@@ -76,11 +76,26 @@ def fold_bn(bn: nn.BatchNorm2d):
     return scale64.float().contiguous(), shift64.float().contiguous()
 
 
-def fuse_bn_act(model: nn.Module, op: Callable = _bn_act) -> Optional[torch.fx.GraphModule]:
+def _train_fold(bn: nn.BatchNorm2d, tag: str) -> Callable:
+    """Graph callable of a train-mode BatchNorm: ``x -> (scale, shift)`` of THIS batch; the module's running statistics
+    and batch counter move on exactly as in the module's own forward (``hip_ops.bn_train_fold``: one streaming pass)."""
+    def fold(x):
+        return hip_ops.bn_train_fold(bn, x)
+
+    fold.__name__ = fold.__qualname__ = "bn_train_fold_%s" % tag
+    return fold
+
+
+def fuse_bn_act(model: nn.Module, op: Callable = _bn_act, train_stats: bool = False) -> Optional[torch.fx.GraphModule]:
     """fx copy of ``model`` (sharing its submodules) with every eval-mode BatchNorm2d chain replaced by
     ``op(x, scale, shift, residual_or_None, relu)`` -- the HIP kernel ``hip_ops.bn_act`` unless a test
     passes its own.  Returns None when the model cannot be traced or holds nothing to fold; the caller
-    then runs the model as it is (vendor kernels)."""
+    then runs the model as it is (vendor kernels).
+
+    ``train_stats=True``: BatchNorm2d modules that normalise with the BATCH's statistics (train mode -- the BN-reset pass
+    after merging, run_domainnet.py:327-341) are folded as well: ``scale, shift = bn_train_fold(bn, x)`` per batch,
+    then the same single ``op`` pass -- x is read twice and written once, where the vendor's train-mode BatchNorm + add +
+    ReLU read or write it seven times."""
     try:
         graph = torch.fx.Tracer().trace(model)      # the graph alone: one code generation at the end, not two
     except Exception:  # noqa: BLE001 -- untraceable control flow: nothing to rewrite
@@ -89,15 +104,17 @@ def fuse_bn_act(model: nn.Module, op: Callable = _bn_act) -> Optional[torch.fx.G
     constants = {}                                    # get_attr targets of the folded scale / shift vectors
     folded = 0
     for node in list(graph.nodes):
-        if node.op != "call_module" or not _foldable(mods.get(node.target)):
+        if node.op != "call_module" or len(node.args) != 1 or node.kwargs:
             continue
-        if len(node.args) != 1 or node.kwargs:
+        bn = mods.get(node.target)
+        per_batch = train_stats and _foldable_train(bn)
+        if not (per_batch or _foldable(bn)):
             continue
-        bn = mods[node.target]
-        scale, shift = fold_bn(bn)
         tag = node.name
-        constants["_pleas_scale_%s" % tag] = scale
-        constants["_pleas_shift_%s" % tag] = shift
+        if not per_batch:
+            scale, shift = fold_bn(bn)
+            constants["_pleas_scale_%s" % tag] = scale
+            constants["_pleas_shift_%s" % tag] = shift
 
         chain, res, relu = [node], None, False
         users = list(node.users)
@@ -114,8 +131,13 @@ def fuse_bn_act(model: nn.Module, op: Callable = _bn_act) -> Optional[torch.fx.G
         last = chain[-1]
         with graph.inserting_before(last):
             # explicit base names: fx would otherwise derive them from the targets character by character
-            s = graph.create_node("get_attr", "_pleas_scale_%s" % tag, (), {}, name="bn_scale")
-            t = graph.create_node("get_attr", "_pleas_shift_%s" % tag, (), {}, name="bn_shift")
+            if per_batch:
+                stats = graph.create_node("call_function", _train_fold(bn, tag), (node.args[0],), {}, name="bn_stats")
+                s = graph.create_node("call_function", operator.getitem, (stats, 0), {}, name="bn_scale")
+                t = graph.create_node("call_function", operator.getitem, (stats, 1), {}, name="bn_shift")
+            else:
+                s = graph.create_node("get_attr", "_pleas_scale_%s" % tag, (), {}, name="bn_scale")
+                t = graph.create_node("get_attr", "_pleas_shift_%s" % tag, (), {}, name="bn_shift")
             fused = graph.create_node("call_function", op, (node.args[0], s, t, res, relu), {}, name="bn_act")
         last.replace_all_uses_with(fused)
         for dead in reversed(chain):

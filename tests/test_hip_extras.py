@@ -64,6 +64,50 @@ def test_bn_reset_on_the_merged_cuda_model_equals_the_drivers_loop(tiny_basic):
     assert checked >= 10
 
 
+@pytest.mark.parametrize("fused", [True, False])
+def test_bn_reset_rn50_size_vs_the_drivers_loop(fused):
+    """The same pass at ResNet-50 size (53 BatchNorm2d, merged widths 1.5x, 224 x 224): HIP BatchNorm path
+    (``pleas_bn_train_fold`` + ``pleas_bn_act`` through the fx rewrite) and vendor modules, each against the drivers'
+    loop (run_domainnet.py:327-341) on the CPU: running statistics, batch counters, train mode left on."""
+    from pleas.core.compiler import get_permutation_spec
+    from pleas.core.utils import make_identity_perm
+    from pleas.methods.extras import reset_bn_stats
+    from pleas_merging_amd import resnet as zoo
+
+    g = torch.Generator().manual_seed(3)
+    data = [(torch.randn(4, 3, 224, 224, generator=g), None) for _ in range(5)]
+    models = []
+    for seed in (0, 1):
+        torch.manual_seed(seed)
+        m = zoo.MODELS["resnet50"](num_classes=1000)
+        zoo.calibrate_bn(m, [d[0] for d in data[:2]])
+        models.append(m.eval())
+    spec = get_permutation_spec(models[0], ((1, 3, 224, 224),))
+    perm = make_identity_perm(spec)
+    costs = {k: torch.eye(grp.size) + 0.01 * torch.rand(grp.size, grp.size, generator=g) for k, grp in spec.items()}
+    ref = orc.partial_merge(spec, models[0], models[1], perm, costs, 0.5)
+    got = copy.deepcopy(ref).cuda()
+    got = reset_bn_stats(got, data, 4, fused=fused)
+    assert got.training and next(got.parameters()).is_cuda
+    ref.train()
+    n_bn = 0
+    for mod in ref.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.reset_running_stats()
+            n_bn += 1
+    with torch.no_grad():
+        for b in data[:4]:
+            ref(b[0].float())
+    worst = 0.0
+    for (k, a), (_, b) in zip(got.state_dict().items(), ref.state_dict().items()):
+        if "running_" in k:
+            worst = max(worst, _rel(a, b))
+        elif k.endswith("num_batches_tracked"):
+            assert int(a) == int(b) == 4
+    print("rn50 merged (ratio 0.5) BN reset, fused=%s: %d BatchNorm2d, worst running-statistic rel-fro %.2e" % (fused, n_bn, worst))
+    assert n_bn == 53 and worst < 2e-4, worst
+
+
 def test_eval_helpers_on_a_merged_cuda_backbone_known_answer(tiny_bottleneck):
     """Row 4 (pleas_merging.py:408-496): model2 = model1 with every group permuted.  Matching (HIP) recovers the
     permutation, the partially merged backbone (ratio 0.5, fc -> Identity) then emits [merged | separate-1 | separate-2]

@@ -5,7 +5,9 @@ far as ONE MI355X allows.
     on one GPU): batch-sharded matching + one all-reduce of the 41 MB cost arena, sample-sharded PLeaS updates with the
     default ``2 * world`` updates per source forward (one full group of 4 and the left-over update), look-ahead, one
     all-reduce of the gradient arena per update -- with and without ``shard_optimizer`` -- against the single-process HIP
-    job on the same inputs: identical assignments, weights to 2e-5, both ranks bit-identical.
+    job on the same inputs: identical assignments, weights to 2e-5 (or 3x what the single-process job differs from
+    ITSELF by when run twice: the vendor convolutions are not run-to-run deterministic at 101 layers), both ranks
+    bit-identical.
 (b) The same job in a ONE-rank ``nccl`` process group with PLEAS_FORCE_COLLECTIVES=1: ``all_reduce`` of the cost and
     gradient arenas, ``reduce_scatter_tensor`` / ``all_gather_into_tensor`` of the sharded optimiser really go through
     RCCL (counted), leave the result bit-identical to the job without a process group, and are timed on the job's own
@@ -105,6 +107,8 @@ def _time_collectives(costs, fit, reps=5):
     keep_a, keep_g = arena.clone(), grads.clone()
     out["all_reduce_cost_arena_s"] = timed(lambda: dist.all_reduce(arena))
     out["all_reduce_gradient_arena_s"] = timed(lambda: dist.all_reduce(grads))
+    if dist.get_world_size() == 1:      # a sum over one rank must hand the buffers back bit for bit
+        out["all_reduce_is_identity"] = bool(torch.equal(arena, keep_a) and torch.equal(grads, keep_g))
     if dist.get_backend() == "nccl":
         out["reduce_scatter_gradient_arena_s"] = timed(lambda: dist.reduce_scatter_tensor(mine, flat))
         out["all_gather_parameter_arena_s"] = timed(lambda: dist.all_gather_into_tensor(flat, mine))
@@ -166,27 +170,47 @@ def single(tmp_path_factory):
     _make_inputs(path)
     want = _job(path, data_parallel=False)
     assert want["info"]["world"] == 1
+    # The yardstick: the SAME single-process job once more.  The vendor's convolution kernels need not be run-to-run
+    # deterministic (split-K GEMMs with atomics at these small batch sizes), and 101 layers amplify that; what two runs of
+    # one program differ by is what two partitionings of it can be held to.
+    again = _job(path, data_parallel=False)
+    spread = {"costs": {k: _rel(again["costs"][k], v) for k, v in want["costs"].items()},
+              "sd": {k: _rel(again["sd"][k], v) for k, v in want["sd"].items() if v.dtype.is_floating_point},
+              "perm_equal": all(torch.equal(again["perm"][k], v) for k, v in want["perm"].items())}
+    print("single-process job twice: worst cost rel-fro %.2e, worst weight rel-fro %.2e, assignments equal: %s"
+          % (max(spread["costs"].values()), max(v for k, v in spread["sd"].items() if k != "conv1.weight"), spread["perm_equal"]))
+    want["spread"] = spread
     return tmp, path, want
 
 
+COST_TOL, WEIGHT_TOL = 1e-5, 2e-5      # floors; a tensor may differ by 3x what two runs of the single-process job differ by
+
+
 def _compare(res, want, exact):
-    worst = 0.0
+    """``exact``: the run must reproduce ``want`` as well as ``want`` reproduces itself (bit for bit when the
+    single-process job is deterministic).  Otherwise rel-fro per tensor within max(floor, 3 x the job's own spread)."""
+    spread = want["spread"]
+    deterministic = spread["perm_equal"] and max(spread["costs"].values()) == 0.0 and max(spread["sd"].values()) == 0.0
+    worst = {"cost": 0.0, "weight": 0.0}
     for k, v in want["perm"].items():
-        assert torch.equal(res["perm"][k], v), k
-        if exact:
+        if spread["perm_equal"]:
+            assert torch.equal(res["perm"][k], v), k
+        r = _rel(res["costs"][k], want["costs"][k])
+        worst["cost"] = max(worst["cost"], r)
+        if exact and deterministic:
             assert torch.equal(res["costs"][k], want["costs"][k]), k
         else:
-            assert torch.allclose(res["costs"][k], want["costs"][k], rtol=1e-5, atol=1e-5), k
+            assert r <= max(COST_TOL, 3 * spread["costs"][k]), (k, r, spread["costs"][k])
     for k, v in want["sd"].items():
         if not v.dtype.is_floating_point:
             continue
-        if exact:
+        if exact and deterministic:
             assert torch.equal(res["sd"][k], v), k
-        elif k != "conv1.weight":      # degenerate stem: gated below
+        elif k != "conv1.weight":      # degenerate stem: gated by the caller
             r = _rel(res["sd"][k], v)
-            worst = max(worst, r)
-            assert r < 2e-5, (k, r)
-    if exact:
+            worst["weight"] = max(worst["weight"], r)
+            assert r <= max(WEIGHT_TOL, 3 * spread["sd"][k]), (k, r, spread["sd"][k])
+    if exact and deterministic:
         assert torch.equal(res["loss"], want["loss"])
     else:
         assert torch.allclose(res["loss"], want["loss"], rtol=1e-4, atol=1e-7)
@@ -201,7 +225,8 @@ def test_rn101_two_rank_job_equals_single_process_job(single, shard):
         assert res["info"]["world"] == 2 and res["info"]["shard"] == shard
         assert res["info"]["fast_updates"] >= 2           # the group's later updates relaunch patched tables
         worst = _compare(res, want, exact=False)
-        print("rank %d shard %s: worst non-stem rel-fro vs single process %.2e; calls %s" % (rank, shard, worst, res["calls"]))
+        print("rank %d shard %s: worst rel-fro vs the single-process job: costs %.2e, weights (non-stem) %.2e; calls %s"
+              % (rank, shard, worst["cost"], worst["weight"], res["calls"]))
         assert res["calls"].get("all_reduce", 0) >= 1 + N_UPDATES
     for k, v in results[0]["sd"].items():
         assert torch.equal(v, results[1]["sd"][k]), k       # every rank applied the same update
@@ -224,8 +249,10 @@ def test_rn101_one_rank_rccl_group_with_forced_collectives(single, shard):
         assert calls.get("reduce_scatter_tensor", 0) >= N_UPDATES and calls.get("all_gather_into_tensor", 0) >= N_UPDATES
     else:          # cost arena + one all-reduce of gradients-and-losses per update
         assert calls.get("all_reduce", 0) >= 1 + N_UPDATES and "reduce_scatter_tensor" not in calls
-    _compare(res, want, exact=True)          # a sum over one rank is the identity: bit for bit the plain job
+    worst = _compare(res, want, exact=True)  # a sum over one rank is the identity: the plain job, as well as that repeats itself
+    print("one-rank RCCL job vs the plain job: costs %.2e, weights %.2e" % (worst["cost"], worst["weight"]))
     t = res["timings"]
+    assert t["all_reduce_is_identity"]       # ... and, checked on the arenas themselves, bit for bit
     assert t["backend"] == "nccl" and t["cost_arena_bytes"] > 4e7 and t["gradient_arena_bytes"] > 1e8
     for k, v in t.items():
         if k.endswith("_s"):
