@@ -3,6 +3,7 @@ import ctypes
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -182,6 +183,27 @@ def test_normal_eq_plan_contracts_one_block_per_lag_class():
     finally:
         del os.environ["PLEAS_NEQ_LAG"]
     assert lib.pleas_normal_eq_plan_info(None, 0, info) == -22 and lib.pleas_normal_eq_finalize(None, 0, None) == -22
+
+
+def test_host_code_under_sanitizers():
+    """SURVEY.md section 5 (sanitizers): the host halves of csrc/*.hip -- plan builders, XCD item ordering, lane dealing,
+    lag classes, the host LAP, argument checks -- compiled with -fsanitize=address,undefined (device code as always) and
+    driven without a GPU through the `*_ws_bytes` / `*_plan_info` / `pleas_lsap_host` entry points on the ResNet-18 / 50 /
+    101 layer lists and on degenerate sizes (tests/sanitize_driver.py, a torch-free subprocess with the ASan runtime
+    preloaded).  Any report aborts the driver."""
+    import subprocess
+
+    from pleas_merging_amd import build
+
+    lib = build.build_sanitized()
+    syms = subprocess.check_output(["nm", "-D", lib], text=True)
+    assert "__asan_report" in syms and "__ubsan_handle" in syms          # the host code really is instrumented
+    env = dict(os.environ, LD_PRELOAD=build.asan_runtime(), ASAN_OPTIONS="detect_leaks=0:halt_on_error=1",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "tests", "sanitize_driver.py"), lib], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "SANITIZE_OK" in out.stdout, (out.stdout[-2000:], out.stderr[-4000:])
+    assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr[-4000:]
 
 
 def test_argument_errors_without_gpu():
