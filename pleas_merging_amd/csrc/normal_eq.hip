@@ -488,9 +488,11 @@ static int build_neq_plan(NeqPlan& P, const pleas_neq_layer* ly, int n) {
     P.lds = 0;
     std::vector<size_t> slab_off(n, 0);
     size_t slabs = 0;
-    // XCD-aware order (common.hpp): every item of one (layer, K range) reads the same pixel range of the SAME input tensor
-    // -- operand rows differ, but a whole range (ResNet-101: 0.9 - 3.2 MB) fits the 4 MB L2 of one XCD -- so they all go
-    // to one XCD.  Measured before (round 3, rocprofv3 FETCH_SIZE x 2): 8.8 GB per batch against 1.0 GB of inputs.
+    // XCD-aware order (common.hpp), OFF by default for this kernel (PLEAS_XCD_ORDER=1 turns it on): every item of one
+    // (layer, K range) reads the same pixel range of the SAME input tensor (ResNet-101: 0.9 - 3.2 MB, fits the 4 MB L2 of
+    // one XCD), so they can all go to one XCD.  Measured (round 3, tools/r03_run2.sh): FETCH_SIZE x 2 falls from 8.8 GB to
+    // 3.1 GB per batch (1.0 GB of inputs), the launch takes 5.89 instead of 5.72 ms -- and the six strided layers alone 1.79
+    // instead of 0.83 ms, because a layer's ~200 items no longer spread over the eight XCDs.  MFMA-issue bound, not L2 bound.
     std::vector<XcdWork<NeqItemDev>> work;
     for (int i = 0; i < n; ++i) {
         const pleas_neq_layer& l = ly[i];
@@ -553,7 +555,7 @@ static int build_neq_plan(NeqPlan& P, const pleas_neq_layer* ly, int n) {
         P.flops_exec += 2.0 * (double)tiles_done * T * T * (double)nchunks * nBK;
         P.bytes += (double)l.Cin * l.N * l.Hin * l.Win * sizeof(float);
     }
-    P.items = xcd_order_items(work, NeqItemDev{-1, 0, 0, 0, 0, 0, 0, 0, 0, 0});
+    P.items = xcd_order_items(work, NeqItemDev{-1, 0, 0, 0, 0, 0, 0, 0, 0, 0}, /*by_default=*/false);
     size_t off = 0;
     P.off_layers = off;
     off = nalign(off + P.layers.size() * sizeof(NeqLayerDev));

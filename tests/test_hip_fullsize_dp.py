@@ -53,7 +53,7 @@ def _make_inputs(path):
     torch.save({"sd": sds, "match": match, "train": train}, path)
 
 
-def _job(path, data_parallel, shard=False, time_collectives=False):
+def _job(path, data_parallel, shard=False, time_collectives=False, calls=None):
     from pleas.core.compiler import get_permutation_spec
     from pleas.methods.activation_matching import activation_matching
     from pleas.methods.partial_matching import partial_merge
@@ -75,12 +75,14 @@ def _job(path, data_parallel, shard=False, time_collectives=False):
     fit = PleasFitter(m1, m2, m3, spec, perm, costs, RATIO, N_UPDATES - 1, data_parallel=data_parallel, shard_optimizer=shard)
     assert list(fit.steps(blob["train"])) == list(range(N_UPDATES))       # default sources_per_forward: 2 * world
     loss = fit.loss_sum.clone()
+    job_calls = dict(calls) if calls is not None else None      # the job's own collectives, before any are timed below
     timings = _time_collectives(costs, fit) if time_collectives else None
     info = {"world": fit.world, "shard": fit.shard_optimizer, "fast_updates": fit.fast_updates}
     sd = {k: v.cpu() for k, v in fit.finish().state_dict().items()}
     torch.cuda.synchronize()
     return {"perm": {str(k): v.cpu() for k, v in perm.items()}, "costs": {str(k): v.cpu() for k, v in costs.items()},
-            "sd": sd, "loss": loss.cpu(), "info": info, "timings": timings, "merged_stem": merged_stem}
+            "sd": sd, "loss": loss.cpu(), "info": info, "timings": timings, "merged_stem": merged_stem,
+            "calls": job_calls}
 
 
 def _time_collectives(costs, fit, reps=5):
@@ -138,8 +140,7 @@ def _worker(rank, world, port, path, out_path, backend, shard, force):
             return _fn(*a, **kw)
         setattr(dist, name, counted)
     try:
-        res = _job(path, data_parallel=True, shard=shard, time_collectives=force)
-        res["calls"] = dict(calls)
+        res = _job(path, data_parallel=True, shard=shard, time_collectives=force, calls=calls)
         torch.save(res, out_path % rank)
     finally:
         dist.barrier()
