@@ -328,6 +328,30 @@ def time_sources_alone(m1, m2, pool, n_updates, per=2, groups=4):
     return per_update * n_updates, per_update
 
 
+def time_bn_reset(m3, pool, n_batches=101):
+    """The step right after ``train`` in every reference driver (run_domainnet.py:327-341): 101 train-mode forwards of the
+    merged model that recompute its BatchNorm statistics.  HIP BatchNorm path (``pleas_bn_train_fold`` + ``pleas_bn_act``
+    through the fx rewrite) and the vendor modules, same batches, one untimed pass each first."""
+    import copy
+
+    from pleas_merging_amd.methods.extras import reset_bn_stats
+
+    loader = pool.loader(0, n_batches)
+    out = {}
+    for name, fused in (("hip_s", True), ("vendor_modules_s", False)):
+        model = copy.deepcopy(m3)
+        reset_bn_stats(model, loader[:3], 3, fused=fused)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reset_bn_stats(model, loader, n_batches, fused=fused)
+        torch.cuda.synchronize()
+        out[name] = round(time.perf_counter() - t0, 3)
+        del model
+    out["note"] = ("BN-statistics reset of the merged model, %d batches of %d (not in `value`: the reference's `train` ends "
+                   "before it); hip = statistics folded per batch on the device + one bn_act pass per chain" % (n_batches, pool.items[0].shape[0]))
+    return out
+
+
 def cpu_baseline(spec, arch, batch_full, sample_batch, n_match, n_pleas, ratio):
     """Oracle (CPU restatement of the reference path) on this box's host cores, bounded sample:
     3 matching batches + 3 PLeaS updates at a reduced batch size (~10-15 s of CPU work), all LAPs, the merge; extrapolated linearly
@@ -540,6 +564,7 @@ def main():
         elapsed = float(t.item())
     value = elapsed / max(1, args.steps)
     prof = hip_ops.profile_collect() if rank == 0 else {}  # the timed jobs' kernels, before anything else is timed
+    fwd_lanes = hip_ops.fwd_plan_lanes() if rank == 0 else None   # forms of the grouped forward: measured ms, lane
     checks = check_result(spec, res, full) if rank == 0 else None
 
     # ---- untimed extras (every rank takes part in the phases job: it contains collectives)
@@ -548,12 +573,14 @@ def main():
         ph = Phases(on=True, verbose=args.phase_log)
         job(ph)
         phases = dict(ph.out)
-    alt = vendor = None
+    alt = vendor = bn_reset = None
     if world == 1 and args.emulate_world <= 1:
         if not args.no_alt_solver:
             alt = time_normal_eq(spec, m1, m2, res["perm"], res["costs"], pool.loader(0, n_pleas), args.ratio,
                                  cfg["sources_per_forward"])
             log("closed form: accumulate %.2fs, solve %.2fs" % (alt["accumulate_s"], alt["solve_s"]))
+        bn_reset = time_bn_reset(res["m3"], pool)
+        log("BN reset of the merged model: HIP path %.2fs, vendor modules %.2fs" % (bn_reset["hip_s"], bn_reset["vendor_modules_s"]))
         src_s, src_per = time_sources_alone(m1, m2, pool, n_pleas, per=cfg["sources_per_forward"] or 2)
         vendor = {"source_forwards_alone_s_per_job": round(src_s, 3), "ms_per_update": round(src_per * 1e3, 3),
                   "share_of_value": round(src_s / value, 3),
@@ -655,8 +682,11 @@ def main():
             out["alt_solver"] = alt
         if vendor is not None:
             out["vendor"] = vendor
+        if bn_reset is not None:
+            out["bn_reset"] = bn_reset
         out["checks"] = checks
         out["kernels_ms"] = {k: {"launches": v[0], "total_ms": round(v[1], 2)} for k, v in sorted(prof.items())}
+        out["fwd_forms"] = fwd_lanes
         print(json.dumps(out), flush=True)
         if not checks["ok"]:
             log("RESULT CHECK FAILED: %r" % (checks,))

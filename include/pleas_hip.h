@@ -261,6 +261,10 @@ typedef struct pleas_fwd_layer {
  * the taps of a channel block re-read the same input rows back to back. */
 #define PLEAS_FWD_KPOS_MAJOR 1
 size_t pleas_fwd_batch_ws_bytes(const pleas_fwd_layer* layers, int n_layers);
+/* Diagnostics of the latest pleas_fwd_batch plan: per tile form (10 entries each) the duration measured on its lane by
+ * the plan's calibration launch [ms] (0 before it), the lane it runs on (0 = the caller's stream) and its work items.
+ * Returns 0 = lanes still dealt from static weights, 1 = calibration launch in flight, 2 = lanes dealt from measurements. */
+int pleas_fwd_plan_lanes(double* form_ms, int* form_lane, int* form_items);
 int pleas_fwd_batch(const pleas_fwd_layer* layers, int n_layers, float* loss, void* ws, size_t ws_bytes, int ws_fresh,
                     void* stream);
 

@@ -133,12 +133,17 @@ __device__ __forceinline__ void fwd_epilogue(const FwdLayerDev& L, const FwdItem
     // flight meanwhile) -> second batch issued -> first consumed -> second consumed.
     if (vec_ok) {
         f32x4 ta[NB][GB], tb[NB][GB];
+        // per-thread bases: the (sample, pixel group) part of every address is the same for all of the thread's channels, so
+        // a gather / store address is one 32 x 32 -> 64-bit multiply-add on top of it
+        const unsigned long long hw = L.HWo;
+        const unsigned long long gbase = (unsigned long long)gn * L.Csrc * hw + gp;
+        const unsigned long long rbase = ((unsigned long long)gn * L.Cout + i0 + (tid >> 5)) * hw + gp;
         auto gather = [&](const int bt) {
 #pragma unroll
             for (int u = 0; u < GB; ++u) {
                 const int j = bt * GB + u;
-                const size_t oa = (((size_t)gn * L.Csrc + max(m1[j], 0)) * L.HWo + gp) & (size_t)(-(long long)(gin && m1[j] >= 0));
-                const size_t ob = (((size_t)gn * L.Csrc + max(m2[j], 0)) * L.HWo + gp) & (size_t)(-(long long)(gin && m2[j] >= 0));
+                const size_t oa = (gin && m1[j] >= 0) ? (size_t)(gbase + (unsigned)m1[j] * hw) : (size_t)0;
+                const size_t ob = (gin && m2[j] >= 0) ? (size_t)(gbase + (unsigned)m2[j] * hw) : (size_t)0;
                 if constexpr ((PLEAS_FWD_ABLATE & 1) != 0) {
                     ta[bt][u] = f32x4{(float)(oa & 3), 0.f, 0.f, 0.f};
                     tb[bt][u] = f32x4{(float)(ob & 3), 0.f, 0.f, 0.f};
@@ -154,17 +159,21 @@ __device__ __forceinline__ void fwd_epilogue(const FwdLayerDev& L, const FwdItem
                 const int j = bt * GB + u;
                 const int lco = (tid >> 5) + 8 * j, co = i0 + lco;
                 const bool live = gin && co < L.Cout;
+                // target = (o1 * [present] + o2 * [present]) * coef, coef in {0.5, 1}: folding coef into the two factors is
+                // exact (power of two), so  fma(o2, cb, o1 * ca)  rounds once, like the sum it replaces
                 const float coef = co < L.n_merged ? 0.5f : 1.0f;
-                const float fa = m1[j] >= 0 ? 1.f : 0.f, fb = m2[j] >= 0 ? 1.f : 0.f;
+                const float ca = m1[j] >= 0 ? coef : 0.f, cb = m2[j] >= 0 ? coef : 0.f;
                 const f32x4 o = *reinterpret_cast<const f32x4*>(Ct + lco * EL + pg);
                 f32x4 d;
+                float s4 = 0.f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float dd = (o[e] + bias_v[j]) - (ta[bt][u][e] * fa + tb[bt][u][e] * fb) * coef;
-                    sq = live ? fmaf(dd, dd, sq) : sq;
+                    const float dd = (o[e] + bias_v[j]) - fmaf(tb[bt][u][e], cb, ta[bt][u][e] * ca);
+                    s4 = fmaf(dd, dd, s4);
                     d[e] = L.dscale * dd;
                 }
-                if (live) *(__attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL_W(L.resid) + ((size_t)gn * L.Cout + co) * L.HWo + gp) = d;
+                sq += live ? s4 : 0.f;
+                if (live) *(__attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL_W(L.resid) + (size_t)(rbase + (unsigned)(8 * j) * hw)) = d;
             }
         };
         gather(0);
@@ -693,7 +702,8 @@ constexpr int fLanes = 3;          // side streams (+ the caller's stream = four
 struct FwdSideStreams {
     hipStream_t streams[fLanes];
     hipEvent_t forked, joined[fLanes];
-    bool ok = false;
+    hipEvent_t t0[10], t1[10];     // per form: around its kernel, on its lane (one calibration launch per plan)
+    bool ok = false, timed = false;
 };
 static FwdSideStreams& fwd_side_streams() {
     // one set per device (streams belong to the device that was current when they were created)
@@ -713,6 +723,10 @@ static FwdSideStreams& fwd_side_streams() {
             ok = hipStreamCreateWithFlags(&s.streams[i], hipStreamNonBlocking) == hipSuccess &&
                  hipEventCreateWithFlags(&s.joined[i], hipEventDisableTiming) == hipSuccess;
         s.ok = ok;
+        bool timed = ok;
+        for (int f = 0; timed && f < 10; ++f)
+            timed = hipEventCreate(&s.t0[f]) == hipSuccess && hipEventCreate(&s.t1[f]) == hipSuccess;
+        s.timed = timed;
     }
     return s;
 }
@@ -775,8 +789,39 @@ struct FwdPlan {
     double flops = 0, bytes = 0;
     int n_parts = 0;
     bool uploaded = false;
+    // lanes from MEASURED durations: launch kCalibAt of a plan brackets every form's kernel with events on its lane; a
+    // later launch that finds them complete deals the forms again, longest measured duration first
+    int launches = 0, calib = 0;       // calib: 0 not measured yet, 1 events recorded, 2 lanes dealt from measurements
+    double form_ms[fForms] = {0};
 };
 static FwdPlan g_fplan;
+constexpr int kCalibAt = 3;
+// measured durations per layer-list geometry (the plan key without its workspace address): a new fitter on the same
+// layers -- every job of a bench run -- starts from the lanes the previous one measured
+static std::vector<std::pair<std::vector<int64_t>, std::vector<double>>> g_fcalib;
+static std::vector<int64_t> fwd_geometry_key(const std::vector<int64_t>& key) {
+    std::vector<int64_t> g(key);
+    if (g.size() > 1) g[1] = 0;      // key[1] is the workspace address
+    return g;
+}
+
+// longest-processing-time first: the form with the most work keeps the caller's stream (lane 0) and is launched first,
+// every other form goes to the lane that is least loaded so far
+static void fwd_deal_lanes(FwdPlan& P, const double* work) {
+    for (int f = 0; f < fForms; ++f) P.form_order[f] = f;
+    std::stable_sort(P.form_order, P.form_order + fForms, [&](int a, int b) { return work[a] > work[b]; });
+    double load[fLanes + 1] = {0};
+    for (int o = 0; o < fForms; ++o) {
+        const int f = P.form_order[o];
+        if (P.form_count[f] == 0) continue;
+        int best = 0;
+        for (int l = 1; l <= fLanes; ++l)
+            if (load[l] < load[best]) best = l;
+        if (o == 0) best = 0;
+        P.form_lane[f] = best;
+        load[best] += work[f];
+    }
+}
 static std::mutex g_fplan_mu;
 static size_t falign(size_t v) { return (v + 255) / 256 * 256; }
 
@@ -889,22 +934,11 @@ static int build_fwd_plan(FwdPlan& P, const pleas_fwd_layer* ly, int n) {
     // Expected duration of a form relative to its MFMA work (measured on the ResNet-101 list, each form alone): the
     // general tile (stride-2 layers: few, long items; stem: scalar weight loads) runs at ~0.4x the flat forms' rate, the
     // scalar-pixel 1x1 form (7x7 images) at ~0.5x.
+    // These static weights deal the FIRST launches of a plan only; launch kCalibAt measures every form on its lane and the
+    // lanes are dealt again from those durations (pleas_fwd_batch).
     for (int f = 0; f < fForms; ++f) form_work[f] *= f < 4 ? 2.5 : ((f == 5 || f == 8) ? 2.0 : 1.0);
-    std::stable_sort(P.form_order, P.form_order + fForms, [&](int a, int b) { return form_work[a] > form_work[b]; });
-    {   // lanes (longest-processing-time first): the largest form keeps the caller's stream (lane 0), every other form goes
-        // to the lane that is least loaded so far
-        double load[fLanes + 1] = {0};
-        for (int o = 0; o < fForms; ++o) {
-            const int f = P.form_order[o];
-            if (P.form_count[f] == 0) continue;
-            int best = 0;
-            for (int l = 1; l <= fLanes; ++l)
-                if (load[l] < load[best]) best = l;
-            if (o == 0) best = 0;
-            P.form_lane[f] = best;
-            load[best] += form_work[f];
-        }
-    }
+    fwd_deal_lanes(P, form_work);
+    P.launches = P.calib = 0;
     P.n_parts = parts;
     size_t off = 0;
     P.off_layers = off;
@@ -929,6 +963,17 @@ extern "C" int pleas_fwd_debug_read(long long* out, int n_items) {
                ? 0 : 1;
 }
 #endif
+
+extern "C" int pleas_fwd_plan_lanes(double* form_ms, int* form_lane, int* form_items) {
+    if (!form_ms || !form_lane || !form_items) return bad_arg("fwd_plan_lanes: null pointer");
+    std::lock_guard<std::mutex> lk(g_fplan_mu);
+    for (int f = 0; f < fForms; ++f) {
+        form_ms[f] = g_fplan.form_ms[f];
+        form_lane[f] = g_fplan.form_lane[f];
+        form_items[f] = g_fplan.form_count[f];
+    }
+    return g_fplan.calib;
+}
 
 extern "C" size_t pleas_fwd_batch_ws_bytes(const pleas_fwd_layer* layers, int n_layers) {
     if (!layers || n_layers <= 0) return 0;
@@ -966,6 +1011,13 @@ extern "C" int pleas_fwd_batch(const pleas_fwd_layer* layers, int n_layers, floa
         const int rc = build_fwd_plan(P, layers, n_layers);
         if (rc != PLEAS_OK) return rc;
         P.key.swap(key);
+        const std::vector<int64_t> geo = fwd_geometry_key(P.key);
+        for (const auto& kv : g_fcalib)
+            if (kv.first == geo) {
+                std::copy(kv.second.begin(), kv.second.end(), P.form_ms);
+                fwd_deal_lanes(P, P.form_ms);
+                P.calib = 2;
+            }
     }
     if (ws_fresh) P.uploaded = false;
     if (!ws || ws_bytes < P.total) {
@@ -1012,6 +1064,25 @@ extern "C" int pleas_fwd_batch(const pleas_fwd_layer* layers, int n_layers, floa
         int active = 0;
         for (int f = 0; f < fForms; ++f) active += P.form_count[f] > 0;
         const bool fork = !serial && active > 1 && side.ok;
+        static const bool calibrate = !(std::getenv("PLEAS_FWD_CALIBRATE") && std::atoi(std::getenv("PLEAS_FWD_CALIBRATE")) == 0);
+        ++P.launches;
+        if (P.calib == 1) {          // the calibration launch's events: all complete?  then deal the lanes from them
+            bool ready = true;
+            for (int f = 0; ready && f < fForms; ++f)
+                if (P.form_count[f] > 0) ready = hipEventQuery(side.t1[f]) == hipSuccess;
+            if (ready) {
+                for (int f = 0; f < fForms; ++f) {
+                    float ms = 0.f;
+                    P.form_ms[f] = (P.form_count[f] > 0 && hipEventElapsedTime(&ms, side.t0[f], side.t1[f]) == hipSuccess) ? ms : 0.0;
+                }
+                fwd_deal_lanes(P, P.form_ms);
+                P.calib = 2;
+                if (g_fcalib.size() >= 16) g_fcalib.erase(g_fcalib.begin());
+                g_fcalib.emplace_back(fwd_geometry_key(P.key), std::vector<double>(P.form_ms, P.form_ms + fForms));
+            }
+            (void)hipGetLastError();   // hipEventQuery's "not ready" is not an error of this call
+        }
+        const bool measure = fork && calibrate && side.timed && P.calib == 0 && P.launches == kCalibAt;
         if (fork) PLEAS_HIP_CHECK(hipEventRecord(side.forked, stream));
         bool lane_used[fLanes + 1] = {false};
         for (int o = 0; o < fForms; ++o) {
@@ -1024,13 +1095,16 @@ extern "C" int pleas_fwd_batch(const pleas_fwd_layer* layers, int n_layers, floa
             const dim3 grid((unsigned)P.form_count[f]);
             const FwdItemDev* its = items + P.form_begin[f];
             const size_t lds = P.form_lds[f];
+            if (measure) PLEAS_HIP_CHECK(hipEventRecord(side.t0[f], st));
             switch (f) {
 #define PLEAS_FWD_LAUNCH(F) case F: hipLaunchKernelGGL(fwd_batch_kernel<F>, grid, dim3(fThreads), lds, st, dl, its, parts); break
                 PLEAS_FWD_LAUNCH(0); PLEAS_FWD_LAUNCH(1); PLEAS_FWD_LAUNCH(2); PLEAS_FWD_LAUNCH(3); PLEAS_FWD_LAUNCH(4);
                 PLEAS_FWD_LAUNCH(5); PLEAS_FWD_LAUNCH(6); PLEAS_FWD_LAUNCH(7); PLEAS_FWD_LAUNCH(8); PLEAS_FWD_LAUNCH(9);
 #undef PLEAS_FWD_LAUNCH
             }
+            if (measure) PLEAS_HIP_CHECK(hipEventRecord(side.t1[f], st));
         }
+        if (measure) P.calib = 1;
         for (int lane = 1; lane <= fLanes; ++lane)
             if (lane_used[lane]) {
                 PLEAS_HIP_CHECK(hipEventRecord(side.joined[lane - 1], side.streams[lane - 1]));

@@ -55,6 +55,66 @@ struct NeqItemDev {
     int layer, tm, tn, rx, ry, split, c_begin, c_end, slot, pad0;
 };
 
+// ---- epilogue shared by both tile forms: S == 1 -> A += tile; else tile -> this (slot, split) slab.
+// The accumulators hold 16 scattered elements per MFMA tile and lane; they go through LDS once ([row][T + 4]; the staging
+// buffers are free after the K loop's last barrier) so that every thread then owns 16-byte runs of a row: all of a
+// thread's read-modify-writes of A are 16-byte accesses, requested together (the accumulator registers are free by then).
+template <int T>
+__device__ __forceinline__ void neq_store_tile(const NeqLayerDev& L, const NeqItemDev& it, f32x16 (&acc)[T / 64][T / 64], float* smem) {
+    constexpr int MT = T / 64, EL = T + 4, VPT = T * T / 4 / nThreads;   // 16-byte vectors per thread: 16 (T = 128) / 4
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i0 = it.tm * T, j0 = it.tn * T;
+    float* Ct = smem;
+#pragma unroll
+    for (int sm = 0; sm < MT; ++sm)
+#pragma unroll
+        for (int sn = 0; sn < MT; ++sn) {
+            const int lj = wn * (T / 2) + sn * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int li = wm * (T / 2) + sm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                Ct[li * EL + lj] = acc[sm][sn][r];
+            }
+        }
+    __syncthreads();
+    if (L.S > 1) {
+        gfloat* slab = PLEAS_GLOBAL_W(L.slab) + ((size_t)it.slot * L.S + it.split) * (T * T);
+#pragma unroll
+        for (int q = 0; q < VPT; ++q) {
+            const int v = tid + q * nThreads, li = v / (T / 4), lj = (v % (T / 4)) * 4;
+            *(__attribute__((address_space(1))) f32x4*)(slab + li * T + lj) = *reinterpret_cast<const f32x4*>(Ct + li * EL + lj);
+        }
+        return;
+    }
+    gfloat* Ab = PLEAS_GLOBAL_W(L.A) + ((size_t)it.rx * L.Cin + i0) * L.K + (size_t)it.ry * L.Cin + j0;
+    if ((L.Cin & 3) == 0 && (((size_t)L.A) & 15) == 0) {      // 16-byte runs never straddle the block's edge
+        f32x4 old[VPT];
+#pragma unroll
+        for (int q = 0; q < VPT; ++q) {
+            const int v = tid + q * nThreads, li = v / (T / 4), lj = (v % (T / 4)) * 4;
+            const bool in = i0 + li < L.Cin && j0 + lj < L.Cin;
+            old[q] = *(const __attribute__((address_space(1))) f32x4*)(Ab + (in ? (size_t)li * L.K + lj : 0));
+        }
+#pragma unroll
+        for (int q = 0; q < VPT; ++q) {
+            const int v = tid + q * nThreads, li = v / (T / 4), lj = (v % (T / 4)) * 4;
+            if (i0 + li < L.Cin && j0 + lj < L.Cin) {
+                const f32x4 add = *reinterpret_cast<const f32x4*>(Ct + li * EL + lj);
+                *(__attribute__((address_space(1))) f32x4*)(Ab + (size_t)li * L.K + lj) = old[q] + add;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < VPT; ++q) {
+            const int v = tid + q * nThreads, li = v / (T / 4), lj = (v % (T / 4)) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (i0 + li < L.Cin && j0 + lj + e < L.Cin) Ab[(size_t)li * L.K + lj + e] += Ct[li * EL + lj + e];
+        }
+    }
+}
+
 template <int T, int VEC, bool SHIFT>
 __device__ __forceinline__ void neq_tile(const NeqLayerDev& L, const NeqItemDev& it, float* smem) {
     constexpr int MT = T / 64;
@@ -172,24 +232,7 @@ __device__ __forceinline__ void neq_tile(const NeqLayerDev& L, const NeqItemDev&
         if (more) store_chunk(buf ^ 1);
         __syncthreads();
     }
-    // epilogue: S == 1 -> A += tile ; else tile -> this (slot, split) slab
-    gfloat* slab = L.S > 1 ? PLEAS_GLOBAL_W(L.slab) + ((size_t)it.slot * L.S + it.split) * (T * T) : nullptr;
-#pragma unroll
-    for (int sm = 0; sm < MT; ++sm)
-#pragma unroll
-        for (int sn = 0; sn < MT; ++sn) {
-            const int lj = wn * (T / 2) + sn * 32 + (lane & 31);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int li = wm * (T / 2) + sm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (slab) {
-                    slab[li * T + lj] = acc[sm][sn][r];
-                } else if (i0 + li < L.Cin && j0 + lj < L.Cin) {
-                    gfloat* o = PLEAS_GLOBAL_W(L.A) + ((size_t)it.rx * L.Cin + i0 + li) * L.K + (size_t)it.ry * L.Cin + j0 + lj;
-                    *o += acc[sm][sn][r];
-                }
-            }
-        }
+    neq_store_tile<T>(L, it, acc, smem);
 }
 
 // ---- lag-class tile (stride 1, "same" padding): item (rx, ry) is the CANONICAL block of its class -----------------
@@ -320,23 +363,7 @@ __device__ __forceinline__ void neq_lag_tile(const NeqLayerDev& L, const NeqItem
         if (more) store_chunk(buf ^ 1);
         __syncthreads();
     }
-    gfloat* slab = L.S > 1 ? PLEAS_GLOBAL_W(L.slab) + ((size_t)it.slot * L.S + it.split) * (T * T) : nullptr;
-#pragma unroll
-    for (int sm = 0; sm < MT; ++sm)
-#pragma unroll
-        for (int sn = 0; sn < MT; ++sn) {
-            const int lj = wn * (T / 2) + sn * 32 + (lane & 31);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int li = wm * (T / 2) + sm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (slab) {
-                    slab[li * T + lj] = acc[sm][sn][r];
-                } else if (i0 + li < L.Cin && j0 + lj < L.Cin) {
-                    gfloat* o = PLEAS_GLOBAL_W(L.A) + ((size_t)it.rx * L.Cin + i0 + li) * L.K + (size_t)it.ry * L.Cin + j0 + lj;
-                    *o += acc[sm][sn][r];
-                }
-            }
-        }
+    neq_store_tile<T>(L, it, acc, smem);
 }
 
 __global__ __launch_bounds__(nThreads) void neq_batch_kernel(const NeqLayerDev* __restrict__ layers,

@@ -538,6 +538,14 @@ class MergeBatch:
               "pleas_merge_batch")
 
 
+def fwd_plan_lanes() -> dict:
+    """Per tile form of the latest grouped forward: measured duration on its lane [ms], lane, work items
+    (``pleas_fwd_plan_lanes``); ``state`` 2 = the lanes were dealt from those measurements."""
+    ms, lane, items = (ctypes.c_double * 10)(), (ctypes.c_int * 10)(), (ctypes.c_int * 10)()
+    state = _lib.lib().pleas_fwd_plan_lanes(ms, lane, items)
+    return {"state": state, "forms": {f: {"ms": round(ms[f], 4), "lane": lane[f], "items": items[f]} for f in range(10) if items[f]}}
+
+
 class FwdBatch:
     """Forward + target + residual + loss of all merged layers of one update in ONE grouped launch
     (``pleas_fwd_batch``).  ``add`` per layer, ``flush(loss)`` once per update."""
