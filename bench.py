@@ -64,8 +64,6 @@ def parse(argv=None):
                     help="updates PER RANK whose batches go through the frozen sources as ONE forward (128 samples per "
                          "forward at 8: the vendor convolutions run 15-30 %% faster per sample than at 32); 0 = the fitter's "
                          "default of 2; the prefetch takes --prefetch-groups forwards of that size")
-    ap.add_argument("--grad-buckets", type=int, default=1, help="data parallel: 1 (default) = one all-reduce per update; "
-                    "2 = the gradient arena is all-reduced in two halves, each beside the other half's kernels")
     ap.add_argument("--miopen-find", type=int, default=0, help="1: torch.backends.cudnn.benchmark = True, i.e. the vendor "
                     "library times its candidate convolution kernels per configuration (Find mode) instead of taking the "
                     "immediate-mode pick; costs seconds per new configuration in the first warm-up job")
@@ -218,7 +216,7 @@ def run_job(cfg, spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, phases
     # Data parallel: each rank's share of an update is small (batch / world samples); the frozen sources therefore forward
     # 2 * world updates' samples at once (steps() default), which keeps their host dispatch off the per-update path.
     fit = PleasFitter(m1, m2, m3, spec, perm, costs, cfg["ratio"], n_pleas_sched, data_parallel=dp,
-                      sources=early.get("sources"), grad_buckets=cfg["grad_buckets"], shard_optimizer=cfg["shard_optimizer"])
+                      sources=early.get("sources"), shard_optimizer=cfg["shard_optimizer"])
     phases.mark("merge_and_setup")
     first = None
     for i in fit.steps(inputs, lookahead=cfg["lookahead"], sources_per_forward=cfg["sources_per_forward"]):
@@ -515,7 +513,7 @@ def main():
         os.environ["PLEAS_EMULATE_ALLREDUCE_US"] = str(args.emulate_allreduce_us)
         dp = True
     cfg = {"dp": dp, "ratio": args.ratio, "prefetch_groups": args.prefetch_groups, "prefetch_memory": args.prefetch_memory,
-           "grad_buckets": args.grad_buckets, "shard_optimizer": args.shard_optimizer, "sources_per_forward": (args.sources_per_forward * ranks) or None, "lookahead": None if args.lookahead < 0 else bool(args.lookahead)}
+           "shard_optimizer": args.shard_optimizer, "sources_per_forward": (args.sources_per_forward * ranks) or None, "lookahead": None if args.lookahead < 0 else bool(args.lookahead)}
     log("spec (%d groups, %.2f s on the host, outside `value`) + %d synthetic batches resident" % (len(spec), spec_s, len(pool.items)))
 
     def job(phases=None):

@@ -288,6 +288,16 @@ int pleas_wgrad_batch(const pleas_wgrad_layer* layers, int n_layers, void* ws, s
                       void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * The path's exchange step under data parallelism (no reference counterpart -- the reference is
+ * single-GPU): buf[0..n) := sum over the ranks of `comm`, in place, ONE RCCL all-reduce (fp32, sum) enqueued on `stream`.
+ * What is exchanged: the flat cost arena of activation matching (all group matrices back to back, ResNet-101: 41 MB) before
+ * the LAPs; the A / B arenas of the closed form before the solve; the gradient arena of an Adam update.
+ * `comm` is the CALLER's ncclComm_t (RCCL is resolved at run time from the instance already loaded in the process, else
+ * $PLEAS_RCCL_LIB, else librccl.so.1 -- a communicator is only valid in the library instance that created it).
+ * The Python host side uses torch.distributed (backend "nccl" = RCCL) for the same step. */
+int pleas_allreduce_sum(float* buf, int64_t n, void* comm, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Normal equations of the per-layer PLeaS objective (closed form of what the reference's Adam
  * loop, pleas_merging.py:281-291 + :357-358, approximates):  W^T = A^-1 B  with
  *   A = sum_batches U^T U   (K x K, K = KH*KW*Cin, index k = (kh*KW + kw)*Cin + ci)

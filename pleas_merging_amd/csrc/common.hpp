@@ -69,6 +69,34 @@ struct ProfScope {
 };
 
 
+// ---- a few plans per grouped launch (host side).
+// A plan (work-item tables of one layer / node list) is keyed by its geometry AND the address of the caller's workspace
+// the tables are uploaded to (element WS of the key).  Keeping several lets callers that alternate inside one process --
+// two fitters, the per-group contractions of weight matching, matching next to PLeaS -- find their plan again instead
+// of rebuilding and re-uploading it at every call.  Slots are recycled round robin.  Guarded by the caller's mutex.
+template <class Plan, int WS, int N = 8>
+struct PlanCache {
+    Plan slots[N];
+    unsigned turn = 0;
+    Plan* last = nullptr;       // most recently used (diagnostics)
+    Plan* find(const std::vector<int64_t>& key) {
+        for (auto& p : slots)
+            if (!p.key.empty() && p.key == key) return last = &p;
+        return nullptr;
+    }
+    Plan& take() {              // slot for a new plan: the caller builds it, then sets its key
+        Plan& p = slots[turn++ % N];
+        p.key.clear();
+        p.uploaded = false;
+        return *(last = &p);
+    }
+    // p's tables are about to be written into its workspace: other plans that had theirs at that address lost them
+    void claims_workspace(const Plan& p) {
+        for (auto& o : slots)
+            if (&o != &p && (int)o.key.size() > WS && (int)p.key.size() > WS && o.key[WS] == p.key[WS]) o.uploaded = false;
+    }
+};
+
 // ---- XCD-aware work-item order for grouped launches (host side).
 // Workgroup b of a grid runs on XCD b % 8, and every XCD has a private L2.  Items that read the same operand rows
 // (same `key`) are therefore given grid positions of ONE residue class, so that their re-reads hit that L2 instead

@@ -794,7 +794,7 @@ struct FwdPlan {
     int launches = 0, calib = 0;       // calib: 0 not measured yet, 1 events recorded, 2 lanes dealt from measurements
     double form_ms[fForms] = {0};
 };
-static FwdPlan g_fplan;
+static PlanCache<FwdPlan, 1> g_fplans;
 constexpr int kCalibAt = 3;
 // measured durations per layer-list geometry (the plan key without its workspace address): a new fitter on the same
 // layers -- every job of a bench run -- starts from the lanes the previous one measured
@@ -967,12 +967,14 @@ extern "C" int pleas_fwd_debug_read(long long* out, int n_items) {
 extern "C" int pleas_fwd_plan_lanes(double* form_ms, int* form_lane, int* form_items) {
     if (!form_ms || !form_lane || !form_items) return bad_arg("fwd_plan_lanes: null pointer");
     std::lock_guard<std::mutex> lk(g_fplan_mu);
+    if (!g_fplans.last) return bad_arg("fwd_plan_lanes: no grouped forward has run yet");
+    const FwdPlan& P = *g_fplans.last;
     for (int f = 0; f < fForms; ++f) {
-        form_ms[f] = g_fplan.form_ms[f];
-        form_lane[f] = g_fplan.form_lane[f];
-        form_items[f] = g_fplan.form_count[f];
+        form_ms[f] = P.form_ms[f];
+        form_lane[f] = P.form_lane[f];
+        form_items[f] = P.form_count[f];
     }
-    return g_fplan.calib;
+    return P.calib;
 }
 
 extern "C" size_t pleas_fwd_batch_ws_bytes(const pleas_fwd_layer* layers, int n_layers) {
@@ -993,7 +995,6 @@ extern "C" int pleas_fwd_batch(const pleas_fwd_layer* layers, int n_layers, floa
     }
     hipStream_t stream = (hipStream_t)stream_;
     std::lock_guard<std::mutex> lk(g_fplan_mu);
-    FwdPlan& P = g_fplan;
     std::vector<int64_t> key;
     key.push_back(n_layers);
     key.push_back((int64_t)(uintptr_t)ws);
@@ -1007,10 +1008,15 @@ extern "C" int pleas_fwd_batch(const pleas_fwd_layer* layers, int n_layers, floa
         key.push_back(bits[0]);
         key.push_back(bits[1]);
     }
-    if (key != P.key) {
-        const int rc = build_fwd_plan(P, layers, n_layers);
+    FwdPlan* hit = g_fplans.find(key);
+    if (!hit) {
+        hit = &g_fplans.take();
+        const int rc = build_fwd_plan(*hit, layers, n_layers);
         if (rc != PLEAS_OK) return rc;
-        P.key.swap(key);
+        hit->key.swap(key);
+    }
+    FwdPlan& P = *hit;
+    if (P.calib == 0 && P.launches == 0) {      // a new plan: start from what another fitter measured on this geometry
         const std::vector<int64_t> geo = fwd_geometry_key(P.key);
         for (const auto& kv : g_fcalib)
             if (kv.first == geo) {
@@ -1027,6 +1033,7 @@ extern "C" int pleas_fwd_batch(const pleas_fwd_layer* layers, int n_layers, floa
     }
     char* base = (char*)ws;
     if (!P.uploaded) {
+        g_fplans.claims_workspace(P);
         PLEAS_HIP_CHECK(hipMemcpyAsync(base + P.off_layers, P.layers.data(), P.layers.size() * sizeof(FwdLayerDev),
                                        hipMemcpyHostToDevice, stream));
         PLEAS_HIP_CHECK(hipMemcpyAsync(base + P.off_items, P.items.data(), P.items.size() * sizeof(FwdItemDev),

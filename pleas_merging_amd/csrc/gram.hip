@@ -523,7 +523,7 @@ struct BatchPlan {
     double flops = 0, bytes = 0, slab_bytes = 0;
     bool uploaded = false;
 };
-static BatchPlan g_bplan;
+static PlanCache<BatchPlan, 2> g_bplans;
 static std::mutex g_bplan_mu;
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -724,13 +724,15 @@ extern "C" int pleas_gram_batch(const pleas_gram_node* nodes, int n_nodes, float
         if (!group_acc[g]) return bad_arg("gram_batch: null group matrix");
     hipStream_t stream = (hipStream_t)stream_;
     std::lock_guard<std::mutex> lk(g_bplan_mu);
-    BatchPlan& P = g_bplan;
     std::vector<int64_t> key = batch_key(nodes, n_nodes, group_acc, group_C, n_groups, ws);
-    if (key != P.key) {
-        const int rc = build_batch_plan(P, nodes, n_nodes, group_acc, group_C, n_groups);
+    BatchPlan* hit = g_bplans.find(key);
+    if (!hit) {
+        hit = &g_bplans.take();
+        const int rc = build_batch_plan(*hit, nodes, n_nodes, group_acc, group_C, n_groups);
         if (rc != PLEAS_OK) return rc;
-        P.key.swap(key);
+        hit->key.swap(key);
     }
+    BatchPlan& P = *hit;
     if (ws_fresh) P.uploaded = false;  // caller says the tables inside ws are not (or no longer) there
     if (!ws || ws_bytes < P.total) {
         std::snprintf(g_last_error, sizeof(g_last_error), "gram_batch workspace too small: need %zu bytes", P.total);
@@ -739,6 +741,7 @@ extern "C" int pleas_gram_batch(const pleas_gram_node* nodes, int n_nodes, float
     }
     char* base = (char*)ws;
     if (!P.uploaded) {  // static tables: once per (shape sequence, workspace, group matrices)
+        g_bplans.claims_workspace(P);
         float* slab0 = reinterpret_cast<float*>(base + P.off_slabs);
         std::vector<GramNodeDev> abs_nodes = P.nodes;
         for (auto& d : abs_nodes) {

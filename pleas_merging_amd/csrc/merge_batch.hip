@@ -116,7 +116,7 @@ struct MergePlan {
     double bytes = 0;
     bool uploaded = false;
 };
-static MergePlan g_mplan;
+static PlanCache<MergePlan, 1> g_mplans;
 static std::mutex g_mplan_mu;
 static size_t malign(size_t v) { return (v + 255) / 256 * 256; }
 
@@ -173,7 +173,6 @@ extern "C" int pleas_merge_batch(const pleas_merge_item* items, int n_items, voi
     }
     hipStream_t stream = (hipStream_t)stream_;
     std::lock_guard<std::mutex> lk(g_mplan_mu);
-    MergePlan& P = g_mplan;
     std::vector<int64_t> key;
     key.push_back(n_items);
     key.push_back((int64_t)(uintptr_t)ws);
@@ -181,11 +180,14 @@ extern "C" int pleas_merge_batch(const pleas_merge_item* items, int n_items, voi
         const pleas_merge_item& m = items[i];
         for (int64_t v : {m.outer, m.inner, (int64_t)m.rows_out, (int64_t)m.rows_src, (int64_t)m.n_merged}) key.push_back(v);
     }
-    if (key != P.key) {
-        const int rc = build_merge_plan(P, items, n_items);
+    MergePlan* hit = g_mplans.find(key);
+    if (!hit) {
+        hit = &g_mplans.take();
+        const int rc = build_merge_plan(*hit, items, n_items);
         if (rc != PLEAS_OK) return rc;
-        P.key.swap(key);
+        hit->key.swap(key);
     }
+    MergePlan& P = *hit;
     if (ws_fresh) P.uploaded = false;
     if (P.block_item.empty()) return PLEAS_OK;
     if (!ws || ws_bytes < P.total) {
@@ -195,6 +197,7 @@ extern "C" int pleas_merge_batch(const pleas_merge_item* items, int n_items, voi
     }
     char* base = (char*)ws;
     if (!P.uploaded) {
+        g_mplans.claims_workspace(P);
         PLEAS_HIP_CHECK(hipMemcpyAsync(base + P.off_items, P.items.data(), P.items.size() * sizeof(MergeItemDev),
                                        hipMemcpyHostToDevice, stream));
         PLEAS_HIP_CHECK(hipMemcpyAsync(base + P.off_blocks, P.block_item.data(), P.block_item.size() * sizeof(int),

@@ -502,7 +502,7 @@ struct NeqPlan {
     int64_t n_copies = 0;
     bool uploaded = false;
 };
-static NeqPlan g_nplan;
+static PlanCache<NeqPlan, 1> g_nplans;
 static std::mutex g_nplan_mu;
 static size_t nalign(size_t v) { return (v + 255) / 256 * 256; }
 
@@ -655,7 +655,6 @@ extern "C" int pleas_normal_eq_accum(const pleas_neq_layer* layers, int n_layers
     }
     hipStream_t stream = (hipStream_t)stream_;
     std::lock_guard<std::mutex> lk(g_nplan_mu);
-    NeqPlan& P = g_nplan;
     std::vector<int64_t> key;
     key.push_back(n_layers);
     key.push_back((int64_t)(uintptr_t)ws);
@@ -664,11 +663,14 @@ extern "C" int pleas_normal_eq_accum(const pleas_neq_layer* layers, int n_layers
         for (int v : {layers[i].N, layers[i].Cin, layers[i].Hin, layers[i].Win, layers[i].KH, layers[i].KW, layers[i].stride,
                       layers[i].pad})
             key.push_back(v);
-    if (key != P.key) {
-        const int rc = build_neq_plan(P, layers, n_layers);
+    NeqPlan* hit = g_nplans.find(key);
+    if (!hit) {
+        hit = &g_nplans.take();
+        const int rc = build_neq_plan(*hit, layers, n_layers);
         if (rc != PLEAS_OK) return rc;
-        P.key.swap(key);
+        hit->key.swap(key);
     }
+    NeqPlan& P = *hit;
     if (ws_fresh) P.uploaded = false;
     if (!ws || ws_bytes < P.total) {
         std::snprintf(g_last_error, sizeof(g_last_error), "normal_eq workspace too small: need %zu bytes", P.total);
@@ -677,6 +679,7 @@ extern "C" int pleas_normal_eq_accum(const pleas_neq_layer* layers, int n_layers
     }
     char* base = (char*)ws;
     if (!P.uploaded) {
+        g_nplans.claims_workspace(P);
         float* slab0 = reinterpret_cast<float*>(base + P.off_slabs);
         std::vector<NeqLayerDev> abs_layers = P.layers;
         for (auto& d : abs_layers) d.slab = slab0 + reinterpret_cast<size_t>(d.slab);

@@ -477,8 +477,7 @@ def compute_matching_costs(spec: PermutationSpec, gm_cross: nn.Module, dataloade
 
 def accumulate_costs_fused(spec: PermutationSpec, model1: nn.Module, model2: nn.Module, dataloader, num_batches: int,
                            epilogue: int, accumulate=True, shard: bool = True,
-                           grouped: bool = True, graph_forward: bool = False,
-                           overlap: bool = True, fuse_bn: bool = True, derive_bn: bool = True) -> Dict[Axis, torch.Tensor]:
+                           grouped: bool = True, overlap: bool = True, fuse_bn: bool = True, derive_bn: bool = True) -> Dict[Axis, torch.Tensor]:
     """HIP fast path: every tracked node adds into its group matrix while the forwards run.
 
     Data parallel: with ``torch.distributed`` initialised (one process per GPU, RCCL), rank r
@@ -503,13 +502,8 @@ def accumulate_costs_fused(spec: PermutationSpec, model1: nn.Module, model2: nn.
         raise RuntimeError("activation_matching: models must be on the GPU for the HIP path (got %s)" % device)
     arena = GroupArena(spec, device)
     gm, sinks = build_fused_module(spec, model1, model2, arena, epilogue, grouped,
-                                   overlap=overlap and grouped and not graph_forward, fuse_bn=fuse_bn, derive_bn=derive_bn)
+                                   overlap=overlap and grouped, fuse_bn=fuse_bn, derive_bn=derive_bn)
     rank, world = _dist_info() if (shard and accumulate is True) else (0, 1)
-    # graph_forward=True (opt-in): after two eager batches (vendor warm-up) the whole twin forward (~1400 launches)
-    # is captured into ONE hipGraph and replayed per batch on a static input; the sinks' tensors are then fixed
-    # addresses, so the grouped contraction keeps its node list.  The matching loop is GPU-bound, and capture
-    # costs ~0.3 s, so this does not pay for 100 batches.  Any capture problem falls back to eager forwards.
-    graph, x_static, eager_seen, use_graph = None, None, 0, bool(graph_forward and grouped)
     # The batches run on a created stream, not on the caller's: work on torch's default (null) stream overlaps the side
     # stream of the split twin graph markedly worse than work on a created stream (see PleasFitter).
     caller = torch.cuda.current_stream(device)
@@ -520,34 +514,12 @@ def accumulate_costs_fused(spec: PermutationSpec, model1: nn.Module, model2: nn.
             if accumulate is not True:
                 arena.zero_()
             x = x.to(device, non_blocking=True)
-            if graph is not None and x.shape == x_static.shape:
-                x_static.copy_(x)
-                graph.replay()
-                sinks.batch.flush(accumulate=True, keep=True)
-                continue
-            if use_graph and eager_seen >= 2 and graph is None:
-                try:
-                    sinks.batch.drop()
-                    x_static = x.clone()
-                    g = torch.cuda.CUDAGraph()
-                    torch.cuda.synchronize()
-                    with torch.cuda.graph(g):
-                        gm(x_static)
-                    g.replay()
-                    graph = g
-                    sinks.batch.flush(accumulate=True, keep=True)
-                    continue
-                except Exception as exc:  # noqa: BLE001 -- capture is an optimisation; eager is always valid
-                    print("pleas: twin-forward graph capture unavailable (%s); running eagerly" % (exc,))
-                    use_graph, graph = False, None
-                    sinks.batch.drop()
             try:
                 gm(x)
             except BaseException:
                 if sinks.streams is not None:
                     sinks.streams.restore()
                 raise
-            eager_seen += 1
             if sinks.batch is not None:
                 sinks.batch.flush(accumulate=True)
     caller.wait_stream(work)

@@ -203,7 +203,7 @@ def cosine_lrs(base_lr: float, t_max: int, n: int) -> List[float]:
 # ------------------------------------------------------------------------------------------ per-layer plan
 class _LayerPlan:
     __slots__ = ("name", "mod", "is_conv", "w", "b", "gw", "gb", "gw2", "gb2", "in_maps", "out_maps", "halves", "w_shape",
-                 "off_w", "kpos", "bucket")
+                 "off_w", "kpos")
 
 
 def _identity_block(n: int):
@@ -320,39 +320,6 @@ def dp_all_gather_(flat: torch.Tensor, rank: int, world: int) -> None:
         dist.all_gather(list(flat.chunk(world)), mine)
 
 
-class _Pending:
-    """An all-reduce in flight (``dist.all_reduce(..., async_op=True)``, or its emulation on a stream of its own);
-    ``wait()`` orders the current stream after it."""
-
-    def __init__(self, work=None, stream=None):
-        self.work, self.stream = work, stream
-
-    def wait(self):
-        if self.work is not None:
-            self.work.wait()
-        if self.stream is not None:
-            torch.cuda.current_stream().wait_stream(self.stream)
-
-
-def dp_sum_async_(flat: torch.Tensor, world: int, share: float = 1.0) -> Optional[_Pending]:
-    """Start the sum of ``flat`` over ranks and return at once; the caller keeps enqueuing work that does not need the
-    result (the other gradient bucket's kernels) and calls ``wait()`` before the first reader."""
-    if world <= 1:
-        return None
-    import torch.distributed as dist
-
-    if dist.is_initialized():
-        return _Pending(work=dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
-    if not flat.is_cuda:
-        return None
-    from .. import hip_ops                       # PLEAS_EMULATE_WORLD: the stall sits on a stream of its own
-    comm = hip_ops.role_stream(flat.device, "emulated-collective")
-    comm.wait_stream(torch.cuda.current_stream(flat.device))
-    with torch.cuda.stream(comm):
-        _emulated_collective(flat, share)
-    return _Pending(stream=comm)
-
-
 _SPIN = {}
 
 
@@ -386,7 +353,7 @@ class FrozenSources:
     enqueued (``prefetch``) -- while the LAP kernel is still running; ``PleasFitter(sources=...)`` then takes it over."""
 
     def __init__(self, model1: nn.Module, model2: nn.Module, data_parallel: bool = False, fuse: bool = True,
-                 overlap: bool = True, graph: bool = False, fused=None):
+                 overlap: bool = True, fused=None):
         from .. import hip_ops
         from .activation_matching import _dist_info
 
@@ -413,18 +380,6 @@ class FrozenSources:
         self._src_events = None
         self._slice_batch = True   # data parallel: every update splits its batch's samples over the ranks
         self.queue: collections.deque = collections.deque()
-        # graph=True: from the second batch of a shape on, the two source forwards (~420 launches, ~35 us of host
-        # time per vendor convolution) are replayed from hipGraphs instead of being dispatched op by op: TWO graphs with
-        # their own static input and taps take turns, so that the sources of the next batch can be replayed while the
-        # update of the current one still reads the other generation.  Inside a graph the two models sit on parallel
-        # branches (captured from the two side streams).  Capture costs ~0.05 s per graph; a capture problem falls back
-        # to eager dispatch for the rest of the run.  (Measured later: one replay of the ~600 nodes costs the host 9.6 ms,
-        # more than dispatching them -- kept as an option, used by nothing.)
-        self.graph_sources = graph
-        self._graphs = [None, None]     # per generation: dict(graph, x, taps1, taps2, shape)
-        self._graph_turn = 0
-        self._graph_seen: Dict[tuple, int] = {}
-        self._graph_stream = hip_ops.role_stream(self.device, "sources.graph", priority=-1) if graph else None
 
     def launch(self, x: torch.Tensor, parts: int = 1, after_current: bool = True):
         """Enqueue both source forwards for ``x``; returns the generation (device batch, taps, events) the update will
@@ -436,64 +391,10 @@ class FrozenSources:
                 x = torch.cat([dp_slice(x[i * h:(i + 1) * h], self.rank, self.world) for i in range(parts)], 0)
             else:
                 x = dp_slice(x, self.rank, self.world)
-        if self.graph_sources:
-            gen = self._launch_graph(x)
-            if gen is not None:
-                return gen
         self.run_eager(x, after_current)
         events = self._src_events
         self._src_events = None
         return (x, self.tap1.take(), self.tap2.take(), events)
-
-    def _capture_sources(self, x: torch.Tensor) -> dict:
-        self.tap1.take()
-        self.tap2.take()
-        x_static = x.clone()
-        graph = torch.cuda.CUDAGraph()
-        torch.cuda.current_stream(self.device).synchronize()
-        # thread_local: other threads (e.g. the collective watchdog of torch.distributed) may keep calling the runtime
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            cap = torch.cuda.current_stream(self.device)
-            side = self._side_streams or (cap, cap)
-            for stream, model in zip(side, (self.src1, self.src2)):
-                if stream is not cap:
-                    stream.wait_stream(cap)
-                with torch.cuda.stream(stream), self.ops.pin_stream():
-                    model(x_static)
-            for stream in side:
-                if stream is not cap:
-                    cap.wait_stream(stream)
-        return {"graph": graph, "x": x_static, "taps1": self.tap1.take(), "taps2": self.tap2.take(),
-                "shape": tuple(x.shape)}
-
-    def _launch_graph(self, x: torch.Tensor):
-        """Replay (capturing first if needed) this generation's source graph on the graph stream; None = run eagerly."""
-        key = tuple(x.shape)
-        seen = self._graph_seen[key] = self._graph_seen.get(key, 0) + 1
-        if seen <= 1:                    # the first batch of a shape runs eagerly: vendor plans, allocator
-            return None
-        slot = self._graph_turn = (self._graph_turn + 1) % 2
-        main, gs = torch.cuda.current_stream(self.device), self._graph_stream
-        try:
-            # everything below is ordered after the work already enqueued on `main`: in particular after the update that
-            # last read this generation's static taps (two updates back with one batch of look-ahead)
-            gs.wait_stream(main)
-            with torch.cuda.stream(gs):
-                g = self._graphs[slot]
-                if g is None or g["shape"] != key:
-                    g = self._graphs[slot] = self._capture_sources(x)
-                g["x"].copy_(x, non_blocking=True)
-                g["graph"].replay()
-                ev = torch.cuda.Event()
-                ev.record(gs)
-            return (x, g["taps1"], g["taps2"], [ev])
-        except Exception as exc:  # noqa: BLE001 -- capture is an optimisation; eager dispatch is always valid
-            print("pleas: source-forward graph capture unavailable (%s); running eagerly" % (exc,))
-            self.graph_sources = False
-            self._graphs = [None, None]
-            self.tap1.take()
-            self.tap2.take()
-            return None
 
     @torch.no_grad()
     def launch_group(self, run: List[torch.Tensor], after_current: bool = True) -> None:
@@ -517,7 +418,7 @@ class FrozenSources:
         the same tensor objects first, in the same order.  Takes whole groups of ``group`` (default ``2 * world``) equal
         batches, at most ``max_groups`` of them and as long as their taps (sized from the first group) fit into
         ``memory_fraction`` of the HBM that is free or idle in the allocator's pools.  Returns the number of batches taken."""
-        if self._side_streams is None or self.graph_sources:
+        if self._side_streams is None:
             return 0
         group = max(1, int(group or 2 * self.world))
         batches = list(batches)
@@ -592,23 +493,19 @@ class PleasFitter:
 
     def __init__(self, model1, model2, model3, spec, perm, costs, budget_ratios, max_steps: int, lr: float = 5e-4,
                  separate_classifier=False, num_classes=1000, model_type="rn50", data_parallel: bool = False,
-                 forward: str = "hip", graph_sources: bool = False, fuse_sources: bool = True,
-                 overlap_sources: bool = True, fused_sources=None, sources: Optional[FrozenSources] = None,
-                 grad_buckets: int = 1, merging: str = "perm_gradmask", shard_optimizer: bool = False):
+                 fuse_sources: bool = True, overlap_sources: bool = True, fused_sources=None,
+                 sources: Optional[FrozenSources] = None, merging: str = "perm_gradmask", shard_optimizer: bool = False):
         from .. import hip_ops
 
         self.ops = hip_ops
         # data parallel: every update splits the batch's samples over the ranks, gradients (one flat
         # arena) are summed with ONE all-reduce, so all ranks apply the same full-batch update
         self.sources = sources if sources is not None else FrozenSources(
-            model1, model2, data_parallel=data_parallel, fuse=fuse_sources, overlap=overlap_sources, graph=graph_sources,
-            fused=fused_sources)
+            model1, model2, data_parallel=data_parallel, fuse=fuse_sources, overlap=overlap_sources, fused=fused_sources)
         self.rank, self.world, self.device = self.sources.rank, self.sources.world, self.sources.device
         self.model1, self.model2, self.model3 = model1, model2, model3
         self.merging = merging_mode(merging)
         self.stacked = self.merging != "perm_gradmask"       # two half-batches per layer (reference :125-144)
-        if self.stacked and (forward != "hip" or grad_buckets >= 2):
-            raise NotImplementedError("merging=%r needs forward='hip' and one gradient bucket" % merging)
         blocks = get_blocks(spec, perm, costs, budget_ratios, False)
         self.perm_blocks = spread_blocks(spec, blocks)
         # The update's own launches go to a dedicated stream, not to the caller's: measured on the 401-update job,
@@ -636,8 +533,6 @@ class PleasFitter:
 
         self.shard_optimizer = bool(shard_optimizer) and (self.world > 1 or _force_collectives())
         if self.shard_optimizer:
-            if grad_buckets >= 2:
-                raise ValueError("shard_optimizer and grad_buckets >= 2 are alternatives")
             total = (total + 4 * self.world - 1) // (4 * self.world) * (4 * self.world)    # equal, 16-byte aligned slices
         self._shard = total // self.world if self.shard_optimizer else total
         dev = self.device
@@ -661,7 +556,7 @@ class PleasFitter:
             # k x k convolutions with Cin % 32 == 0 keep their weight (gradient, mask, Adam state) KERNEL-POSITION-MAJOR
             # [Cout][KH][KW][Cin] in the arenas: the fused forward then has one tap per K chunk, the weight-gradient
             # kernel writes that layout directly, and the elementwise optimiser does not care (finish() permutes back)
-            plan.kpos = bool(forward == "hip" and plan.is_conv and _square_conv(mod) and mod.kernel_size[0] > 1
+            plan.kpos = bool(plan.is_conv and _square_conv(mod) and mod.kernel_size[0] > 1
                              and mod.weight.shape[1] % 32 == 0)   # the tensor's width: module attributes may be stale
             for pname, prm in mod.named_parameters():
                 n = prm.numel()
@@ -702,29 +597,7 @@ class PleasFitter:
         self.step_count = 0
         self.loss_now = self._g_ext[total:]                                             # this step, per layer
         self.loss_sum = torch.zeros(len(self.plans), dtype=torch.float32, device=dev)   # since last report
-        self.loss_parts = torch.zeros(len(self.plans), hip_ops.target_residual_max_partials(), dtype=torch.float32,
-                                      device=dev)
-        self.loss_nparts = torch.zeros(len(self.plans), dtype=torch.int32, device=dev)
-        self.loss_scale = torch.zeros(len(self.plans), dtype=torch.float32, device=dev)
-        self.loss_meta_host = [None] * len(self.plans)
         self.wgrad = hip_ops.WgradBatch(dev)
-        # Data parallel, grad_buckets=2 (option): the gradient arena is summed in TWO buckets (first / second half of its
-        # bytes, layers in plan order).  Bucket 0's all-reduce is started as soon as its grouped weight-gradient launch is
-        # enqueued and runs beside bucket 1's launch; bucket 1's runs beside bucket 0's Adam; the losses ride at the end
-        # of bucket 1.  Off by default: with the collective modelled as a stall of a stream of its own
-        # (PLEAS_EMULATE_ALLREDUCE_US) the split cost more than it hid -- 1.69 vs 1.64 s per rank at 8 ranks, 4.33 vs
-        # 3.76 s at 2 -- and RCCL itself cannot be timed on a one-GPU box; same results either way (two-rank test).
-        self.wgrad_b = hip_ops.WgradBatch(dev) if (self.world > 1 and grad_buckets >= 2) else None
-        self._bucket_cut = 0
-        if self.wgrad_b is not None:
-            half = total // 2
-            cut_plan = next((pl for pl in self.plans if pl.off_w >= half), None)
-            self._bucket_cut = cut_plan.off_w if cut_plan is not None else 0
-        for pl in self.plans:
-            pl.bucket = 1 if (self.wgrad_b is not None and self._bucket_cut > 0 and pl.off_w >= self._bucket_cut) else 0
-        if forward not in ("hip", "vendor"):
-            raise ValueError("forward must be 'hip' (fused MFMA kernel) or 'vendor' (MIOpen + pleas_target_residual)")
-        self.forward = forward
         self.fwd = hip_ops.FwdBatch(dev)
         self.merge = hip_ops.MergeBatch(dev)
         self._fwd_loss = None
@@ -737,8 +610,6 @@ class PleasFitter:
     src2 = property(lambda self: self.sources.src2)
     _queue = property(lambda self: self.sources.queue)
     _side_streams = property(lambda self: self.sources._side_streams)
-    _graphs = property(lambda self: self.sources._graphs)
-    graph_sources = property(lambda self: self.sources.graph_sources)
 
     @property
     def _slice_batch(self):
@@ -764,47 +635,31 @@ class PleasFitter:
         cout = plan.w_shape[0]
         square = plan.is_conv and _square_conv(mod)
         linear = (not plan.is_conv) and ip1.dim() == 2
+        if not (square or linear):
+            raise NotImplementedError("layer %s: the grouped HIP kernels take dense, undilated Conv2d layers with a square "
+                                      "kernel / stride / padding and Linear layers on 2-D inputs" % name)
         geo = (tuple(mod.kernel_size), mod.stride[0], mod.padding[0]) if plan.is_conv else ((1, 1), 1, 0)
-        hip_forward = self.forward == "hip" and (square or linear)
         halves = len(plan.halves)
-        if halves > 1 and not hip_forward:
-            raise NotImplementedError("merging=%r: layer %s has a geometry only the vendor forward takes" % (self.merging, name))
         for h, (in_maps, (r1, r2, nm)) in enumerate(plan.halves):
             if cout != r1.numel():
                 raise RuntimeError("layer %s: %d merged outputs vs %d target blocks" % (name, cout, r1.numel()))
             if in_maps[0].numel() != plan.w_shape[1]:
                 raise RuntimeError("layer %s: %d merged inputs vs %d input blocks" % (name, plan.w_shape[1], in_maps[0].numel()))
-            # merged input: queued for the ONE grouped merge launch that precedes the grouped forward (merge.flush); the
-            # vendor-forward path consumes it right here and takes the single-tensor launch
-            kept = self._bufs.get((idx, h)) if hip_forward else None
-            ip = self.merge.add(ip1, ip2, 1, *in_maps, out=kept[0] if kept else None) if hip_forward \
-                else ops.merge_blocks(ip1, ip2, 1, *in_maps)
-            if hip_forward:
-                resid = kept[1] if kept else torch.empty((ip.shape[0], cout) + tuple(o1.shape[2:]), dtype=torch.float32,
-                                                         device=ip.device)
-                if kept is None:
-                    self._bufs[(idx, h)] = (ip, resid)
-                n = resid.numel() * halves * self.world    # the mean runs over the full (global, stacked) batch
-                self.fwd.add(ip, plan.w, plan.b, o1, o2, r1, r2, nm, resid, 2.0 / n, 1.0 / n, *geo,
-                             flags=ops.FwdBatch.KPOS_MAJOR if plan.kpos else 0)
-                self._fwd_rows.append(idx)
-            else:                                        # vendor forward + fused target/residual (one launch per layer)
-                out = F.conv2d(ip, plan.w, plan.b, mod.stride, mod.padding, mod.dilation, mod.groups) if plan.is_conv \
-                    else F.linear(ip, plan.w, plan.b)
-                if out.shape[2:] != o1.shape[2:]:
-                    raise RuntimeError("layer %s: merged output %s vs source output %s" % (name, tuple(out.shape), tuple(o1.shape)))
-                n = out.numel() * self.world
-                nparts = ops.target_residual(out, o1, o2, r1, r2, nm, 2.0 / n, self.loss_parts[idx])
-                if self.loss_meta_host[idx] != (nparts, n):
-                    self.loss_meta_host[idx] = (nparts, n)
-                    self.loss_nparts[idx] = nparts
-                    self.loss_scale[idx] = 1.0 / n
-                resid = out
+            # merged input: queued for the ONE grouped merge launch that precedes the grouped forward (merge.flush)
+            kept = self._bufs.get((idx, h))
+            ip = self.merge.add(ip1, ip2, 1, *in_maps, out=kept[0] if kept else None)
+            resid = kept[1] if kept else torch.empty((ip.shape[0], cout) + tuple(o1.shape[2:]), dtype=torch.float32,
+                                                     device=ip.device)
+            if kept is None:
+                self._bufs[(idx, h)] = (ip, resid)
+            n = resid.numel() * halves * self.world    # the mean runs over the full (global, stacked) batch
+            self.fwd.add(ip, plan.w, plan.b, o1, o2, r1, r2, nm, resid, 2.0 / n, 1.0 / n, *geo,
+                         flags=ops.FwdBatch.KPOS_MAJOR if plan.kpos else 0)
+            self._fwd_rows.append(idx)
             gw, gb = (plan.gw, plan.gb) if h == 0 else (plan.gw2, plan.gb2)   # second half: its own arena, added in _step
-            if (square and ip.shape[1] >= 16) or linear:
-                (self.wgrad_b if plan.bucket else self.wgrad).add(resid, ip, gw, *geo,
-                                                                 flags=ops.WgradBatch.KPOS_MAJOR if plan.kpos else 0)
-            else:   # stem (3 input channels) and exotic geometries: vendor weight gradient
+            if ip.shape[1] >= 16 or linear:
+                self.wgrad.add(resid, ip, gw, *geo, flags=ops.WgradBatch.KPOS_MAJOR if plan.kpos else 0)
+            else:   # the stem (3 input channels): narrower than the tile's 16-channel chunks -> vendor weight gradient
                 self._vendor_wgrad.append((resid, ip, plan, gw))
             if gb is not None:
                 self._bias_grads.append((resid, plan, gb))
@@ -827,7 +682,7 @@ class PleasFitter:
         if self._queue and self._queue[0][0] is not x:
             raise RuntimeError("PleasFitter.step: a different batch was prefetched than the one passed now")
         cur = self._queue.popleft() if self._queue else (x,) + self._launch_sources(x)
-        if next_x is not None and not self._queue and (self._side_streams is not None or self.graph_sources):
+        if next_x is not None and not self._queue and self._side_streams is not None:
             self._queue.append((next_x,) + self._launch_sources(next_x))
         _, self._cur_x, (self.t1_in, self.t1_out), (self.t2_in, self.t2_out), events = cur
         if events is not None:
@@ -857,12 +712,12 @@ class PleasFitter:
         finally:
             caller.wait_stream(upd)
 
-    def steps(self, batches, lookahead: Optional[bool] = None, pair_sources: bool = True, sources_per_forward: Optional[int] = None):
+    def steps(self, batches, lookahead: Optional[bool] = None, sources_per_forward: Optional[int] = None):
         """Run one update per tensor of ``batches``; yields the index of each finished update.  Between two updates the
         consumer's code runs on ITS OWN current stream, ordered after the update just applied (the fitter's stream is
         entered and left per update).
 
-        ``pair_sources=True`` (default): up to ``sources_per_forward`` consecutive batches of equal shape go through the
+        Up to ``sources_per_forward`` consecutive batches of equal shape (1: every batch on its own) go through the
         frozen sources as ONE forward of the concatenated batch, and the updates read their slices (views) of its taps --
         the sources are in eval mode, so every sample's activations are what a separate forward gives (up to the vendor
         kernels' rounding at another batch size) and the update order is unchanged.  ResNet-101 pair, 16 samples per
@@ -882,7 +737,7 @@ class PleasFitter:
         gradient all-reduce, and the prefetched source forwards are what fills those gaps."""
         if sources_per_forward is None:
             sources_per_forward = 2 * self.world
-        group = max(1, int(sources_per_forward)) if pair_sources else 1
+        group = max(1, int(sources_per_forward))
         if lookahead is None:
             lookahead = self.world > 1
         keep = group if lookahead else 0      # sources are launched whenever no more than `keep` generations are queued
@@ -983,9 +838,6 @@ class PleasFitter:
                     self._fwd_loss = torch.zeros(len(self._fwd_rows), dtype=torch.float32, device=self.device)
                     self._fwd_index = torch.tensor(self._fwd_rows, dtype=torch.long, device=self.device)
                 self.fwd.flush(self._fwd_loss)
-        vendor_rows = len(set(self._fwd_rows)) < len(self.plans)
-        if vendor_rows:
-            self.ops.loss_final(self.loss_parts, self.loss_nparts, self.loss_scale, self.loss_now)
         if self._fwd_rows:
             if self.stacked:        # two entries (half-batches) per layer: their losses add up
                 self.loss_now.zero_()
@@ -993,23 +845,13 @@ class PleasFitter:
             else:
                 self.loss_now.index_copy_(0, self._fwd_index, self._fwd_loss)
         self._finish_vendor_parts()
-        two = self.wgrad_b is not None and self._bucket_cut > 0
-        cut = self._bucket_cut
-        pending = [None, None]
         if replay is not None:
             with self.ops.pin_stream():
                 self.wgrad.relaunch()
-                if two:
-                    pending[0] = dp_sum_async_(self._g_ext[:cut], self.world, cut / self._g_ext.numel())
-                    self.wgrad_b.relaunch()
         else:
-            n_wgrad = len(self.wgrad._keep) + (len(self.wgrad_b._keep) if two else 0)
-            n_b = len(self.wgrad_b._keep) if two else 0
-            self.wgrad.flush()  # ONE grouped MFMA launch: weight gradients of every merged layer (of bucket 0)
-            if two:
-                pending[0] = dp_sum_async_(self._g_ext[:cut], self.world, cut / self._g_ext.numel())
-                self.wgrad_b.flush()
-            if complete and not vendor_rows and n_wgrad > 0 and (not two or n_b > 0):
+            n_wgrad = len(self.wgrad._keep)
+            self.wgrad.flush()  # ONE grouped MFMA launch: weight gradients of every merged layer
+            if complete and n_wgrad > 0:
                 names = tuple(self.plans[i].name for i in self._fwd_rows)
                 merge_tab, fwd_tab = self.merge.table(), self.fwd.table()
                 if merge_tab is not None and fwd_tab is not None and len(merge_tab) == len(fwd_tab) == len(names):
@@ -1018,14 +860,7 @@ class PleasFitter:
             self.g.add_(self.g2)     # second half-batch's gradients (same launch, own arena)
         lr = self.lrs[min(self.step_count, len(self.lrs) - 1)]
         self.step_count += 1
-        if two:
-            pending[1] = dp_sum_async_(self._g_ext[cut:], self.world, 1.0 - cut / self._g_ext.numel())   # + the losses
-            for half, sl in enumerate((slice(0, cut), slice(cut, None))):
-                if pending[half] is not None:
-                    pending[half].wait()
-                self.ops.masked_adam(self.p[sl], self.g[sl], self.mask[sl], self.m[sl], self.v[sl], lr, self.step_count)
-            self.loss_sum.add_(self.loss_now)
-        elif self.shard_optimizer:
+        if self.shard_optimizer:
             lo, hi = self.rank * self._shard, (self.rank + 1) * self._shard
             g_mine = dp_reduce_scatter_(self.g, self._g_shard, self.rank, self.world)
             dp_sum_(self.loss_now, self.world)
@@ -1033,7 +868,7 @@ class PleasFitter:
             self.ops.masked_adam(self.p[lo:hi], g_mine, self.mask[lo:hi], self.m, self.v, lr, self.step_count)
             dp_all_gather_(self.p, self.rank, self.world)
         else:
-            dp_sum_(self._g_ext, self.world)     # gradients + losses
+            dp_sum_(self._g_ext, self.world)     # gradients + losses: ONE collective per update
             self.loss_sum.add_(self.loss_now)
             self.ops.masked_adam(self.p, self.g, self.mask, self.m, self.v, lr, self.step_count)
         self._end_update()

@@ -23,7 +23,7 @@ def _batches(t):
     return [x + 0.01 * i for i, x in enumerate(xs)][:N_UPDATES]
 
 
-def _job(t, data_parallel, buckets=1, shard=False):
+def _job(t, data_parallel, shard=False):
     from pleas.methods.activation_matching import activation_matching
     from pleas.methods.partial_matching import partial_merge
     from pleas.methods.pleas_merging import PleasFitter
@@ -33,7 +33,7 @@ def _job(t, data_parallel, buckets=1, shard=False):
     m3 = partial_merge(t.spec, m1, m2, perm, costs, 0.5)
     merged_stem = m3.state_dict()["conv1.weight"].detach().cpu().clone()
     fit = PleasFitter(m1, m2, m3, t.spec, perm, costs, 0.5, N_UPDATES - 1, num_classes=10, data_parallel=data_parallel,
-                      grad_buckets=buckets, shard_optimizer=shard)
+                      shard_optimizer=shard)
     assert fit.shard_optimizer == (shard and fit.world > 1) and fit.m.numel() * (fit.world if fit.shard_optimizer else 1) == fit.p.numel()
     assert list(fit.steps(_batches(t))) == list(range(N_UPDATES))
     loss = fit.loss_sum.clone()
@@ -85,7 +85,7 @@ def _worker(rank, world, port, q, buckets):
         elif buckets == "shard":
             perm, costs, sd, loss, world = _job(Tiny("tiny_bottleneck.npz"), data_parallel=True, shard=True)
         else:
-            perm, costs, sd, loss, world = _job(Tiny("tiny_bottleneck.npz"), data_parallel=True, buckets=buckets)
+            perm, costs, sd, loss, world = _job(Tiny("tiny_bottleneck.npz"), data_parallel=True)
         as_np = lambda d: {k: v.numpy() for k, v in d.items()}   # plain arrays: nothing shared with a process that exits
         q.put((rank, (as_np(perm), as_np(costs), as_np(sd), loss.numpy(), world)))
     finally:
@@ -97,8 +97,8 @@ def _rel(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
 
 
-@pytest.mark.parametrize("buckets", [1, 2, "shard"])     # one all-reduce per update / two halves, each started early /
-def test_two_rank_job_equals_single_process_job(tiny_bottleneck, buckets):    # reduce-scatter + sharded Adam + all-gather
+@pytest.mark.parametrize("buckets", [1, "shard"])     # one all-reduce per update / reduce-scatter + sharded Adam + all-gather
+def test_two_rank_job_equals_single_process_job(tiny_bottleneck, buckets):
     want_perm, want_costs, want_sd, want_loss, world1 = _job(tiny_bottleneck, data_parallel=False)
     assert world1 == 1
     ctx = mp.get_context("spawn")

@@ -393,6 +393,48 @@ def test_gram_batch_derived_affine_nodes_match_contracted_ones(ops, epi):
         derived.add_derived(0, sx, tx, sy, ty, 0)      # nothing queued yet after the flush
 
 
+@pytest.mark.parametrize("shape", [(16, 1024, 14, 14), (16, 2048, 7, 7)])
+def test_gram_batch_derived_train_mode_batchnorm_at_full_width(ops, shape):
+    """The reduce pass's derived branch at the widths of ResNet-101's layer3 / layer4 residual streams, fed the way the
+    drivers' mode feeds it (no .eval() before activation_matching, run_domainnet.py:172-186): the per-batch statistics of
+    a TRAIN-mode BatchNorm2d folded on the device (``bn_train_fold``) are the affine map of the derived node.  Against
+    fp64: -cdist of the two train-mode BatchNorm outputs (reference activation_matching.py:31-46), and against the same
+    launch contracting those outputs."""
+    import torch.nn.functional as F
+
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(C)
+    x = torch.relu(torch.randn(shape, generator=g) * 1.3 + 0.4) * (0.5 + torch.rand(1, C, 1, 1, generator=g))
+    y = torch.relu(torch.randn(shape, generator=g) * 0.9 + 0.2) * (0.5 + torch.rand(1, C, 1, 1, generator=g))
+    bns = []
+    for _ in range(2):
+        bn = torch.nn.BatchNorm2d(C).train()
+        with torch.no_grad():
+            bn.weight.copy_(0.5 + torch.rand(C, generator=g))
+            bn.bias.copy_(0.3 * torch.randn(C, generator=g))
+        bns.append(bn)
+    want = []
+    for t, bn in zip((x, y), bns):
+        want.append(F.batch_norm(t.double(), None, None, bn.weight.double(), bn.bias.double(), True, 0.0, bn.eps))
+    a = want[0].movedim(1, 0).reshape(C, -1)
+    b = want[1].movedim(1, 0).reshape(C, -1)
+    ref = -torch.cdist(a, b)
+    xg, yg = x.cuda(), y.cuda()
+    gbn = [copy_bn.cuda() for copy_bn in bns]
+    (sx, tx), (sy, ty) = ops.bn_train_fold(gbn[0], xg), ops.bn_train_fold(gbn[1], yg)
+    mats = [torch.zeros(C, C, device="cuda") for _ in range(3)]
+    batch = ops.GramBatch(mats, ops.EPI_NEG_CDIST)
+    src = batch.add(xg, yg, 1, 0)
+    batch.add_derived(src, sx, tx, sy, ty, 1)                                      # derived in the reduce pass
+    view = (1, C, 1, 1)
+    batch.add(xg * sx.view(view) + tx.view(view), yg * sy.view(view) + ty.view(view), 1, 2)   # the same tensors, contracted
+    batch.flush(accumulate=False)
+    derived, contracted = _rel(mats[1], ref), _rel(mats[2], ref)
+    print("C = %d: derived %.2e, contracted %.2e vs fp64" % (C, derived, contracted))
+    assert derived < max(3 * contracted, 2e-6), (derived, contracted)
+    assert int(gbn[0].num_batches_tracked) == 1
+
+
 def test_gram_batch_deterministic_and_overwrite(ops):
     x, y = torch.randn(8, 256, 14, 14).cuda(), torch.randn(8, 256, 14, 14).cuda()
     outs = []
@@ -710,3 +752,60 @@ def test_fwd_batch_flat_forms_random_geometries(ops):
     for i, (keep, want, want_loss, geo) in enumerate(cases):
         assert _rel(keep[7].cpu(), want) < 5e-6, (geo, _rel(keep[7].cpu(), want))
         assert abs(float(loss[i]) - want_loss) < 1e-5 * max(1.0, want_loss), geo
+
+
+# ------------------------------------------------------------------------------------------ exchange step through the C-ABI
+_ALLREDUCE_CHILD = r"""
+import ctypes, sys, time
+sys.path.insert(0, %r)
+import torch
+from pleas_merging_amd import _lib
+
+class UniqueId(ctypes.Structure):
+    _fields_ = [("internal", ctypes.c_char * 128)]
+
+torch.cuda.set_device(0)
+torch.zeros(1, device="cuda")
+rccl = None
+for name in ("librccl.so.1", "/opt/rocm/lib/librccl.so.1"):
+    try:
+        rccl = ctypes.CDLL(name, mode=ctypes.RTLD_GLOBAL)      # the instance pleas_allreduce_sum will find in the process
+        break
+    except OSError:
+        pass
+assert rccl is not None, "no RCCL on this box"
+uid, comm = UniqueId(), ctypes.c_void_p()
+rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0      # a ONE-rank communicator: all one GPU allows
+lib = _lib.lib()
+n = 10317824                                                            # ResNet-101's cost arena: 71 group matrices, 41 MB
+buf = torch.randn(n, device="cuda")
+keep = buf.clone()
+stream = torch.cuda.current_stream().cuda_stream
+assert lib.pleas_allreduce_sum(buf.data_ptr(), n, comm, stream) == 0, lib.pleas_last_error()
+torch.cuda.synchronize()
+assert torch.equal(buf, keep)                                           # a sum over one rank is the identity
+t0 = time.perf_counter()
+for _ in range(10):
+    assert lib.pleas_allreduce_sum(buf.data_ptr(), n, comm, stream) == 0
+torch.cuda.synchronize()
+print("ALLREDUCE_OK %%.1f us per call" %% ((time.perf_counter() - t0) / 10 * 1e6))
+assert lib.pleas_allreduce_sum(buf.data_ptr(), 0, comm, stream) == 0 and lib.pleas_allreduce_sum(None, 4, comm, stream) == -22
+rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+rccl.ncclCommDestroy(comm)
+"""
+
+
+def test_allreduce_sum_entry_point_on_a_one_rank_rccl_communicator():
+    """``pleas_allreduce_sum(buf, n, ncclComm_t, stream)`` -- the exchange step for consumers of the
+    C-ABI that are not under torch.distributed.  A one-rank RCCL communicator made with RCCL's own API (ncclGetUniqueId /
+    ncclCommInitRank), the 41 MB cost arena, in place; own process, so that a stuck communicator cannot hang the suite."""
+    import subprocess
+    import sys
+
+    from conftest import REPO
+
+    out = subprocess.run([sys.executable, "-c", _ALLREDUCE_CHILD % REPO], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ALLREDUCE_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+    print(out.stdout.strip().splitlines()[-1])
