@@ -265,6 +265,12 @@ size_t pleas_fwd_batch_ws_bytes(const pleas_fwd_layer* layers, int n_layers);
  * the plan's calibration launch [ms] (0 before it), the lane it runs on (0 = the caller's stream) and its work items.
  * Returns 0 = lanes still dealt from static weights, 1 = calibration launch in flight, 2 = lanes dealt from measurements. */
 int pleas_fwd_plan_lanes(double* form_ms, int* form_lane, int* form_items);
+/* Host only (no GPU): the launch units of the grouped forward of `layers` -- one kernel launch each: a tile form over a
+ * contiguous slice of that form's work items, on a lane -- as 4 ints per unit (form, first item, items, lane) in launch
+ * order.  form_ms == NULL: the units of a fresh plan (one per form, lanes from static weights); else the units after a
+ * calibration launch that measured form_ms[10] milliseconds per form (long forms cut into slices of equal work).
+ * Returns the number of units (> max_units: only the first max_units were written) or a negative error code. */
+int pleas_fwd_plan_units(const pleas_fwd_layer* layers, int n_layers, const double* form_ms, int* units, int max_units);
 int pleas_fwd_batch(const pleas_fwd_layer* layers, int n_layers, float* loss, void* ws, size_t ws_bytes, int ws_fresh,
                     void* stream);
 

@@ -41,18 +41,25 @@ struct WgradLayerDev {
     int Cout, Cin, Hin, Win, Hout, Wout, KH, KW, stride, pad;
     uint32_t HWo, Ktot;  // Ktot = N * HWo
     int S;
-    int variant;         // bit0: TM==64, bit1: TN==64, bit2: X scalar loads, bit3: Y shifted (scalar) loader
+    int variant;         // bit0: TM==64, bit1: TN==64, bit2: X scalar loads, bit3: Y shifted (scalar) loader,
+                         // bit4: Y shifted through aligned 16-byte loads (stride-1 "same" layers; X carries the border mask)
     int flags;           // PLEAS_WGRAD_ACCUMULATE | PLEAS_WGRAD_KPOS_MAJOR
-    int pad0;
+    int total;           // floats in ip (bit4 form: clamps the shifted operand's loads)
 };
 struct WgradItemDev {
     int layer, tm, tn, r, split, c_begin, c_end, pad;
 };
 
-template <int TM, int TN, int VECX, bool YSHIFT>
+// YMODE: 0 = Y read in place (1x1, stride 1), 1 = shifted / strided view, one pixel per load, 2 = stride-1 "same" layer
+// with HW % 4 == 0: tap r reads the SAME flat pixel run `delta = dh * W + dw` further on, so a thread's four pixels come
+// from two aligned 16-byte loads and a wave-uniform register shift; nothing of Y is masked -- the taps that fall off the
+// image are voided by zeroing the RESIDUAL at those output pixels (a rectangle of (oh, ow)) when it is staged.
+template <int TM, int TN, int VECX, int YMODE>
 __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradItemDev& it, float* smem) {
     constexpr int MTM = TM / 64, MTN = TN / 64;
-    constexpr int VECY = YSHIFT ? 1 : VECX;
+    constexpr bool YSHIFT = YMODE == 1;
+    constexpr int VECY = YMODE == 1 ? 1 : (YMODE == 2 ? 4 : VECX);
+    static_assert(YMODE != 2 || VECX == 4, "the 16-byte shifted form needs HW % 4 == 0, hence vector loads of X too");
     constexpr int LPR_X = cBK / VECX, RPP_X = cThreads / LPR_X, PASS_X = TM / RPP_X;
     constexpr int LPR_Y = cBK / VECY, RPP_Y = cThreads / LPR_Y, PASS_Y = TN / RPP_Y;
     float* As = smem;                    // [2][TM][cLds]
@@ -67,7 +74,11 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradIt
     const int xrow = tid / LPR_X, xcol = (tid % LPR_X) * VECX;
     const int yrow = tid / LPR_Y, ycol = (tid % LPR_Y) * VECY;
     float rx[PASS_X][VECX], ry[PASS_Y][VECY];
+    f32x4 ry1[YMODE == 2 ? PASS_Y : 1];   // YMODE 2: the second aligned group of every row
     unsigned okx = 0, oky = 0;
+    unsigned win = 0xFu;                  // YMODE 2: bit e = output pixel e of this thread's run has tap r inside the image
+    const int delta = dh * L.Win + dw, sh = ((delta % 4) + 4) % 4;      // YMODE 2 (wave-uniform)
+    const int oh0 = max(0, -dh), oh1 = L.Hout - 1 - max(0, dh), ow0 = max(0, -dw), ow1 = L.Wout - 1 - max(0, dw);
     uint32_t offx[PASS_X], offy[PASS_Y];  // < 2^32: one sample's C*HW slab
 #pragma unroll
     for (int q = 0; q < PASS_X; ++q) {
@@ -97,6 +108,15 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradIt
             const uint32_t n = kinx ? P / L.HWo : 0u;
             const uint32_t p = kinx ? P - n * L.HWo : 0u;
             const size_t base = (size_t)n * L.Cout * L.HWo + p;
+            if constexpr (YMODE == 2) {
+                int oh = (int)(p / (uint32_t)L.Wout), ow = (int)(p - (uint32_t)oh * L.Wout);
+                win = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (oh >= oh0 && oh <= oh1 && ow >= ow0 && ow <= ow1) win |= 1u << e;
+                    if (++ow == L.Wout) { ow = 0; ++oh; }
+                }
+            }
 #pragma unroll
             for (int q = 0; q < PASS_X; ++q) {
                 if constexpr (VECX == 4) {
@@ -123,6 +143,19 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradIt
                 base = (size_t)n * L.Cin * HWi + p;
             }
             kiny = in;
+            if constexpr (YMODE == 2) {
+                // each aligned group clamped on its own: whatever lies outside the tensor lies outside its image, i.e. at
+                // an output pixel whose residual is zeroed
+                const int b0 = (int)base + delta - sh;
+#pragma unroll
+                for (int q = 0; q < PASS_Y; ++q) {
+                    const int g0 = min(max(b0 + (int)offy[q], 0), L.total - 4), g1 = min(max(b0 + (int)offy[q] + 4, 0), L.total - 4);
+                    const f32x4 v0 = *(const __attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL(L.ip) + g0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ry[q][e] = v0[e];
+                    if (sh) ry1[q] = *(const __attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL(L.ip) + g1);
+                }
+            } else
 #pragma unroll
             for (int q = 0; q < PASS_Y; ++q) {
                 if constexpr (VECY == 4) {
@@ -143,7 +176,8 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradIt
             const bool ok = kinx && ((okx >> q) & 1u);
             const int row = xrow + q * RPP_X;
             if constexpr (VECX == 4) {
-                f32x4 v = {ok ? rx[q][0] : 0.f, ok ? rx[q][1] : 0.f, ok ? rx[q][2] : 0.f, ok ? rx[q][3] : 0.f};
+                f32x4 v = {(ok && (win & 1u)) ? rx[q][0] : 0.f, (ok && (win & 2u)) ? rx[q][1] : 0.f,
+                           (ok && (win & 4u)) ? rx[q][2] : 0.f, (ok && (win & 8u)) ? rx[q][3] : 0.f};
                 *reinterpret_cast<f32x4*>(a + row * cLds + xcol) = v;
             } else {
                 a[row * cLds + xcol] = ok ? rx[q][0] : 0.f;
@@ -153,7 +187,17 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradIt
         for (int q = 0; q < PASS_Y; ++q) {
             const bool ok = kiny && ((oky >> q) & 1u);
             const int row = yrow + q * RPP_Y;
-            if constexpr (VECY == 4) {
+            if constexpr (YMODE == 2) {
+                f32x4 v;
+                switch (sh) {       // wave-uniform
+                    case 0: v = f32x4{ry[q][0], ry[q][1], ry[q][2], ry[q][3]}; break;
+                    case 1: v = f32x4{ry[q][1], ry[q][2], ry[q][3], ry1[q][0]}; break;
+                    case 2: v = f32x4{ry[q][2], ry[q][3], ry1[q][0], ry1[q][1]}; break;
+                    default: v = f32x4{ry[q][3], ry1[q][0], ry1[q][1], ry1[q][2]}; break;
+                }
+                if (!((oky >> q) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(b + row * cLds + ycol) = v;
+            } else if constexpr (VECY == 4) {
                 f32x4 v = {ok ? ry[q][0] : 0.f, ok ? ry[q][1] : 0.f, ok ? ry[q][2] : 0.f, ok ? ry[q][3] : 0.f};
                 *reinterpret_cast<f32x4*>(b + row * cLds + ycol) = v;
             } else {
@@ -223,10 +267,11 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradIt
 template <int TM, int TN>
 __device__ __forceinline__ void wgrad_dispatch(const WgradLayerDev& L, const WgradItemDev& it, float* smem) {
     const bool xs = L.variant & 4, ys = L.variant & 8;
-    if (!xs && !ys) wgrad_tile<TM, TN, 4, false>(L, it, smem);
-    else if (!xs && ys) wgrad_tile<TM, TN, 4, true>(L, it, smem);
-    else if (xs && !ys) wgrad_tile<TM, TN, 1, false>(L, it, smem);
-    else wgrad_tile<TM, TN, 1, true>(L, it, smem);
+    if (L.variant & 16) wgrad_tile<TM, TN, 4, 2>(L, it, smem);
+    else if (!xs && !ys) wgrad_tile<TM, TN, 4, 0>(L, it, smem);
+    else if (!xs && ys) wgrad_tile<TM, TN, 4, 1>(L, it, smem);
+    else if (xs && !ys) wgrad_tile<TM, TN, 1, 0>(L, it, smem);
+    else wgrad_tile<TM, TN, 1, 1>(L, it, smem);
 }
 
 __global__ __launch_bounds__(cThreads, 2) void wgrad_batch_kernel(const WgradLayerDev* __restrict__ layers,
@@ -413,7 +458,16 @@ static int build_wgrad_plan(WgradPlan& P, const pleas_wgrad_layer* ly, int n) {
         const bool xvec = HWo % 4 == 0;
         // direct Y shares X's vector width, so it also needs HWi == HWo (true for 1x1 stride 1)
         d.variant = (TM == 64 ? 1 : 0) | (TN == 64 ? 2 : 0) | (xvec ? 0 : 4) | (ydirect ? 0 : 8);
-        (void)HWi;
+        // stride-1 "same" k x k layers on images with HW % 4 == 0: the shifted operand comes through aligned 16-byte loads
+        // (PLEAS_WGRAD_VECSHIFT=0 keeps the one-pixel-per-load form for A/B)
+        static const bool vecshift = !(std::getenv("PLEAS_WGRAD_VECSHIFT") && std::atoi(std::getenv("PLEAS_WGRAD_VECSHIFT")) == 0);
+        const int64_t total = (int64_t)l.N * l.Cin * HWi;
+        d.total = 0;
+        if (vecshift && !ydirect && xvec && l.stride == 1 && l.KH == l.KW && 2 * l.pad == l.KH - 1 && HWi == HWo &&
+            total < (1ll << 31)) {
+            d.variant |= 16;
+            d.total = (int)total;
+        }
         const int nchunks = (int)ceil_div(K, cBK);
         const int S = (int)ceil_div(nchunks, g_wgrad_item_chunks);
         const int cps = (int)ceil_div(nchunks, S);

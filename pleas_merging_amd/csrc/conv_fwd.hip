@@ -702,7 +702,7 @@ constexpr int fLanes = 3;          // side streams (+ the caller's stream = four
 struct FwdSideStreams {
     hipStream_t streams[fLanes];
     hipEvent_t forked, joined[fLanes];
-    hipEvent_t t0[10], t1[10];     // per form: around its kernel, on its lane (one calibration launch per plan)
+    hipEvent_t t0[24], t1[24];     // per launch unit: around its kernel, on its lane (one calibration launch per plan)
     bool ok = false, timed = false;
 };
 static FwdSideStreams& fwd_side_streams() {
@@ -724,7 +724,7 @@ static FwdSideStreams& fwd_side_streams() {
                  hipEventCreateWithFlags(&s.joined[i], hipEventDisableTiming) == hipSuccess;
         s.ok = ok;
         bool timed = ok;
-        for (int f = 0; timed && f < 10; ++f)
+        for (int f = 0; timed && f < 24; ++f)
             timed = hipEventCreate(&s.t0[f]) == hipSuccess && hipEventCreate(&s.t1[f]) == hipSuccess;
         s.timed = timed;
     }
@@ -784,50 +784,83 @@ struct FwdPlan {
     std::vector<FwdItemDev> items;
     std::vector<FwdLossDev> loss;
     size_t off_layers = 0, off_items = 0, off_loss = 0, off_parts = 0, total = 0;
-    int form_begin[fForms] = {0}, form_count[fForms] = {0}, form_order[fForms] = {0}, form_lane[fForms] = {0};
+    int form_begin[fForms] = {0}, form_count[fForms] = {0};
     size_t form_lds[fForms] = {0};
+    std::vector<float> item_work;      // per item (aligned with `items`): relative duration, 0 for padding
+    // A launch UNIT is a form's kernel over a contiguous slice of the form's items.  At first every form is one unit; after
+    // the calibration launch a form that alone would outlast a lane's fair share is cut into slices of equal work.
+    struct Unit { int form, begin, count, lane; double ms; };
+    std::vector<Unit> units;           // in launch order (longest first)
     double flops = 0, bytes = 0;
     int n_parts = 0;
     bool uploaded = false;
     // lanes from MEASURED durations: launch kCalibAt of a plan brackets every form's kernel with events on its lane; a
     // later launch that finds them complete deals the forms again, longest measured duration first
     int launches = 0, calib = 0;       // calib: 0 not measured yet, 1 events recorded, 2 lanes dealt from measurements
-    double form_ms[fForms] = {0};
 };
+constexpr int fMaxUnits = 24;
 static PlanCache<FwdPlan, 1> g_fplans;
 constexpr int kCalibAt = 3;
 // measured durations per layer-list geometry (the plan key without its workspace address): a new fitter on the same
 // layers -- every job of a bench run -- starts from the lanes the previous one measured
-static std::vector<std::pair<std::vector<int64_t>, std::vector<double>>> g_fcalib;
+static std::vector<std::pair<std::vector<int64_t>, std::vector<FwdPlan::Unit>>> g_fcalib;
 static std::vector<int64_t> fwd_geometry_key(const std::vector<int64_t>& key) {
     std::vector<int64_t> g(key);
     if (g.size() > 1) g[1] = 0;      // key[1] is the workspace address
     return g;
 }
 
-// longest-processing-time first: the form with the most work keeps the caller's stream (lane 0) and is launched first,
-// every other form goes to the lane that is least loaded so far
-static void fwd_deal_lanes(FwdPlan& P, const double* work) {
-    for (int f = 0; f < fForms; ++f) P.form_order[f] = f;
-    std::stable_sort(P.form_order, P.form_order + fForms, [&](int a, int b) { return work[a] > work[b]; });
+// longest-processing-time first over the units' expected durations: the longest unit keeps the caller's stream (lane 0) and
+// is launched first, every other unit goes to the lane that is least loaded so far
+static void fwd_deal_lanes(FwdPlan& P) {
+    std::stable_sort(P.units.begin(), P.units.end(), [](const FwdPlan::Unit& a, const FwdPlan::Unit& b) { return a.ms > b.ms; });
     double load[fLanes + 1] = {0};
-    for (int o = 0; o < fForms; ++o) {
-        const int f = P.form_order[o];
-        if (P.form_count[f] == 0) continue;
+    for (size_t o = 0; o < P.units.size(); ++o) {
         int best = 0;
         for (int l = 1; l <= fLanes; ++l)
             if (load[l] < load[best]) best = l;
         if (o == 0) best = 0;
-        P.form_lane[f] = best;
-        load[best] += work[f];
+        P.units[o].lane = best;
+        load[best] += P.units[o].ms;
     }
 }
+// after the calibration launch: a unit that takes more than 0.7 of a lane's fair share of the measured total is cut into
+// slices of (nearly) equal WORK -- items are sorted longest first, so equal counts would not do -- and the lanes are dealt
+// again.  A 1x1 form with 20 000 short items then fills two or three lanes instead of bounding the whole group.
+static void fwd_split_units(FwdPlan& P) {
+    double total = 0;
+    for (const auto& u : P.units) total += u.ms;
+    const double fair = total / (fLanes + 1);
+    std::vector<FwdPlan::Unit> out;
+    for (size_t ui = 0; ui < P.units.size(); ++ui) {
+        const FwdPlan::Unit u = P.units[ui];
+        int parts = (u.ms > 0.7 * fair && u.count >= 64) ? (int)std::min<double>(4.0, std::ceil(u.ms / (0.45 * fair))) : 1;
+        const int room = fMaxUnits - (int)out.size() - (int)(P.units.size() - ui - 1);   // every later unit needs one slot
+        parts = std::max(1, std::min(parts, room));
+        if (parts <= 1) { out.push_back(u); continue; }
+        double work = 0;
+        for (int i = 0; i < u.count; ++i) work += P.item_work[u.begin + i];
+        int begin = u.begin;
+        double acc = 0;
+        for (int k = 0; k < parts; ++k) {
+            const double upto = work * (k + 1) / parts;
+            int end = begin;
+            while (end < u.begin + u.count && (k == parts - 1 || acc + P.item_work[end] <= upto)) acc += P.item_work[end++];
+            if (end == begin && end < u.begin + u.count) acc += P.item_work[end++];
+            if (end > begin) out.push_back(FwdPlan::Unit{u.form, begin, end - begin, 0, u.ms / parts});
+            begin = end;
+        }
+    }
+    P.units.swap(out);
+}
+
 static std::mutex g_fplan_mu;
 static size_t falign(size_t v) { return (v + 255) / 256 * 256; }
 
 static int build_fwd_plan(FwdPlan& P, const pleas_fwd_layer* ly, int n) {
     P.layers.assign(n, FwdLayerDev());
     P.items.clear();
+    for (int f = 0; f < fForms; ++f) P.form_begin[f] = P.form_count[f] = 0;
     P.loss.assign(n, FwdLossDev());
     P.flops = P.bytes = 0;
     std::vector<XcdWork<FwdItemDev>> work[fForms];
@@ -928,16 +961,25 @@ static int build_fwd_plan(FwdPlan& P, const pleas_fwd_layer* ly, int n) {
         }
         P.items.insert(P.items.end(), part.begin(), part.end());
         P.form_count[f] = (int)part.size();
-        P.form_order[f] = f;
     }
+    P.item_work.assign(P.items.size(), 0.f);
+    for (size_t k = 0; k < P.items.size(); ++k)
+        if (P.items[k].layer >= 0) {
+            const FwdLayerDev& d = P.layers[P.items[k].layer];
+            P.item_work[k] = (float)(ceil_div(d.Kd, fBK) * ((d.variant & 1) ? 64 : 128));
+        }
     // launch order: the form with the most work first (its tail is then covered by nothing, the small ones' tails are short)
     // Expected duration of a form relative to its MFMA work (measured on the ResNet-101 list, each form alone): the
     // general tile (stride-2 layers: few, long items; stem: scalar weight loads) runs at ~0.4x the flat forms' rate, the
     // scalar-pixel 1x1 form (7x7 images) at ~0.5x.
     // These static weights deal the FIRST launches of a plan only; launch kCalibAt measures every form on its lane and the
     // lanes are dealt again from those durations (pleas_fwd_batch).
-    for (int f = 0; f < fForms; ++f) form_work[f] *= f < 4 ? 2.5 : ((f == 5 || f == 8) ? 2.0 : 1.0);
-    fwd_deal_lanes(P, form_work);
+    P.units.clear();
+    for (int f = 0; f < fForms; ++f)
+        if (P.form_count[f] > 0)
+            P.units.push_back(FwdPlan::Unit{f, P.form_begin[f], P.form_count[f], 0,
+                                            form_work[f] * (f < 4 ? 2.5 : ((f == 5 || f == 8) ? 2.0 : 1.0))});
+    fwd_deal_lanes(P);
     P.launches = P.calib = 0;
     P.n_parts = parts;
     size_t off = 0;
@@ -970,11 +1012,35 @@ extern "C" int pleas_fwd_plan_lanes(double* form_ms, int* form_lane, int* form_i
     if (!g_fplans.last) return bad_arg("fwd_plan_lanes: no grouped forward has run yet");
     const FwdPlan& P = *g_fplans.last;
     for (int f = 0; f < fForms; ++f) {
-        form_ms[f] = P.form_ms[f];
-        form_lane[f] = P.form_lane[f];
+        form_ms[f] = 0;
+        form_lane[f] = 0;
         form_items[f] = P.form_count[f];
     }
+    for (const auto& u : P.units) {      // a form cut into slices: summed duration, lanes as decimal digits (lane + 1 each)
+        form_ms[u.form] += u.ms;
+        form_lane[u.form] = form_lane[u.form] * 10 + u.lane + 1;
+    }
     return P.calib;
+}
+
+extern "C" int pleas_fwd_plan_units(const pleas_fwd_layer* layers, int n_layers, const double* form_ms, int* units, int max_units) {
+    if (!layers || n_layers <= 0 || !units || max_units <= 0) return bad_arg("fwd_plan_units: empty layer list / null output");
+    FwdPlan tmp;
+    const int rc = build_fwd_plan(tmp, layers, n_layers);
+    if (rc != PLEAS_OK) return rc;
+    if (form_ms) {       // as if the calibration launch had measured these per-form durations
+        for (auto& u : tmp.units) u.ms = form_ms[u.form];
+        fwd_split_units(tmp);
+        fwd_deal_lanes(tmp);
+    }
+    const int n = (int)std::min<size_t>(tmp.units.size(), (size_t)max_units);
+    for (int i = 0; i < n; ++i) {
+        units[4 * i + 0] = tmp.units[i].form;
+        units[4 * i + 1] = tmp.units[i].begin;
+        units[4 * i + 2] = tmp.units[i].count;
+        units[4 * i + 3] = tmp.units[i].lane;
+    }
+    return (int)tmp.units.size();
 }
 
 extern "C" size_t pleas_fwd_batch_ws_bytes(const pleas_fwd_layer* layers, int n_layers) {
@@ -1020,8 +1086,7 @@ extern "C" int pleas_fwd_batch(const pleas_fwd_layer* layers, int n_layers, floa
         const std::vector<int64_t> geo = fwd_geometry_key(P.key);
         for (const auto& kv : g_fcalib)
             if (kv.first == geo) {
-                std::copy(kv.second.begin(), kv.second.end(), P.form_ms);
-                fwd_deal_lanes(P, P.form_ms);
+                P.units = kv.second;
                 P.calib = 2;
             }
     }
@@ -1068,48 +1133,47 @@ extern "C" int pleas_fwd_batch(const pleas_fwd_layer* layers, int n_layers, floa
         const FwdItemDev* items = reinterpret_cast<const FwdItemDev*>(base + P.off_items);
         FwdSideStreams& side = fwd_side_streams();
         static const bool serial = std::getenv("PLEAS_FWD_SERIAL") && std::atoi(std::getenv("PLEAS_FWD_SERIAL")) != 0;
-        int active = 0;
-        for (int f = 0; f < fForms; ++f) active += P.form_count[f] > 0;
+        const int active = (int)P.units.size();
         const bool fork = !serial && active > 1 && side.ok;
         static const bool calibrate = !(std::getenv("PLEAS_FWD_CALIBRATE") && std::atoi(std::getenv("PLEAS_FWD_CALIBRATE")) == 0);
         ++P.launches;
-        if (P.calib == 1) {          // the calibration launch's events: all complete?  then deal the lanes from them
+        if (P.calib == 1) {          // the calibration launch's events: all complete?  then cut long units and deal the lanes
             bool ready = true;
-            for (int f = 0; ready && f < fForms; ++f)
-                if (P.form_count[f] > 0) ready = hipEventQuery(side.t1[f]) == hipSuccess;
+            for (int u = 0; ready && u < active; ++u) ready = hipEventQuery(side.t1[u]) == hipSuccess;
             if (ready) {
-                for (int f = 0; f < fForms; ++f) {
+                for (int u = 0; u < active; ++u) {
                     float ms = 0.f;
-                    P.form_ms[f] = (P.form_count[f] > 0 && hipEventElapsedTime(&ms, side.t0[f], side.t1[f]) == hipSuccess) ? ms : 0.0;
+                    P.units[u].ms = hipEventElapsedTime(&ms, side.t0[u], side.t1[u]) == hipSuccess ? ms : 0.0;
                 }
-                fwd_deal_lanes(P, P.form_ms);
+                fwd_split_units(P);
+                fwd_deal_lanes(P);
                 P.calib = 2;
                 if (g_fcalib.size() >= 16) g_fcalib.erase(g_fcalib.begin());
-                g_fcalib.emplace_back(fwd_geometry_key(P.key), std::vector<double>(P.form_ms, P.form_ms + fForms));
+                g_fcalib.emplace_back(fwd_geometry_key(P.key), P.units);
             }
             (void)hipGetLastError();   // hipEventQuery's "not ready" is not an error of this call
         }
-        const bool measure = fork && calibrate && side.timed && P.calib == 0 && P.launches == kCalibAt;
+        const bool measure = fork && calibrate && side.timed && P.calib == 0 && P.launches == kCalibAt && active <= fMaxUnits;
         if (fork) PLEAS_HIP_CHECK(hipEventRecord(side.forked, stream));
         bool lane_used[fLanes + 1] = {false};
-        for (int o = 0; o < fForms; ++o) {
-            const int f = P.form_order[o];
-            if (P.form_count[f] == 0) continue;
-            const int lane = fork ? P.form_lane[f] : 0;          // lane 0 = the caller's stream
+        for (size_t o = 0; o < P.units.size(); ++o) {
+            const FwdPlan::Unit& un = P.units[o];
+            const int f = un.form;
+            const int lane = fork ? un.lane : 0;          // lane 0 = the caller's stream
             hipStream_t st = lane == 0 ? stream : side.streams[lane - 1];
             if (lane > 0 && !lane_used[lane]) PLEAS_HIP_CHECK(hipStreamWaitEvent(st, side.forked, 0));
             lane_used[lane] = true;
-            const dim3 grid((unsigned)P.form_count[f]);
-            const FwdItemDev* its = items + P.form_begin[f];
+            const dim3 grid((unsigned)un.count);
+            const FwdItemDev* its = items + un.begin;
             const size_t lds = P.form_lds[f];
-            if (measure) PLEAS_HIP_CHECK(hipEventRecord(side.t0[f], st));
+            if (measure) PLEAS_HIP_CHECK(hipEventRecord(side.t0[o], st));
             switch (f) {
 #define PLEAS_FWD_LAUNCH(F) case F: hipLaunchKernelGGL(fwd_batch_kernel<F>, grid, dim3(fThreads), lds, st, dl, its, parts); break
                 PLEAS_FWD_LAUNCH(0); PLEAS_FWD_LAUNCH(1); PLEAS_FWD_LAUNCH(2); PLEAS_FWD_LAUNCH(3); PLEAS_FWD_LAUNCH(4);
                 PLEAS_FWD_LAUNCH(5); PLEAS_FWD_LAUNCH(6); PLEAS_FWD_LAUNCH(7); PLEAS_FWD_LAUNCH(8); PLEAS_FWD_LAUNCH(9);
 #undef PLEAS_FWD_LAUNCH
             }
-            if (measure) PLEAS_HIP_CHECK(hipEventRecord(side.t1[f], st));
+            if (measure) PLEAS_HIP_CHECK(hipEventRecord(side.t1[o], st));
         }
         if (measure) P.calib = 1;
         for (int lane = 1; lane <= fLanes; ++lane)

@@ -192,12 +192,14 @@ class GramBatch:
         self._meta.append((B, C, HW, group, source))
         return len(self._keep) - 1
 
-    def flush(self, accumulate: bool = True, keep: bool = False) -> None:
-        """Contract everything added since the last flush.  ``keep=True`` leaves the node list in place: used when
-        the forward pass is a replayed hipGraph, whose activations are the same device tensors every batch."""
+    def flush(self, accumulate: bool = True, keep: bool = False, hold: bool = False):
+        """Contract everything added since the last flush.  ``keep=True`` leaves the node list in place (a caller that
+        contracts the same device tensors again).  ``hold=True`` returns the operand tensors instead of dropping them: a
+        caller that launches on ANOTHER stream than the one the operands were produced (and allocated) on keeps them alive
+        until that stream is done with them."""
         n = len(self._keep)
         if n == 0:
-            return
+            return [] if hold else None
         if self._arr is None or len(self._arr) != n:
             self._arr = (_lib.GramNode * n)()
         arr = self._arr
@@ -223,12 +225,13 @@ class GramBatch:
         self._fresh = 0
         if rc == -12:  # node list changed shape: size the workspace again
             self._ws = None
-            self.flush(accumulate, keep)
-            return
+            return self.flush(accumulate, keep, hold)
         check(rc, "pleas_gram_batch")
+        held = list(self._keep) if hold else None
         if not keep:
             self._keep.clear()
             self._meta.clear()
+        return held
 
     def drop(self) -> None:
         self._keep.clear()

@@ -23,30 +23,8 @@ _lib.LIB_PATH = sys.argv[1]
 lib = _lib.lib()
 
 
-def resnet_layers(arch):
-    """(Cout, Cin, H, W, k, stride, pad) of every Conv2d / the Linear head of a torchvision-style ResNet at 224 x 224."""
-    out = [(64, 3, 224, 224, 7, 2, 3)]
-    blocks = {"resnet18": (2, 2, 2, 2), "resnet50": (3, 4, 6, 3), "resnet101": (3, 4, 23, 3)}[arch]
-    bottleneck = arch != "resnet18"
-    cin, hw = 64, 56
-    for stage, nb in enumerate(blocks):
-        planes = 64 << stage
-        for b in range(nb):
-            stride = 2 if (b == 0 and stage > 0) else 1
-            if bottleneck:
-                out += [(planes, cin, hw, hw, 1, 1, 0), (planes, planes, hw, hw, 3, stride, 1),
-                        (planes * 4, planes, hw // stride, hw // stride, 1, 1, 0)]
-                if b == 0:
-                    out.append((planes * 4, cin, hw, hw, 1, stride, 0))
-                cin = planes * 4
-            else:
-                out += [(planes, cin, hw, hw, 3, stride, 1), (planes, planes, hw // stride, hw // stride, 3, 1, 1)]
-                if b == 0 and stage > 0:
-                    out.append((planes, cin, hw, hw, 1, stride, 0))
-                cin = planes
-            hw //= stride
-    out.append((1000, cin, 1, 1, 1, 1, 0))
-    return out
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from sanitize_driver_layers import resnet_layers  # noqa: E402
 
 
 def expect(cond, what):
@@ -93,6 +71,9 @@ def main():
         for N, widen in ((16, 1.0), (2, 1.0), (1, 1.0), (4, 1.5), (16, 2.0 - 1.0 / 64)):
             fwd, wg, neq, n = plan_lists(layers, N, widen)
             expect(lib.pleas_fwd_batch_ws_bytes(fwd, n) > 0, "fwd plan %s N=%d x%.2f" % (arch, N, widen))
+            units = (ctypes.c_int * 96)()
+            for ms in (None, (ctypes.c_double * 10)(1.8, 0.1, 0.1, 0.2, 2.6, 0.3, 1.6, 2.6, 0.2, 0.4), (ctypes.c_double * 10)(*([0.0] * 7 + [5.0, 0.0, 0.0]))):
+                expect(0 < lib.pleas_fwd_plan_units(fwd, n, ms, units, 24) <= 24, "fwd launch units " + arch)
             # the weight-gradient / normal-equation launches take layers with >= 16 input channels (the stem goes elsewhere)
             expect(lib.pleas_wgrad_batch_ws_bytes(ctypes.byref(wg, ctypes.sizeof(_lib.WgradLayer)), n - 1) > 0, "wgrad plan " + arch)
             expect(lib.pleas_normal_eq_ws_bytes(ctypes.byref(neq, ctypes.sizeof(_lib.NeqLayer)), n - 1) > 0, "neq plan " + arch)

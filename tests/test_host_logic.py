@@ -185,6 +185,47 @@ def test_normal_eq_plan_contracts_one_block_per_lag_class():
     assert lib.pleas_normal_eq_plan_info(None, 0, info) == -22 and lib.pleas_normal_eq_finalize(None, 0, None) == -22
 
 
+def test_forward_launch_units_partition_every_form():
+    """Host side of pleas_fwd_batch (no GPU): the grouped forward is launched as UNITS -- a tile form over a slice of its
+    items, on one of four lanes.  A fresh plan has one unit per form; after a calibration launch a form that outlasts a
+    lane's fair share is cut into slices of equal work.  Whatever the measured durations, the units must partition every
+    form's item range exactly (a missing or doubled slice would drop or repeat output tiles) and use lanes 0..3."""
+    from pleas_merging_amd import _lib
+
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from sanitize_driver_layers import resnet_layers
+
+    lib = _lib.lib()
+    layers = resnet_layers("resnet101")
+    arr = (_lib.FwdLayer * len(layers))()
+    for f, (co, ci, h, w, k, s_, p_) in zip(arr, layers):
+        f.N, f.Cout, f.Cin, f.Hin, f.Win, f.KH, f.KW, f.stride, f.pad = 16, co, ci, h, w, k, k, s_, p_
+        f.Csrc, f.n_merged, f.flags = co, co, (1 if (k > 1 and ci % 32 == 0) else 0)
+    units = (ctypes.c_int * (4 * 24))()
+
+    def get(ms):
+        n = lib.pleas_fwd_plan_units(arr, len(layers), ms, units, 24)
+        assert 0 < n <= 24, n
+        return [tuple(units[4 * i:4 * i + 4]) for i in range(n)]
+
+    fresh = get(None)
+    forms = {u[0]: (u[1], u[2]) for u in fresh}
+    assert len(forms) == len(fresh) and sum(c for _, c in forms.values()) > 20000      # one unit per form
+    rng = np.random.default_rng(0)
+    cases = [np.array([1.76, 0, 0, 0.24, 2.56, 0.27, 1.61, 2.56, 0, 0.36]),             # measured in round 3's bench job
+             np.ones(10), np.array([0, 0, 0, 0, 0, 0, 0, 9.0, 0, 0.01])] + [rng.random(10) * 3 for _ in range(20)]
+    for ms in cases:
+        got = get((ctypes.c_double * 10)(*ms.tolist()))
+        assert all(0 <= lane <= 3 for _, _, _, lane in got) and got[0][3] == 0
+        for f, (begin, count) in forms.items():
+            slices = sorted((b, c) for ff, b, c, _ in got if ff == f)
+            assert slices and slices[0][0] == begin and sum(c for _, c in slices) == count, (f, slices, begin, count)
+            for (b0, c0), (b1, _) in zip(slices, slices[1:]):
+                assert b0 + c0 == b1 and c0 > 0, (f, slices)
+    split = get((ctypes.c_double * 10)(*cases[0].tolist()))
+    assert len([u for u in split if u[0] == 7]) >= 2 and len([u for u in split if u[0] == 4]) >= 2   # the two 2.56 ms forms
+
+
 def test_host_code_under_sanitizers():
     """SURVEY.md section 5 (sanitizers): the host halves of csrc/*.hip -- plan builders, XCD item ordering, lane dealing,
     lag classes, the host LAP, argument checks -- compiled with -fsanitize=address,undefined (device code as always) and
