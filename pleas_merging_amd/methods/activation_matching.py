@@ -479,7 +479,7 @@ def compute_matching_costs(spec: PermutationSpec, gm_cross: nn.Module, dataloade
 def accumulate_costs_fused(spec: PermutationSpec, model1: nn.Module, model2: nn.Module, dataloader, num_batches: int,
                            epilogue: int, accumulate=True, shard: bool = True,
                            grouped: bool = True, overlap: bool = True, fuse_bn: bool = True, derive_bn: bool = True,
-                           pipeline: Optional[bool] = None) -> Dict[Axis, torch.Tensor]:
+                           pipeline: Optional[bool] = None, presharded: bool = False) -> Dict[Axis, torch.Tensor]:
     """HIP fast path: every tracked node adds into its group matrix while the forwards run.
 
     Data parallel: with ``torch.distributed`` initialised (one process per GPU, RCCL), rank r
@@ -505,6 +505,11 @@ def accumulate_costs_fused(spec: PermutationSpec, model1: nn.Module, model2: nn.
     referenced until the forward streams have been ordered after its contraction (one batch later), so the caching
     allocator cannot hand their memory to the next forward early; contractions stay in batch order on their stream, so
     the sums are what the sequential loop gives, bit for bit.
+
+    ``presharded=True`` (data parallel): ``dataloader`` already yields THIS rank's batches only (a loader over a
+    ``DistributedSampler``-style partition) and ``num_batches`` counts them; nothing is skipped here and the arena is still
+    all-reduced over the whole group.  The default lets every rank walk the same loader and keep every ``world``-th batch,
+    which preserves the reference's consumption order (:120) but makes each rank decode all batches.
     """
     device = _model_device(model1)
     if device.type != "cuda":
@@ -513,6 +518,7 @@ def accumulate_costs_fused(spec: PermutationSpec, model1: nn.Module, model2: nn.
     gm, sinks = build_fused_module(spec, model1, model2, arena, epilogue, grouped,
                                    overlap=overlap and grouped, fuse_bn=fuse_bn, derive_bn=derive_bn)
     rank, world = _dist_info() if (shard and accumulate is True) else (0, 1)
+    take = (0, 1) if presharded else (rank, world)      # which of the loader's batches this rank contracts
     # The batches run on a created stream, not on the caller's: work on torch's default (null) stream overlaps the side
     # stream of the split twin graph markedly worse than work on a created stream (see PleasFitter).
     caller = torch.cuda.current_stream(device)
@@ -524,7 +530,7 @@ def accumulate_costs_fused(spec: PermutationSpec, model1: nn.Module, model2: nn.
     contract = hip_ops.role_stream(device, "contract") if pipeline else None
     in_flight: collections.deque = collections.deque()       # (operands of a batch, event after its contraction)
     with torch.inference_mode(), torch.cuda.stream(work):
-        for x, _ in shard_batches(dataloader, num_batches, rank, world):
+        for x, _ in shard_batches(dataloader, num_batches, *take):
             if accumulate is not True:
                 arena.zero_()
             x = x.to(device, non_blocking=True)
@@ -587,19 +593,20 @@ def solve_all(costs: Dict[Axis, torch.Tensor], lsa_solver: Callable, while_solvi
 
 def activation_matching(spec: PermutationSpec, model1: nn.Module, model2: nn.Module, dataloader, num_batches=1000,
                         cross_features=cross_features_cdist, lsa_solver=hip_solve_lsa, output_costs=False,
-                        accumulate=True, grouped=True, while_solving: Optional[Callable] = None):
+                        accumulate=True, grouped=True, while_solving: Optional[Callable] = None, presharded: bool = False):
     """Permutation of ``model2``'s units that best matches ``model1``'s activations.
 
     Reference: :139-177 (same positional arguments; additions: ``accumulate`` -- ``"reference"``
     reproduces the shipped last-batch-only costs -- and ``grouped`` -- one contraction launch per
-    batch (default) instead of one per tracked node).  Returns ``perm``
+    batch (default) instead of one per tracked node -- and ``presharded``: under data parallelism the loader already
+    yields this rank's batches only).  Returns ``perm``
     (CPU int64 per group) or ``(perm, costs)`` with fp32 costs on the compute device.
     Does not change the models' train/eval mode and does not move them.
     """
     epilogue = _FUSED_EPILOGUE.get(cross_features)
     if epilogue is not None:
         costs = accumulate_costs_fused(spec, model1, model2, dataloader, num_batches, epilogue, accumulate,
-                                       grouped=grouped)
+                                       grouped=grouped, presharded=presharded)
     else:
         axes = [ax for group in spec.values() for ax in group.node]
         gm = build_cross_module(model1, model2, axes, cross_features)

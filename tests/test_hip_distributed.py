@@ -23,13 +23,19 @@ def _batches(t):
     return [x + 0.01 * i for i, x in enumerate(xs)][:N_UPDATES]
 
 
-def _job(t, data_parallel, shard=False):
+def _job(t, data_parallel, shard=False, presharded=False):
     from pleas.methods.activation_matching import activation_matching
     from pleas.methods.partial_matching import partial_merge
     from pleas.methods.pleas_merging import PleasFitter
 
     m1, m2 = copy.deepcopy(t.m1).cuda(), copy.deepcopy(t.m2).cuda()
-    perm, costs = activation_matching(t.spec, m1, m2, t.batches(), N_MATCH, output_costs=True)
+    if presharded:      # the loader hands every rank ITS batches only (DistributedSampler-style); same partition b % world
+        import torch.distributed as dist
+
+        mine = [b for i, b in enumerate(t.batches()[:N_MATCH]) if i % dist.get_world_size() == dist.get_rank()]
+        perm, costs = activation_matching(t.spec, m1, m2, mine, len(mine), output_costs=True, presharded=True)
+    else:
+        perm, costs = activation_matching(t.spec, m1, m2, t.batches(), N_MATCH, output_costs=True)
     m3 = partial_merge(t.spec, m1, m2, perm, costs, 0.5)
     merged_stem = m3.state_dict()["conv1.weight"].detach().cpu().clone()
     fit = PleasFitter(m1, m2, m3, t.spec, perm, costs, 0.5, N_UPDATES - 1, num_classes=10, data_parallel=data_parallel,
@@ -84,6 +90,8 @@ def _worker(rank, world, port, q, buckets):
             perm, costs, sd, loss, world = _job_normal_eq(Tiny("tiny_bottleneck.npz"))
         elif buckets == "shard":
             perm, costs, sd, loss, world = _job(Tiny("tiny_bottleneck.npz"), data_parallel=True, shard=True)
+        elif buckets == "presharded":
+            perm, costs, sd, loss, world = _job(Tiny("tiny_bottleneck.npz"), data_parallel=True, presharded=True)
         else:
             perm, costs, sd, loss, world = _job(Tiny("tiny_bottleneck.npz"), data_parallel=True)
         as_np = lambda d: {k: v.numpy() for k, v in d.items()}   # plain arrays: nothing shared with a process that exits
@@ -97,13 +105,14 @@ def _rel(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
 
 
-@pytest.mark.parametrize("buckets", [1, "shard"])     # one all-reduce per update / reduce-scatter + sharded Adam + all-gather
+# one all-reduce per update / reduce-scatter + sharded Adam + all-gather / the matching loader already split per rank
+@pytest.mark.parametrize("buckets", [1, "shard", "presharded"])
 def test_two_rank_job_equals_single_process_job(tiny_bottleneck, buckets):
     want_perm, want_costs, want_sd, want_loss, world1 = _job(tiny_bottleneck, data_parallel=False)
     assert world1 == 1
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29641 + (buckets if isinstance(buckets, int) else 7)
+    port = 29641 + (buckets if isinstance(buckets, int) else 7 + len(buckets))
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, buckets)) for r in range(2)]
     for p in procs:
         p.start()

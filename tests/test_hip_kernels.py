@@ -429,7 +429,7 @@ def test_gram_batch_derived_train_mode_batchnorm_at_full_width(ops, shape):
     view = (1, C, 1, 1)
     batch.add(xg * sx.view(view) + tx.view(view), yg * sy.view(view) + ty.view(view), 1, 2)   # the same tensors, contracted
     batch.flush(accumulate=False)
-    derived, contracted = _rel(mats[1], ref), _rel(mats[2], ref)
+    derived, contracted = _rel(mats[1].cpu(), ref), _rel(mats[2].cpu(), ref)
     print("C = %d: derived %.2e, contracted %.2e vs fp64" % (C, derived, contracted))
     assert derived < max(3 * contracted, 2e-6), (derived, contracted)
     assert int(gbn[0].num_batches_tracked) == 1
