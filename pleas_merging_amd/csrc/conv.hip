@@ -28,6 +28,7 @@ namespace pleas {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef f32x4 f32x4u __attribute__((aligned(4)));   // 16 bytes at a 4-byte-aligned address: still ONE global_load_dwordx4
 
 constexpr int cBK = 32;
 constexpr int cLds = 36;
@@ -51,9 +52,10 @@ struct WgradItemDev {
 };
 
 // YMODE: 0 = Y read in place (1x1, stride 1), 1 = shifted / strided view, one pixel per load, 2 = stride-1 "same" layer
-// with HW % 4 == 0: tap r reads the SAME flat pixel run `delta = dh * W + dw` further on, so a thread's four pixels come
-// from two aligned 16-byte loads and a wave-uniform register shift; nothing of Y is masked -- the taps that fall off the
-// image are voided by zeroing the RESIDUAL at those output pixels (a rectangle of (oh, ow)) when it is staged.
+// with HW % 4 == 0: tap r reads the SAME flat pixel run `delta = dh * W + dw` further on, so a thread's four pixels are
+// ONE 16-byte load at a 4-byte-aligned address (the hardware takes it; two aligned loads + a register shift move twice the
+// bytes through the 64 B/clk vector L1 and measured 5 % SLOWER than one pixel per load); nothing of Y is masked -- the
+// taps that fall off the image are voided by zeroing the RESIDUAL at those output pixels (a rectangle of (oh, ow)).
 template <int TM, int TN, int VECX, int YMODE>
 __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradItemDev& it, float* smem) {
     constexpr int MTM = TM / 64, MTN = TN / 64;
@@ -74,10 +76,9 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradIt
     const int xrow = tid / LPR_X, xcol = (tid % LPR_X) * VECX;
     const int yrow = tid / LPR_Y, ycol = (tid % LPR_Y) * VECY;
     float rx[PASS_X][VECX], ry[PASS_Y][VECY];
-    f32x4 ry1[YMODE == 2 ? PASS_Y : 1];   // YMODE 2: the second aligned group of every row
     unsigned okx = 0, oky = 0;
     unsigned win = 0xFu;                  // YMODE 2: bit e = output pixel e of this thread's run has tap r inside the image
-    const int delta = dh * L.Win + dw, sh = ((delta % 4) + 4) % 4;      // YMODE 2 (wave-uniform)
+    const int delta = dh * L.Win + dw;    // YMODE 2
     const int oh0 = max(0, -dh), oh1 = L.Hout - 1 - max(0, dh), ow0 = max(0, -dw), ow1 = L.Wout - 1 - max(0, dw);
     uint32_t offx[PASS_X], offy[PASS_Y];  // < 2^32: one sample's C*HW slab
 #pragma unroll
@@ -144,16 +145,20 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradIt
             }
             kiny = in;
             if constexpr (YMODE == 2) {
-                // each aligned group clamped on its own: whatever lies outside the tensor lies outside its image, i.e. at
-                // an output pixel whose residual is zeroed
-                const int b0 = (int)base + delta - sh;
+                // whatever lies outside the tensor lies outside its image, i.e. at an output pixel whose residual is zeroed:
+                // only the run that straddles the tensor's first / last float goes element by element, clamped
+                const int b0 = (int)base + delta;
 #pragma unroll
                 for (int q = 0; q < PASS_Y; ++q) {
-                    const int g0 = min(max(b0 + (int)offy[q], 0), L.total - 4), g1 = min(max(b0 + (int)offy[q] + 4, 0), L.total - 4);
-                    const f32x4 v0 = *(const __attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL(L.ip) + g0);
+                    const int g = b0 + (int)offy[q];
+                    if (g >= 0 && g <= L.total - 4) {
+                        const f32x4 v = *(const __attribute__((address_space(1))) f32x4u*)(PLEAS_GLOBAL(L.ip) + g);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) ry[q][e] = v0[e];
-                    if (sh) ry1[q] = *(const __attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL(L.ip) + g1);
+                        for (int e = 0; e < 4; ++e) ry[q][e] = v[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ry[q][e] = PLEAS_GLOBAL(L.ip)[min(max(g + e, 0), L.total - 1)];
+                    }
                 }
             } else
 #pragma unroll
@@ -188,14 +193,8 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradIt
             const bool ok = kiny && ((oky >> q) & 1u);
             const int row = yrow + q * RPP_Y;
             if constexpr (YMODE == 2) {
-                f32x4 v;
-                switch (sh) {       // wave-uniform
-                    case 0: v = f32x4{ry[q][0], ry[q][1], ry[q][2], ry[q][3]}; break;
-                    case 1: v = f32x4{ry[q][1], ry[q][2], ry[q][3], ry1[q][0]}; break;
-                    case 2: v = f32x4{ry[q][2], ry[q][3], ry1[q][0], ry1[q][1]}; break;
-                    default: v = f32x4{ry[q][3], ry1[q][0], ry1[q][1], ry1[q][2]}; break;
-                }
-                if (!((oky >> q) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                const bool rowok = (oky >> q) & 1u;
+                f32x4 v = {rowok ? ry[q][0] : 0.f, rowok ? ry[q][1] : 0.f, rowok ? ry[q][2] : 0.f, rowok ? ry[q][3] : 0.f};
                 *reinterpret_cast<f32x4*>(b + row * cLds + ycol) = v;
             } else if constexpr (VECY == 4) {
                 f32x4 v = {ok ? ry[q][0] : 0.f, ok ? ry[q][1] : 0.f, ok ? ry[q][2] : 0.f, ok ? ry[q][3] : 0.f};

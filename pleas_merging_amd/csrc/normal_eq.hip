@@ -23,8 +23,8 @@
 // (delta, Q) among the 9 tap pairs (delta = 0: three windows; delta = +-1, +-2: the full lag range each), so the 81
 // blocks of a 3x3 layer take 49 distinct values, 29 up to transposition -- against the 45 blocks of the lower triangle.
 // Only those 29 are contracted (tile form neq_lag_tile: operand x is the UNSHIFTED image, 16-byte loads, zeroed
-// outside Q when staged; operand y is read delta further on with two aligned 16-byte loads and a wave-uniform register
-// shift, unmasked, because x's zeros already void every product outside Q); pleas_normal_eq_finalize copies /
+// outside Q when staged; operand y is read delta floats further on -- one 16-byte load at a 4-byte-aligned address --
+// unmasked, because x's zeros already void every product outside Q); pleas_normal_eq_finalize copies /
 // transposes them into the other 16 blocks ONCE, after the last batch (and after the all-reduce of a multi-GPU run).
 #include <algorithm>
 #include <mutex>
@@ -36,6 +36,7 @@ namespace pleas {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef f32x4 f32x4u __attribute__((aligned(4)));   // 16 bytes at a 4-byte-aligned address: still ONE global_load_dwordx4
 
 constexpr int nBK = 32;
 constexpr int nLds = 36;
@@ -249,7 +250,6 @@ __device__ __forceinline__ void neq_lag_tile(const NeqLayerDev& L, const NeqItem
     const int khx = it.rx / L.KW, kwx = it.rx - khx * L.KW, khy = it.ry / L.KW, kwy = it.ry - khy * L.KW;
     const int dhx = khx - L.pad, dwx = kwx - L.pad, dhy = khy - L.pad, dwy = kwy - L.pad;
     const int delta = (dhy - dhx) * L.Win + (dwy - dwx);     // operand y reads delta floats further on
-    const int sh = ((delta % 4) + 4) % 4;                    // its misalignment against 16-byte groups (wave-uniform)
     // the window Q of q = o + d_x: o, q and q + delta inside the image
     const int qh0 = max(0, max(-dhx, -dhy)) + dhx, qh1 = L.Hin - 1 - max(0, max(dhx, dhy)) + dhx;
     const int qw0 = max(0, max(-dwx, -dwy)) + dwx, qw1 = L.Win - 1 - max(0, max(dwx, dwy)) + dwx;
@@ -271,7 +271,7 @@ __device__ __forceinline__ void neq_lag_tile(const NeqLayerDev& L, const NeqItem
         for (int b = 0; b < MT; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    f32x4 ra[PASS], rb0[PASS], rb1[PASS];      // VEC == 1: element 0 only
+    f32x4 ra[PASS], rb0[PASS];                 // VEC == 1: element 0 only
     unsigned win = 0;                          // bit e: pixel e of this thread's run is inside Q
     auto load_chunk = [&](int c) {
         const uint32_t P = (uint32_t)c * nBK + scol;
@@ -287,14 +287,18 @@ __device__ __forceinline__ void neq_lag_tile(const NeqLayerDev& L, const NeqItem
         }
         const int base = n * L.Cin * HW + p;
         if constexpr (VEC == 4) {
-            const int b0 = base + delta - sh;          // 16-byte aligned: HW % 4 == 0, p % 4 == 0
 #pragma unroll
             for (int q = 0; q < PASS; ++q) {
                 ra[q] = *(const __attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL(L.ip) + base + offa[q]);
-                // each group clamped on its own: whatever lies outside the tensor lies outside its image, hence outside Q
-                const int g0 = min(max(b0 + offb[q], 0), L.total - 4), g1 = min(max(b0 + offb[q] + 4, 0), L.total - 4);
-                rb0[q] = *(const __attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL(L.ip) + g0);
-                if (sh) rb1[q] = *(const __attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL(L.ip) + g1);
+                // ONE 16-byte load at a 4-byte-aligned address.  Whatever lies outside the tensor lies outside its image,
+                // hence outside Q: only the run that straddles the tensor's first / last float goes element by element
+                const int g = base + delta + offb[q];
+                if (g >= 0 && g <= L.total - 4) {
+                    rb0[q] = *(const __attribute__((address_space(1))) f32x4u*)(PLEAS_GLOBAL(L.ip) + g);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rb0[q][e] = PLEAS_GLOBAL(L.ip)[min(max(g + e, 0), L.total - 1)];
+                }
             }
         } else {
 #pragma unroll
@@ -314,13 +318,7 @@ __device__ __forceinline__ void neq_lag_tile(const NeqLayerDev& L, const NeqItem
             if constexpr (VEC == 4) {
                 f32x4 va = {(fa && (win & 1u)) ? ra[q][0] : 0.f, (fa && (win & 2u)) ? ra[q][1] : 0.f,
                             (fa && (win & 4u)) ? ra[q][2] : 0.f, (fa && (win & 8u)) ? ra[q][3] : 0.f};
-                f32x4 vb;
-                switch (sh) {       // wave-uniform
-                    case 0: vb = rb0[q]; break;
-                    case 1: vb = f32x4{rb0[q][1], rb0[q][2], rb0[q][3], rb1[q][0]}; break;
-                    case 2: vb = f32x4{rb0[q][2], rb0[q][3], rb1[q][0], rb1[q][1]}; break;
-                    default: vb = f32x4{rb0[q][3], rb1[q][0], rb1[q][1], rb1[q][2]}; break;
-                }
+                f32x4 vb = rb0[q];
                 if (!fb) vb = f32x4{0.f, 0.f, 0.f, 0.f};
                 *reinterpret_cast<f32x4*>(a + row * nLds + scol) = va;
                 *reinterpret_cast<f32x4*>(b + row * nLds + scol) = vb;

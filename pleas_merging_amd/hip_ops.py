@@ -192,14 +192,12 @@ class GramBatch:
         self._meta.append((B, C, HW, group, source))
         return len(self._keep) - 1
 
-    def flush(self, accumulate: bool = True, keep: bool = False, hold: bool = False):
+    def flush(self, accumulate: bool = True, keep: bool = False) -> None:
         """Contract everything added since the last flush.  ``keep=True`` leaves the node list in place (a caller that
-        contracts the same device tensors again).  ``hold=True`` returns the operand tensors instead of dropping them: a
-        caller that launches on ANOTHER stream than the one the operands were produced (and allocated) on keeps them alive
-        until that stream is done with them."""
+        contracts the same device tensors again)."""
         n = len(self._keep)
         if n == 0:
-            return [] if hold else None
+            return
         if self._arr is None or len(self._arr) != n:
             self._arr = (_lib.GramNode * n)()
         arr = self._arr
@@ -225,13 +223,12 @@ class GramBatch:
         self._fresh = 0
         if rc == -12:  # node list changed shape: size the workspace again
             self._ws = None
-            return self.flush(accumulate, keep, hold)
+            self.flush(accumulate, keep)
+            return
         check(rc, "pleas_gram_batch")
-        held = list(self._keep) if hold else None
         if not keep:
             self._keep.clear()
             self._meta.clear()
-        return held
 
     def drop(self) -> None:
         self._keep.clear()
@@ -365,6 +362,53 @@ def bn_train_fold(bn: "torch.nn.BatchNorm2d", x: torch.Tensor) -> Tuple[torch.Te
                                  out[0].data_ptr(), out[1].data_ptr(), ws.data_ptr(), need, _stream())
     check(rc, "pleas_bn_train_fold")
     return out[0], out[1]
+
+
+class BnTrainFold:
+    """``bn_train_fold`` for ONE BatchNorm2d called batch after batch (graph callable of the matching twin in train mode and
+    of the BN-reset pass): workspace, output vectors and the module's parameter / buffer addresses are looked up once per
+    input shape instead of per call -- those passes are bound by host dispatch (104 BatchNorm2d per ResNet-101 forward).
+    The returned ``(scale, shift)`` are views of a buffer that the NEXT call overwrites: consume them on the same stream
+    before folding the next batch (what a forward pass does)."""
+
+    def __init__(self, bn: "torch.nn.BatchNorm2d"):
+        self.bn = bn
+        self._shape = None
+
+    def _prepare(self, x: torch.Tensor) -> None:
+        bn = self.bn
+        n, C = x.shape[0], x.shape[1]
+        inner = math.prod(x.shape[2:])
+        if n * inner <= 1:
+            raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(x.shape),))
+        track = bn.track_running_stats and bn.running_mean is not None
+        for t in (bn.weight, bn.bias, bn.running_mean if track else None, bn.running_var if track else None):
+            if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.device != x.device):
+                raise PleasHipError("bn_train_fold: BatchNorm parameters / buffers must be contiguous fp32 on x's device")
+        need = int(_lib.lib().pleas_bn_train_ws_bytes(n, C))
+        self._ws = torch.empty(need // 8, dtype=torch.float64, device=x.device)
+        self._out = torch.empty(2, C, dtype=torch.float32, device=x.device)
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        self._tensors = (bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked)   # identity check below
+        self._args = (n, C, inner, ptr(bn.weight), ptr(bn.bias), float(bn.eps),
+                      ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
+                      ptr(bn.num_batches_tracked) if (track and bn.num_batches_tracked is not None) else None,
+                      self._out[0].data_ptr(), self._out[1].data_ptr(), self._ws.data_ptr(), need)
+        self._shape = (tuple(x.shape), x.device)
+
+    def __call__(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        if not x.is_cuda or x.dtype != torch.float32 or x.dim() < 2:
+            raise PleasHipError("bn_train_fold needs an fp32 [N, C, ...] tensor on the GPU")
+        x = x.contiguous()
+        bn = self.bn
+        if self._shape != (tuple(x.shape), x.device) or any(a is not b for a, b in zip(
+                self._tensors, (bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked))):
+            self._prepare(x)
+        n, C, inner, w, b, eps, rm, rv, nbt, o0, o1, ws, need = self._args
+        rc = _lib.lib().pleas_bn_train_fold(x.data_ptr(), n, C, inner, w, b, eps, -1.0 if bn.momentum is None else float(bn.momentum),
+                                            rm, rv, nbt, o0, o1, ws, need, _stream())
+        check(rc, "pleas_bn_train_fold")
+        return self._out[0], self._out[1]
 
 
 # ---------------------------------------------------------------------------------------- merge blocks

@@ -16,7 +16,6 @@ the reference's plug points (generic path).
 """
 from __future__ import annotations
 
-import collections
 import os
 
 from typing import Callable, Dict, Iterable, List, Optional, Tuple
@@ -203,8 +202,10 @@ def _bn_chains(traced: _Trace, model1: nn.Module, model2: nn.Module):
 def _train_fold(mod: nn.BatchNorm2d, side: int, name: str) -> Callable:
     """Graph callable of a train-mode BatchNorm: ``x -> (scale, shift)`` of THIS batch (and the module's running
     statistics move on, as in the module's own forward)."""
+    folder = hip_ops.BnTrainFold(mod)     # workspace / output vectors / addresses looked up once per input shape
+
     def fold(x):
-        return hip_ops.bn_train_fold(mod, x)
+        return folder(x)
 
     fold.__name__ = fold.__qualname__ = "bn_train_fold_%d_%s" % (side, name)
     return fold
@@ -479,7 +480,7 @@ def compute_matching_costs(spec: PermutationSpec, gm_cross: nn.Module, dataloade
 def accumulate_costs_fused(spec: PermutationSpec, model1: nn.Module, model2: nn.Module, dataloader, num_batches: int,
                            epilogue: int, accumulate=True, shard: bool = True,
                            grouped: bool = True, overlap: bool = True, fuse_bn: bool = True, derive_bn: bool = True,
-                           pipeline: Optional[bool] = None, presharded: bool = False) -> Dict[Axis, torch.Tensor]:
+                           presharded: bool = False) -> Dict[Axis, torch.Tensor]:
     """HIP fast path: every tracked node adds into its group matrix while the forwards run.
 
     Data parallel: with ``torch.distributed`` initialised (one process per GPU, RCCL), rank r
@@ -499,13 +500,6 @@ def accumulate_costs_fused(spec: PermutationSpec, model1: nn.Module, model2: nn.
     104 of ResNet-101's 344 tracked nodes, i.e. ~30 % of the contraction's flops, and the BatchNorm tensors are not
     written at all.
 
-    ``pipeline`` (default on with the two-stream twin; ``PLEAS_MATCH_PIPELINE=0`` turns it off): the grouped contraction of
-    batch b runs on a stream of its own BESIDE the twin forward of batch b + 1 -- the forward is two chains of small vendor
-    kernels that leave most of the 256 CUs idle, the contraction is one grid that fills them.  The operands of batch b stay
-    referenced until the forward streams have been ordered after its contraction (one batch later), so the caching
-    allocator cannot hand their memory to the next forward early; contractions stay in batch order on their stream, so
-    the sums are what the sequential loop gives, bit for bit.
-
     ``presharded=True`` (data parallel): ``dataloader`` already yields THIS rank's batches only (a loader over a
     ``DistributedSampler``-style partition) and ``num_batches`` counts them; nothing is skipped here and the arena is still
     all-reduced over the whole group.  The default lets every rank walk the same loader and keep every ``world``-th batch,
@@ -524,42 +518,19 @@ def accumulate_costs_fused(spec: PermutationSpec, model1: nn.Module, model2: nn.
     caller = torch.cuda.current_stream(device)
     work = hip_ops.role_stream(device, "model1") if sinks.streams is not None else caller
     work.wait_stream(caller)
-    if pipeline is None:
-        pipeline = os.environ.get("PLEAS_MATCH_PIPELINE", "1") != "0"
-    pipeline = bool(pipeline and sinks.streams is not None and sinks.batch is not None and accumulate is True)
-    contract = hip_ops.role_stream(device, "contract") if pipeline else None
-    in_flight: collections.deque = collections.deque()       # (operands of a batch, event after its contraction)
     with torch.inference_mode(), torch.cuda.stream(work):
         for x, _ in shard_batches(dataloader, num_batches, *take):
             if accumulate is not True:
                 arena.zero_()
             x = x.to(device, non_blocking=True)
-            while len(in_flight) >= 2:      # the batch before the previous one: order the forward streams after its
-                held, done = in_flight.popleft()     # contraction, THEN let go of its operands
-                work.wait_event(done)
-                del held
             try:
                 gm(x)
             except BaseException:
                 if sinks.streams is not None:
                     sinks.streams.restore()
                 raise
-            if sinks.batch is None:
-                continue
-            if not pipeline:
+            if sinks.batch is not None:
                 sinks.batch.flush(accumulate=True)
-                continue
-            forwarded = torch.cuda.Event()
-            forwarded.record(work)          # the twin graph joined model2's stream into `work` before its sinks ran
-            contract.wait_event(forwarded)
-            with torch.cuda.stream(contract):
-                held = sinks.batch.flush(accumulate=True, hold=True)
-                done = torch.cuda.Event()
-                done.record(contract)
-            in_flight.append((held, done))
-        if pipeline:
-            work.wait_stream(contract)
-            in_flight.clear()
     caller.wait_stream(work)
     allreduce_sum_(arena.flat, world)
     return dict(arena.view)

@@ -79,8 +79,10 @@ def fold_bn(bn: nn.BatchNorm2d):
 def _train_fold(bn: nn.BatchNorm2d, tag: str) -> Callable:
     """Graph callable of a train-mode BatchNorm: ``x -> (scale, shift)`` of THIS batch; the module's running statistics
     and batch counter move on exactly as in the module's own forward (``hip_ops.bn_train_fold``: one streaming pass)."""
+    folder = hip_ops.BnTrainFold(bn)      # workspace / output vectors / addresses looked up once per input shape
+
     def fold(x):
-        return hip_ops.bn_train_fold(bn, x)
+        return folder(x)
 
     fold.__name__ = fold.__qualname__ = "bn_train_fold_%s" % tag
     return fold

@@ -27,6 +27,6 @@ def run(n, **kw):
     return statistics.median(gaps) * 1e3, (t1 - stamps[10]) / (len(stamps) - 10) * 1e3, (stamps[0] - t0)
 for rep in range(3):
     for tag, kw in (("vendor BN modules", {"fuse_bn": False}), ("fused BN, contracted", {"derive_bn": False}),
-                    ("fused, derived, sequential", {"pipeline": False}), ("fused, derived, pipelined", {"pipeline": True})):
+                    ("fused BN, derived", {})):
         host, wall, build = run(60, **kw)
         print("%-27s: host per batch (median) %.2f ms, wall per batch %.2f ms, build %.3f s" % (tag, host, wall, build), flush=True)

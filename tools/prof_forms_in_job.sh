@@ -21,13 +21,16 @@ for r in rows:
 for f, v in sorted(per.items()):
     v = v[len(v) // 2:]
     print("form %s: %d launches, avg %.1f us (second half)" % (f, len(v), sum(v) / len(v)))
-# group launches of one update: consecutive kernels until a form repeats
+# group launches of one update: every fwd_batch kernel up to the update's fwd_loss_kernel (a form may be launched as several
+# units -- slices of its items on different lanes -- so "until a form repeats" no longer delimits an update)
+ends = sorted(int(r["Start_Timestamp"]) for r in rows if "fwd_loss_kernel" in r["Kernel_Name"])
 spans.sort()
-groups, cur, seen = [], [], set()
+groups, cur, k = [], [], 0
 for s, e, f in spans:
-    if f in seen:
-        groups.append(cur); cur, seen = [], set()
-    cur.append((s, e, f)); seen.add(f)
+    while k < len(ends) and ends[k] <= s:
+        if cur: groups.append(cur)
+        cur = []; k += 1
+    cur.append((s, e, f))
 if cur: groups.append(cur)
 g = groups[len(groups) // 2:]
 tot = [(max(e for _, e, _ in x) - min(s for s, _, _ in x)) / 1e3 for x in g]
