@@ -824,34 +824,74 @@ static void fwd_deal_lanes(FwdPlan& P) {
         load[best] += P.units[o].ms;
     }
 }
-// after the calibration launch: a unit that takes more than 0.7 of a lane's fair share of the measured total is cut into
-// slices of (nearly) equal WORK -- items are sorted longest first, so equal counts would not do -- and the lanes are dealt
-// again.  A 1x1 form with 20 000 short items then fills two or three lanes instead of bounding the whole group.
-static void fwd_split_units(FwdPlan& P) {
+// After the calibration launch (measured duration per form).  What the in-job timelines showed: a form with few long items
+// (stride-2 layers, the 7 x 7 layers: 400 - 900 items for 512 workgroup slots) needs WALL time whatever runs beside it,
+// while the form with the most items (1 x 1 layers with K <= 256: 20 000 short ones) soaks up whatever the chip has left.
+// So: (1) every form but that FILLER is cut into slices of equal work if it outlasts 0.7 of a lane's fair share, and the
+// units are list-scheduled onto the least-loaded lane in ascending order of their form's item count -- low parallelism
+// first; (2) the filler is cut into one slice per lane, sized so that all lanes end together, launched last on each.
+static void fwd_slice_by_work(const FwdPlan& P, const FwdPlan::Unit& u, const std::vector<double>& share, std::vector<FwdPlan::Unit>& out) {
+    double work = 0, want = 0;
+    for (int i = 0; i < u.count; ++i) work += P.item_work[u.begin + i];
+    for (double v : share) want += v;
+    int begin = u.begin;
+    double acc = 0, upto = 0;
+    size_t final_slice = 0;          // the last slice with a share takes what rounding left over
+    for (size_t k = 0; k < share.size(); ++k)
+        if (share[k] > 0) final_slice = k;
+    for (size_t k = 0; k < share.size(); ++k) {
+        upto += work * share[k] / want;
+        int end = begin;
+        while (end < u.begin + u.count && share[k] > 0 && (k == final_slice || acc + P.item_work[end] <= upto)) acc += P.item_work[end++];
+        if (end == begin && share[k] > 0 && end < u.begin + u.count) acc += P.item_work[end++];
+        out.push_back(FwdPlan::Unit{u.form, begin, end - begin, (int)k, u.ms * share[k] / want});   // lane field: slice index
+        begin = end;
+    }
+}
+static void fwd_schedule_measured(FwdPlan& P) {
     double total = 0;
     for (const auto& u : P.units) total += u.ms;
     const double fair = total / (fLanes + 1);
-    std::vector<FwdPlan::Unit> out;
+    int filler = -1;
+    for (size_t i = 0; i < P.units.size(); ++i)
+        if (filler < 0 || P.units[i].count > P.units[filler].count) filler = (int)i;
+    if (filler >= 0 && (P.units[filler].ms < 0.15 * total || P.units[filler].count < 8 * (fLanes + 1))) filler = -1;
+    // (1) the other forms, long ones in equal slices
+    std::vector<FwdPlan::Unit> rest;
     for (size_t ui = 0; ui < P.units.size(); ++ui) {
+        if ((int)ui == filler) continue;
         const FwdPlan::Unit u = P.units[ui];
         int parts = (u.ms > 0.7 * fair && u.count >= 64) ? (int)std::min<double>(4.0, std::ceil(u.ms / (0.45 * fair))) : 1;
-        const int room = fMaxUnits - (int)out.size() - (int)(P.units.size() - ui - 1);   // every later unit needs one slot
+        const int room = fMaxUnits - (fLanes + 1) - (int)rest.size() - (int)(P.units.size() - ui - 1);
         parts = std::max(1, std::min(parts, room));
-        if (parts <= 1) { out.push_back(u); continue; }
-        double work = 0;
-        for (int i = 0; i < u.count; ++i) work += P.item_work[u.begin + i];
-        int begin = u.begin;
-        double acc = 0;
-        for (int k = 0; k < parts; ++k) {
-            const double upto = work * (k + 1) / parts;
-            int end = begin;
-            while (end < u.begin + u.count && (k == parts - 1 || acc + P.item_work[end] <= upto)) acc += P.item_work[end++];
-            if (end == begin && end < u.begin + u.count) acc += P.item_work[end++];
-            if (end > begin) out.push_back(FwdPlan::Unit{u.form, begin, end - begin, 0, u.ms / parts});
-            begin = end;
-        }
+        if (parts <= 1) rest.push_back(u);
+        else fwd_slice_by_work(P, u, std::vector<double>(parts, 1.0), rest);
     }
-    P.units.swap(out);
+    std::stable_sort(rest.begin(), rest.end(), [&](const FwdPlan::Unit& a, const FwdPlan::Unit& b) {
+        return P.form_count[a.form] != P.form_count[b.form] ? P.form_count[a.form] < P.form_count[b.form] : a.ms > b.ms;
+    });
+    double load[fLanes + 1] = {0};
+    for (size_t o = 0; o < rest.size(); ++o) {
+        int best = 0;
+        for (int l = 1; l <= fLanes; ++l)
+            if (load[l] < load[best]) best = l;
+        rest[o].lane = best;
+        load[best] += rest[o].ms;
+    }
+    // (2) the filler levels the lanes
+    if (filler >= 0) {
+        const FwdPlan::Unit f = P.units[filler];
+        double sum = f.ms;
+        for (double v : load) sum += v;
+        const double level = sum / (fLanes + 1);
+        std::vector<double> share(fLanes + 1);
+        for (int l = 0; l <= fLanes; ++l) share[l] = std::max(0.0, level - load[l]);
+        std::vector<FwdPlan::Unit> slices;
+        fwd_slice_by_work(P, f, share, slices);
+        for (auto& sl : slices)
+            if (sl.count > 0) rest.push_back(sl);      // .lane = slice index = the lane it levels
+    }
+    P.units.swap(rest);
 }
 
 static std::mutex g_fplan_mu;
@@ -1030,8 +1070,7 @@ extern "C" int pleas_fwd_plan_units(const pleas_fwd_layer* layers, int n_layers,
     if (rc != PLEAS_OK) return rc;
     if (form_ms) {       // as if the calibration launch had measured these per-form durations
         for (auto& u : tmp.units) u.ms = form_ms[u.form];
-        fwd_split_units(tmp);
-        fwd_deal_lanes(tmp);
+        fwd_schedule_measured(tmp);
     }
     const int n = (int)std::min<size_t>(tmp.units.size(), (size_t)max_units);
     for (int i = 0; i < n; ++i) {
@@ -1145,8 +1184,7 @@ extern "C" int pleas_fwd_batch(const pleas_fwd_layer* layers, int n_layers, floa
                     float ms = 0.f;
                     P.units[u].ms = hipEventElapsedTime(&ms, side.t0[u], side.t1[u]) == hipSuccess ? ms : 0.0;
                 }
-                fwd_split_units(P);
-                fwd_deal_lanes(P);
+                fwd_schedule_measured(P);
                 P.calib = 2;
                 if (g_fcalib.size() >= 16) g_fcalib.erase(g_fcalib.begin());
                 g_fcalib.emplace_back(fwd_geometry_key(P.key), P.units);
