@@ -27,6 +27,7 @@ Besides the contract's keys the JSON line carries
   checks        invariants of the last timed job's result (permutations valid, losses fell, weights finite).
 """
 import argparse
+import gc
 import json
 import os
 import socket
@@ -78,6 +79,11 @@ def parse(argv=None):
     ap.add_argument("--profile-all", action="store_true", help="also bracket the many-launch elementwise kernel "
                     "(bn_act) with events: complete kernels_ms, slightly slower timed region")
     ap.add_argument("--cpu-sample-batch", type=int, default=8)
+    ap.add_argument("--gc", default="lap", choices=("lap", "auto"),
+                    help="lap (default): Python's cyclic garbage collector is switched off while a job runs and called once "
+                         "per job where the host has nothing to do -- while the batched LAP kernel runs; auto: the "
+                         "interpreter's own schedule (a full collection over the job's fx graphs / tap dictionaries then "
+                         "lands inside every other job: 6.36 / 6.52 s alternating)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                                                       "the multi-rank logic on a single GPU)")
     ap.add_argument("--all-ranks-on-gpu0", action="store_true", help="rehearsal only: every rank uses cuda:0")
@@ -193,6 +199,8 @@ def run_job(cfg, spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, phases
 
     phases = phases or Phases()
     dp = cfg["dp"]
+    if cfg.get("gc") == "lap":
+        gc.disable()
     # The frozen sources of the PLeaS phase do not depend on the permutation: while the batched LAP kernel runs (one
     # workgroup per problem), the host builds their fused forwards and enqueues the first groups of source forwards on
     # the side streams, where they also fill the GPU's idle time during partial merge and fitter set-up.
@@ -203,6 +211,8 @@ def run_job(cfg, spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, phases
         early["sources"] = src = FrozenSources(m1, m2, data_parallel=dp)
         src.prefetch(inputs, group=cfg["sources_per_forward"], max_groups=cfg["prefetch_groups"],
                      memory_fraction=cfg["prefetch_memory"])
+        if cfg.get("gc") == "lap":      # the LAP kernel has ~0.2 s to go and the host nothing to enqueue: collect now
+            gc.collect()
 
     if phases.on:      # the same two calls activation_matching() makes, with a synchronising boundary between them
         costs = accumulate_costs_fused(spec, m1, m2, match_loader, len(match_loader), hip_ops.EPI_NEG_CDIST)
@@ -226,6 +236,8 @@ def run_job(cfg, spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, phases
     phases.mark("updates")
     m3 = fit.finish()
     phases.mark("finish")
+    if cfg.get("gc") == "lap":
+        gc.enable()
     return {"m3": m3, "perm": perm, "costs": costs, "first_loss": first, "last_loss": last, "layers": len(fit.plans)}
 
 
@@ -513,7 +525,7 @@ def main():
         os.environ["PLEAS_EMULATE_ALLREDUCE_US"] = str(args.emulate_allreduce_us)
         dp = True
     cfg = {"dp": dp, "ratio": args.ratio, "prefetch_groups": args.prefetch_groups, "prefetch_memory": args.prefetch_memory,
-           "shard_optimizer": args.shard_optimizer, "sources_per_forward": (args.sources_per_forward * ranks) or None, "lookahead": None if args.lookahead < 0 else bool(args.lookahead)}
+           "shard_optimizer": args.shard_optimizer, "gc": args.gc, "sources_per_forward": (args.sources_per_forward * ranks) or None, "lookahead": None if args.lookahead < 0 else bool(args.lookahead)}
     log("spec (%d groups, %.2f s on the host, outside `value`) + %d synthetic batches resident" % (len(spec), spec_s, len(pool.items)))
 
     def job(phases=None):
@@ -642,6 +654,7 @@ def main():
                                "" if full else " (SHORTENED job: not a benchmark result)"),
                 "solver": "adam", "parallelism": "dp%d" % world,
                 "sources_per_forward": cfg["sources_per_forward"] or 2 * ranks,
+                "host_gc": "collected once per job while the LAP kernel runs" if args.gc == "lap" else "interpreter default",
                 "not_in_value": "get_permutation_spec %.2f s (host, once per model)" % spec_s,
             },
             "job_s": {"mean": round(value, 4), "median": round(srt[len(srt) // 2], 4), "min": round(srt[0], 4),
