@@ -30,8 +30,7 @@ def job(nm, nu, prof=None):
     t1 = sync()
     m3 = partial_merge(spec, m1, m2, perm, costs, 0.0, device=dev)
     t2 = sync()
-    fit = PleasFitter(m1, m2, m3, spec, perm, costs, 0.0, nu - 1, data_parallel=True, graph_sources=GRAPH,
-                      fused_sources=early["s"])
+    fit = PleasFitter(m1, m2, m3, spec, perm, costs, 0.0, nu - 1, data_parallel=True, fused_sources=early["s"])
     t3 = sync()
     if prof: prof.enable()
     h0 = time.time()

@@ -13,7 +13,7 @@ spec = get_permutation_spec(m1, ((1, 3, 224, 224),))
 perm = make_identity_perm(spec)
 costs = {k: torch.eye(g.size, device=dev) for k, g in spec.items()}
 m3 = partial_merge(spec, m1, m2, perm, costs, 0.0)
-fit = PleasFitter(m1, m2, m3, spec, perm, costs, 0.0, 400, fuse_sources='nofuse' not in sys.argv, overlap_sources='nooverlap' not in sys.argv, graph_sources='graph' in sys.argv)
+fit = PleasFitter(m1, m2, m3, spec, perm, costs, 0.0, 400, fuse_sources='nofuse' not in sys.argv, overlap_sources='nooverlap' not in sys.argv)
 print('overlap', 'nooverlap' not in sys.argv, 'fuse_sources', 'nofuse' not in sys.argv, 'graph', 'graph' in sys.argv)
 x = torch.randn(B, 3, 224, 224, device=dev)
 for _ in range(3): fit.step(x)

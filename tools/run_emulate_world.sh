@@ -8,7 +8,7 @@ LOOK=${3:--1}
 BUCKETS=${4:-1}
 for n in ${1:-2 4 8}; do
   tag=w${n}_us${US}_la${LOOK}_b${BUCKETS}
-  timeout -k 10 300 python bench.py --emulate-world $n --emulate-allreduce-us $US --lookahead $LOOK --grad-buckets $BUCKETS --no-cpu-baseline \
+  timeout -k 10 300 python bench.py --emulate-world $n --emulate-allreduce-us $US --lookahead $LOOK --no-cpu-baseline \
       > gpurun_out/emulate_$tag.json 2> gpurun_out/emulate_$tag.err
   python - <<PY
 import json
