@@ -65,6 +65,9 @@ def parse(argv=None):
                     help="updates PER RANK whose batches go through the frozen sources as ONE forward (128 samples per "
                          "forward at 8: the vendor convolutions run 15-30 %% faster per sample than at 32); 0 = the fitter's "
                          "default of 2; the prefetch takes --prefetch-groups forwards of that size")
+    ap.add_argument("--match-per-forward", type=int, default=4,
+                    help="matching batches per twin forward (every tracked node is still contracted per batch): the vendor "
+                         "convolutions run faster per sample at 64 samples than at 16; 0 = the library's default of 2")
     ap.add_argument("--miopen-find", type=int, default=0, help="1: torch.backends.cudnn.benchmark = True, i.e. the vendor "
                     "library times its candidate convolution kernels per configuration (Find mode) instead of taking the "
                     "immediate-mode pick; costs seconds per new configuration in the first warm-up job")
@@ -215,13 +218,14 @@ def run_job(cfg, spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, phases
             gc.collect()
 
     if phases.on:      # the same two calls activation_matching() makes, with a synchronising boundary between them
-        costs = accumulate_costs_fused(spec, m1, m2, match_loader, len(match_loader), hip_ops.EPI_NEG_CDIST)
+        costs = accumulate_costs_fused(spec, m1, m2, match_loader, len(match_loader), hip_ops.EPI_NEG_CDIST,
+                                       batches_per_forward=cfg["match_per_forward"])
         phases.mark("matching")
         perm = solve_all(costs, hip_solve_lsa, while_solving)
         phases.mark("lap")
     else:
         perm, costs = activation_matching(spec, m1, m2, match_loader, len(match_loader), output_costs=True,
-                                          while_solving=while_solving)
+                                          while_solving=while_solving, batches_per_forward=cfg["match_per_forward"])
     m3 = partial_merge(spec, m1, m2, perm, costs, cfg["ratio"], device=next(m1.parameters()).device)   # stays on the GPU
     # Data parallel: each rank's share of an update is small (batch / world samples); the frozen sources therefore forward
     # 2 * world updates' samples at once (steps() default), which keeps their host dispatch off the per-update path.
@@ -525,7 +529,7 @@ def main():
         os.environ["PLEAS_EMULATE_ALLREDUCE_US"] = str(args.emulate_allreduce_us)
         dp = True
     cfg = {"dp": dp, "ratio": args.ratio, "prefetch_groups": args.prefetch_groups, "prefetch_memory": args.prefetch_memory,
-           "shard_optimizer": args.shard_optimizer, "gc": args.gc, "sources_per_forward": (args.sources_per_forward * ranks) or None, "lookahead": None if args.lookahead < 0 else bool(args.lookahead)}
+           "shard_optimizer": args.shard_optimizer, "gc": args.gc, "match_per_forward": args.match_per_forward or None, "sources_per_forward": (args.sources_per_forward * ranks) or None, "lookahead": None if args.lookahead < 0 else bool(args.lookahead)}
     log("spec (%d groups, %.2f s on the host, outside `value`) + %d synthetic batches resident" % (len(spec), spec_s, len(pool.items)))
 
     def job(phases=None):
@@ -654,6 +658,7 @@ def main():
                                "" if full else " (SHORTENED job: not a benchmark result)"),
                 "solver": "adam", "parallelism": "dp%d" % world,
                 "sources_per_forward": cfg["sources_per_forward"] or 2 * ranks,
+                "matching_batches_per_forward": cfg["match_per_forward"] or 2,
                 "host_gc": "collected once per job while the LAP kernel runs" if args.gc == "lap" else "interpreter default",
                 "not_in_value": "get_permutation_spec %.2f s (host, once per model)" % spec_s,
             },

@@ -387,6 +387,40 @@ def test_full_size_planted_permutation_resnet50():
         assert (perm[k] == inv[k]).all(), k
 
 
+def test_matching_several_batches_per_forward_equals_one_by_one(tiny_bottleneck):
+    """``batches_per_forward``: k batches go through the twin forward as ONE forward of the concatenated batch, every
+    tracked node (and every derived BatchNorm node) is still contracted per batch -- the distance epilogue is per batch
+    (reference activation_matching.py:31-46, :123-134).  Same costs as one forward per batch up to the vendor kernels'
+    rounding at another batch size, same assignments; 7 batches, so every group size leaves a smaller last forward.  Models
+    whose BatchNorm uses batch statistics are never concatenated: bit-identical to one forward per batch."""
+    from pleas_merging_amd import hip_ops
+    from pleas_merging_amd.core.solvers import hip_solve_lsa
+    from pleas_merging_amd.methods.activation_matching import accumulate_costs_fused, solve_all
+
+    t = tiny_bottleneck
+    m1, m2 = _cuda_pair(t)
+    data = (t.batches() + t.batches())[:7]
+    data = [(x + 0.01 * i, y) for i, (x, y) in enumerate(data)]
+    want = accumulate_costs_fused(t.spec, m1, m2, data, 7, hip_ops.EPI_NEG_CDIST, batches_per_forward=1)
+    want_perm = solve_all(want, hip_solve_lsa)
+    want = {k: v.clone() for k, v in want.items()}
+    for per in (2, 3, 8, None):
+        got = accumulate_costs_fused(t.spec, m1, m2, data, 7, hip_ops.EPI_NEG_CDIST, batches_per_forward=per)
+        perm = solve_all(got, hip_solve_lsa)
+        for k in t.spec:
+            assert _rel(got[k], want[k]) < 1e-5, (per, k, _rel(got[k], want[k]))
+            assert torch.equal(perm[k], want_perm[k]), (per, k)
+    for m in (m1, m2):
+        m.train()
+    a = accumulate_costs_fused(t.spec, m1, m2, data, 7, hip_ops.EPI_NEG_CDIST, batches_per_forward=1)
+    a = {k: v.clone() for k, v in a.items()}
+    for m in (m1, m2):          # the first pass moved the running statistics (not used in train mode) -- same start again
+        m.load_state_dict({k: v.cuda() for k, v in (t.m1 if m is m1 else t.m2).state_dict().items()})
+    b = accumulate_costs_fused(t.spec, m1, m2, data, 7, hip_ops.EPI_NEG_CDIST, batches_per_forward=4)
+    for k in t.spec:
+        assert torch.equal(a[k], b[k]), k
+
+
 def test_fused_source_forwards_match_module_forwards(tiny_bottleneck):
     """BN + add + ReLU folded into one HIP pass (default) vs the sources run module by module: same taps up to the
     fp32 rounding of the fold, same fitted weights within the training tolerance."""

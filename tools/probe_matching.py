@@ -24,9 +24,9 @@ def run(n, **kw):
     accumulate_costs_fused(spec, m1, m2, data(), n, hip_ops.EPI_NEG_CDIST, **kw)
     torch.cuda.synchronize(); t1 = time.time()
     gaps = [b - a for a, b in zip(stamps[10:-1], stamps[11:])]
-    return statistics.median(gaps) * 1e3, (t1 - stamps[10]) / (len(stamps) - 10) * 1e3, (stamps[0] - t0)
+    return statistics.median(gaps) * 1e3, (t1 - stamps[16]) / (n - 16) * 1e3, (stamps[0] - t0)
 for rep in range(3):
-    for tag, kw in (("vendor BN modules", {"fuse_bn": False}), ("fused BN, contracted", {"derive_bn": False}),
-                    ("fused BN, derived", {})):
-        host, wall, build = run(60, **kw)
+    for tag, kw in (("fused, derived, 1 per forward", {"batches_per_forward": 1}), ("fused, derived, 2 per forward", {"batches_per_forward": 2}),
+                    ("fused, derived, 4 per forward", {"batches_per_forward": 4}), ("fused, derived, 8 per forward", {"batches_per_forward": 8})):
+        host, wall, build = run(64, **kw)
         print("%-27s: host per batch (median) %.2f ms, wall per batch %.2f ms, build %.3f s" % (tag, host, wall, build), flush=True)
