@@ -702,8 +702,7 @@ constexpr int fLanes = 3;          // side streams (+ the caller's stream = four
 struct FwdSideStreams {
     hipStream_t streams[fLanes];
     hipEvent_t forked, joined[fLanes];
-    hipEvent_t t0[24], t1[24];     // per launch unit: around its kernel, on its lane (one calibration launch per plan)
-    bool ok = false, timed = false;
+    bool ok = false;
 };
 static FwdSideStreams& fwd_side_streams() {
     // one set per device (streams belong to the device that was current when they were created)
@@ -723,10 +722,6 @@ static FwdSideStreams& fwd_side_streams() {
             ok = hipStreamCreateWithFlags(&s.streams[i], hipStreamNonBlocking) == hipSuccess &&
                  hipEventCreateWithFlags(&s.joined[i], hipEventDisableTiming) == hipSuccess;
         s.ok = ok;
-        bool timed = ok;
-        for (int f = 0; timed && f < 24; ++f)
-            timed = hipEventCreate(&s.t0[f]) == hipSuccess && hipEventCreate(&s.t1[f]) == hipSuccess;
-        s.timed = timed;
     }
     return s;
 }
@@ -797,6 +792,18 @@ struct FwdPlan {
     // lanes from MEASURED durations: launch kCalibAt of a plan brackets every form's kernel with events on its lane; a
     // later launch that finds them complete deals the forms again, longest measured duration first
     int launches = 0, calib = 0;       // calib: 0 not measured yet, 1 events recorded, 2 lanes dealt from measurements
+    // the calibration launch's events, around every unit's kernel on its lane.  They belong to the PLAN (a slot of the plan
+    // cache, alive for the process): two plans that calibrate at the same time must not read each other's timings.
+    hipEvent_t t0[24], t1[24];
+    int timed = 0;                     // 0 events not created yet, 1 created, -1 creation failed (no calibration)
+    bool timing_events() {
+        if (timed == 0) {
+            timed = 1;
+            for (int u = 0; u < 24 && timed == 1; ++u)
+                if (hipEventCreate(&t0[u]) != hipSuccess || hipEventCreate(&t1[u]) != hipSuccess) timed = -1;
+        }
+        return timed == 1;
+    }
 };
 constexpr int fMaxUnits = 24;
 static PlanCache<FwdPlan, 1> g_fplans;
@@ -1178,11 +1185,11 @@ extern "C" int pleas_fwd_batch(const pleas_fwd_layer* layers, int n_layers, floa
         ++P.launches;
         if (P.calib == 1) {          // the calibration launch's events: all complete?  then cut long units and deal the lanes
             bool ready = true;
-            for (int u = 0; ready && u < active; ++u) ready = hipEventQuery(side.t1[u]) == hipSuccess;
+            for (int u = 0; ready && u < active; ++u) ready = hipEventQuery(P.t1[u]) == hipSuccess;
             if (ready) {
                 for (int u = 0; u < active; ++u) {
                     float ms = 0.f;
-                    P.units[u].ms = hipEventElapsedTime(&ms, side.t0[u], side.t1[u]) == hipSuccess ? ms : 0.0;
+                    P.units[u].ms = hipEventElapsedTime(&ms, P.t0[u], P.t1[u]) == hipSuccess ? ms : 0.0;
                 }
                 fwd_schedule_measured(P);
                 P.calib = 2;
@@ -1191,7 +1198,7 @@ extern "C" int pleas_fwd_batch(const pleas_fwd_layer* layers, int n_layers, floa
             }
             (void)hipGetLastError();   // hipEventQuery's "not ready" is not an error of this call
         }
-        const bool measure = fork && calibrate && side.timed && P.calib == 0 && P.launches == kCalibAt && active <= fMaxUnits;
+        const bool measure = fork && calibrate && P.calib == 0 && P.launches == kCalibAt && active <= fMaxUnits && P.timing_events();
         if (fork) PLEAS_HIP_CHECK(hipEventRecord(side.forked, stream));
         bool lane_used[fLanes + 1] = {false};
         for (size_t o = 0; o < P.units.size(); ++o) {
@@ -1204,14 +1211,14 @@ extern "C" int pleas_fwd_batch(const pleas_fwd_layer* layers, int n_layers, floa
             const dim3 grid((unsigned)un.count);
             const FwdItemDev* its = items + un.begin;
             const size_t lds = P.form_lds[f];
-            if (measure) PLEAS_HIP_CHECK(hipEventRecord(side.t0[o], st));
+            if (measure) PLEAS_HIP_CHECK(hipEventRecord(P.t0[o], st));
             switch (f) {
 #define PLEAS_FWD_LAUNCH(F) case F: hipLaunchKernelGGL(fwd_batch_kernel<F>, grid, dim3(fThreads), lds, st, dl, its, parts); break
                 PLEAS_FWD_LAUNCH(0); PLEAS_FWD_LAUNCH(1); PLEAS_FWD_LAUNCH(2); PLEAS_FWD_LAUNCH(3); PLEAS_FWD_LAUNCH(4);
                 PLEAS_FWD_LAUNCH(5); PLEAS_FWD_LAUNCH(6); PLEAS_FWD_LAUNCH(7); PLEAS_FWD_LAUNCH(8); PLEAS_FWD_LAUNCH(9);
 #undef PLEAS_FWD_LAUNCH
             }
-            if (measure) PLEAS_HIP_CHECK(hipEventRecord(side.t1[o], st));
+            if (measure) PLEAS_HIP_CHECK(hipEventRecord(P.t1[o], st));
         }
         if (measure) P.calib = 1;
         for (int lane = 1; lane <= fLanes; ++lane)
