@@ -515,7 +515,7 @@ static int build_neq_plan(NeqPlan& P, const pleas_neq_layer* ly, int n) {
     size_t slabs = 0;
     // XCD-aware order (common.hpp), OFF by default for this kernel (PLEAS_XCD_ORDER=1 turns it on): every item of one
     // (layer, K range) reads the same pixel range of the SAME input tensor (ResNet-101: 0.9 - 3.2 MB, fits the 4 MB L2 of
-    // one XCD), so they can all go to one XCD.  Measured (round 3, tools/r03_run2.sh): FETCH_SIZE x 2 falls from 8.8 GB to
+    // one XCD), so they can all go to one XCD.  Measured (round 3, tools/r03/r03_run2.sh): FETCH_SIZE x 2 falls from 8.8 GB to
     // 3.1 GB per batch (1.0 GB of inputs), the launch takes 5.89 instead of 5.72 ms -- and the six strided layers alone 1.79
     // instead of 0.83 ms, because a layer's ~200 items no longer spread over the eight XCDs.  MFMA-issue bound, not L2 bound.
     std::vector<XcdWork<NeqItemDev>> work;
