@@ -238,8 +238,51 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradIt
         __syncthreads();
     }
 
-    // epilogue: direct (S == 1) into the standard [Cout][Cin][R] gradient, else into this split's slab
+    // epilogue: direct (S == 1) into the gradient ([Cout][Cin][R], or kernel-position-major [Cout][R][Cin]), else into this
+    // split's slab ([S][Cout][R][Cin]).  Wherever the Cin axis is contiguous in the destination (slabs, kernel-position-major
+    // gradients, 1x1 layers) the accumulators go through LDS once ([co][TN + 4]; the staging buffers are free after the K
+    // loop's last barrier) and every thread writes 16-byte runs along ci; otherwise one element per lane as before.
     const int R = L.KH * L.KW;
+    const bool kpos = (L.flags & PLEAS_WGRAD_KPOS_MAJOR) != 0;
+    const bool rows = (L.S > 1 || kpos || R == 1) && (L.Cin & 3) == 0 && (((size_t)(L.S > 1 ? L.slab : L.out)) & 15) == 0;
+    if (rows) {
+        constexpr int EL = TN + 4, VPT = TM * TN / 4 / cThreads;
+        float* Ct = smem;
+#pragma unroll
+        for (int sm = 0; sm < MTM; ++sm)
+#pragma unroll
+            for (int sn = 0; sn < MTN; ++sn) {
+                const int lci = wn * (TN / 2) + sn * 32 + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int lco = wm * (TM / 2) + sm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    Ct[lco * EL + lci] = acc[sm][sn][r];
+                }
+            }
+        __syncthreads();
+        const size_t row_len = (size_t)R * L.Cin;          // floats per output channel in the row-contiguous layouts
+        gfloat* dst = L.S > 1 ? PLEAS_GLOBAL_W(L.slab) + (size_t)it.split * L.Cout * row_len : PLEAS_GLOBAL_W(L.out);
+        const bool add = L.S == 1 && (L.flags & PLEAS_WGRAD_ACCUMULATE);
+        f32x4 old[VPT];
+        if (add) {
+#pragma unroll
+            for (int q = 0; q < VPT; ++q) {
+                const int v = tid + q * cThreads, lco = v / (TN / 4), lci = (v % (TN / 4)) * 4;
+                const bool in = i0 + lco < L.Cout && j0 + lci < L.Cin;
+                old[q] = *(const __attribute__((address_space(1))) f32x4*)(dst + (in ? (size_t)(i0 + lco) * row_len + (size_t)it.r * L.Cin + j0 + lci : 0));
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < VPT; ++q) {
+            const int v = tid + q * cThreads, lco = v / (TN / 4), lci = (v % (TN / 4)) * 4;
+            if (i0 + lco < L.Cout && j0 + lci < L.Cin) {
+                f32x4 val = *reinterpret_cast<const f32x4*>(Ct + lco * EL + lci);
+                if (add) val += old[q];
+                *(__attribute__((address_space(1))) f32x4*)(dst + (size_t)(i0 + lco) * row_len + (size_t)it.r * L.Cin + j0 + lci) = val;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int sm = 0; sm < MTM; ++sm)
 #pragma unroll
@@ -250,9 +293,8 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradIt
                 const int co = i0 + wm * (TM / 2) + sm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (co < L.Cout && ci < L.Cin) {
                     if (L.S == 1) {
-                        const size_t o = (L.flags & PLEAS_WGRAD_KPOS_MAJOR)
-                                             ? (size_t)co * ((size_t)R * L.Cin) + (size_t)it.r * L.Cin + ci
-                                             : ((size_t)co * L.Cin + ci) * R + it.r;
+                        const size_t o = kpos ? (size_t)co * ((size_t)R * L.Cin) + (size_t)it.r * L.Cin + ci
+                                              : ((size_t)co * L.Cin + ci) * R + it.r;
                         gfloat* outp = PLEAS_GLOBAL_W(L.out);
                         outp[o] = (L.flags & PLEAS_WGRAD_ACCUMULATE) ? outp[o] + acc[sm][sn][r] : acc[sm][sn][r];
                     } else
