@@ -620,8 +620,15 @@ def main():
         # `achieved` counts the flops the contraction kernel EXECUTES.  The path's algorithmic work per matching batch
         # (6.368e10 flop per sample for ResNet-101, every tracked node contracted) is larger: the 104
         # tracked BatchNorm nodes are derived from their convolution node in the reduce pass, not contracted.
+        # one contraction launch covers the batches of one twin forward (--match-per-forward): batches per launch, from the
+        # launches this rank made
+        gram_batches = 1.0
+        if roofs["gram_partial"]["launches"]:
+            mine = len(range(rank, n_match, world)) * args.steps
+            gram_batches = mine / roofs["gram_partial"]["launches"]
+            roofs["gram_partial"]["matching_batches_per_launch"] = round(gram_batches, 3)
         if args.arch == "resnet101" and roofs["gram_partial"]["launches"]:
-            per_launch = 6.368e10 * args.batch      # whole batches per rank: matching shards batch indices, not samples
+            per_launch = 6.368e10 * args.batch * gram_batches      # whole batches per rank: matching shards batch indices
             us = roofs["gram_partial"]["avg_launch_us"]
             roofs["gram_partial"]["path_equivalent"] = {
                 "flop_per_launch": per_launch, "tflops": round(per_launch / (us * 1e-6) / 1e12, 2) if us else 0.0,
@@ -638,6 +645,8 @@ def main():
                     roofs[key]["traffic_refused"] = "profiles/%s was measured on another version of %s" % (fname, ", ".join(stale))
                     continue
                 roofs[key]["traffic"] = blob.get("hbm_bytes_per_launch")
+                if key == "gram_partial" and roofs[key]["traffic"]:      # the file is per matching batch
+                    roofs[key]["traffic"] = round(roofs[key]["traffic"] * gram_batches)
                 roofs[key]["traffic_source"] = "profiles/" + fname
                 if roofs[key]["traffic"] and roofs[key]["avg_launch_us"]:    # north_star: rocprof HBM GB/s of the accumulation
                     roofs[key]["hbm_gbps"] = round(roofs[key]["traffic"] / (roofs[key]["avg_launch_us"] * 1e-6) / 1e9, 1)

@@ -185,6 +185,57 @@ def test_normal_eq_plan_contracts_one_block_per_lag_class():
     assert lib.pleas_normal_eq_plan_info(None, 0, info) == -22 and lib.pleas_normal_eq_finalize(None, 0, None) == -22
 
 
+def test_weight_matching_independent_runs_equal_the_sequential_sweep(tiny_basic, tiny_bottleneck):
+    """On the device consecutive visits that do not depend on each other share one grouped contraction and one LAP launch
+    (``_Visitor.independent_run``): no group of a run scores a tensor that an earlier group of the run permutes, so every
+    score matrix is what the reference's one-by-one sweep (weight_matching.py:59-91) computes at that visit.  Checked on
+    the host through the plug-point path: (1) the rule itself on the ResNet-101 spec, (2) a sweep in runs gives the same
+    permutations and score matrices as the sweep one visit at a time, bit for bit."""
+    import importlib
+
+    from pleas_merging_amd.core.utils import spec_from_json
+
+    wm = importlib.import_module("pleas_merging_amd.methods.weight_matching")    # the package re-exports the FUNCTION by that name
+
+    host_inner = lambda a, b, axis: torch.einsum("ik,jk->ij", a.movedim(axis, 0).reshape(a.shape[axis], -1),
+                                                 b.movedim(axis, 0).reshape(b.shape[axis], -1))
+    # (1) the independence rule on a big spec, random orders
+    spec = spec_from_json(json.load(open(os.path.join(GOLDEN, "spec_resnet101.json")))["spec"])
+    keys = sorted({ax.key for g in spec.values() for ax in g.state})
+    sd = {k: torch.zeros(1) for k in keys}
+    walker = wm._Visitor(spec, [sd], [dict(sd)], ("running_mean", "running_var"), True, host_inner, orc.solve_lsa, batch_runs=True)
+    names = list(spec.keys())
+    rng = torch.Generator().manual_seed(0)
+    lengths = []
+    for _ in range(5):
+        order = [names[i] for i in torch.randperm(len(names), generator=rng)]
+        at = 0
+        while at < len(order):
+            end = walker.independent_run(order, at)
+            assert end > at
+            for j in range(at, end):
+                scored = {ax.key for _, ax in walker.axes[order[j]]}
+                for i in range(at, j):
+                    assert not scored & {ax.key for ax in spec[order[i]].state}, (order[i], order[j])
+            lengths.append(end - at)
+            at = end
+    assert sum(lengths) == 5 * len(names) and max(lengths) >= 4      # most visits of a ResNet sweep do share launches
+    # (2) same result as one visit at a time
+    for t in (tiny_basic, tiny_bottleneck):
+        outs = []
+        for runs in (False, True):
+            real = wm._Visitor
+            wm._Visitor = lambda *a, _real=real, _runs=runs, **k: _real(*a, batch_runs=_runs, **k)
+            try:
+                outs.append(wm.weight_matching(t.spec, t.m1.state_dict(), t.m2.state_dict(), max_iter=20, seed=0, verbose=False,
+                                               lsa_solver=orc.solve_lsa, cross_weights=host_inner, return_costs=True))
+            finally:
+                wm._Visitor = real
+        (p0, c0), (p1, c1) = outs
+        for k in t.spec:
+            assert torch.equal(p0[k], p1[k]) and torch.equal(c0[k], c1[k]), k
+
+
 def test_forward_launch_units_partition_every_form():
     """Host side of pleas_fwd_batch (no GPU): the grouped forward is launched as UNITS -- a tile form over a slice of its
     items, on one of four lanes.  A fresh plan has one unit per form; after a calibration launch a form that outlasts a
