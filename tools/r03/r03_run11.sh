@@ -7,4 +7,5 @@ timeout -k 10 400 python tools/probe_weight_matching.py resnet18 resnet50 resnet
 timeout -k 10 300 python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-alt-solver > $O/r03_bench_short.json 2> $O/r03_bench_short.err; echo "bench rc $?"
 python -c "
 import json; d=json.load(open('$O/r03_bench_short.json')); print(d['value'], d['roofline']['traffic'], d['roofline'].get('hbm_gbps'), {k:(v.get('traffic'), v.get('hbm_gbps'), v.get('traffic_refused')) for k,v in d['roofline_other'].items()})"
+timeout -k 10 120 python tools/probe_bn_act.py > $O/r03_probe_bn_act.txt 2>&1; grep -v Warn $O/r03_probe_bn_act.txt | tail -40
 exit $rc
