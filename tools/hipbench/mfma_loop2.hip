@@ -143,6 +143,88 @@ static void run_wab(const char* tag, const float* src, int rows_total, int krow)
     hipFree(out);
 }
 
+// mode 4 (round 3): PRODUCER / CONSUMER waves.  512 threads: waves 0-3 only read LDS and issue MFMAs (the 2 x 2 wave grid of
+// the 128 x 128 tile, as before), waves 4-7 only stage: ds_write chunk c+1 (loaded during the previous iteration) into the
+// other buffer, then issue the global loads of chunk c+2.  One barrier per chunk for all eight waves.  Two workgroups per CU
+// = four waves per SIMD, i.e. <= 128 VGPRs per wave (the consumers' 64 accumulators + fragments fit; the producers need ~40).
+// Question: does taking every VMEM / ds_write / address instruction out of the MFMA waves' streams lift the loop?
+__global__ __launch_bounds__(512, 4) void loop_kernel_pc(const float* __restrict__ src, float* out, int chunks, int rows_total, int krow) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, t = tid & 255, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+    const bool producer = tid >= 256;
+    for (int i = tid; i < 4 * TILE * kLds; i += 512) smem[i] = (float)((i * 7 + blockIdx.x) % 13) * 0.01f;
+    const int row0 = (int)((blockIdx.x * 2u * TILE) % (unsigned)(rows_total - 2 * TILE));
+    float s = 0.f;
+    if (producer) {
+        const int srow = t >> 3, scol = (t & 7) * 4;
+        f32x4 ra[4], rb[4];
+        auto load = [&](int c) {
+            const int k0 = (c * 32) % (krow - 32) / 4 * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ra[q] = *reinterpret_cast<const f32x4*>(src + (size_t)(row0 + srow + 32 * q) * krow + k0 + scol);
+                rb[q] = *reinterpret_cast<const f32x4*>(src + (size_t)(row0 + TILE + srow + 32 * q) * krow + k0 + scol);
+            }
+        };
+        load(1);
+        for (int c = 0; c < chunks; ++c) {
+            const int buf = c & 1;
+            __syncthreads();
+            float* wa = smem + (buf ^ 1) * TILE * kLds;
+            float* wb = smem + (2 + (buf ^ 1)) * TILE * kLds;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                *reinterpret_cast<f32x4*>(wa + (srow + 32 * q) * kLds + scol) = ra[q];
+                *reinterpret_cast<f32x4*>(wb + (srow + 32 * q) * kLds + scol) = rb[q];
+            }
+            load(c + 2);
+        }
+        s = ra[0][0] + rb[0][0];
+    } else {
+        f32x16 acc[2][2];
+        for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        for (int c = 0; c < chunks; ++c) {
+            const int buf = c & 1;
+            __syncthreads();
+            const float* a = smem + buf * TILE * kLds + (wm * 64 + (lane & 31)) * kLds + 4 * (lane >> 5);
+            const float* b = smem + (2 + buf) * TILE * kLds + (wn * 64 + (lane & 31)) * kLds + 4 * (lane >> 5);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                f32x4 fa[2], fb[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    fa[q] = *reinterpret_cast<const f32x4*>(a + q * 32 * kLds + kk * 8);
+                    fb[q] = *reinterpret_cast<const f32x4*>(b + q * 32 * kLds + kk * 8);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+                        for (int sn = 0; sn < 2; ++sn)
+                            acc[sm][sn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sm][e], fb[sn][e], acc[sm][sn], 0, 0, 0);
+            }
+        }
+        for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int r = 0; r < 16; ++r) s += acc[a][b][r];
+    }
+    out[(size_t)blockIdx.x * 512 + tid] = s;
+}
+
+static void run_pc(const char* tag, const float* src, int rows_total, int krow) {
+    const int chunks = 512, grid = 256 * 2 * 8;
+    const size_t lds = 76 * 1024;
+    hipFuncSetAttribute((const void*)loop_kernel_pc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    float* out; hipMalloc(&out, (size_t)grid * 512 * 4);
+    hipLaunchKernelGGL(loop_kernel_pc, dim3(grid), dim3(512), lds, 0, src, out, chunks, rows_total, krow);
+    hipDeviceSynchronize();
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, 0);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(loop_kernel_pc, dim3(grid), dim3(512), lds, 0, src, out, chunks, rows_total, krow);
+    hipEventRecord(b, 0); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b); ms /= 3;
+    const double flop = (double)grid * 4 * chunks * 64 * 4096.0;
+    printf("%-62s %.2f ms -> %.1f TF/s (%.3f of 157.3)\n", tag, ms, flop / (ms * 1e-3) / 1e12, flop / (ms * 1e-3) / 1e12 / 157.3);
+    hipFree(out);
+}
+
 template <int MODE>
 static void run(const char* tag, const float* src, int rows_total, int krow) {
     const int chunks = 512, grid = 256 * 2 * 8;
@@ -169,6 +251,8 @@ int main() {
     run<2>("mode 2: + global loads (822 MB footprint: HBM)", big, 65536, krow);
     run_wab("mode 3: write-after-barrier order (12.8 MB footprint)", small, 1024, krow);
     run_wab("mode 3: write-after-barrier order (822 MB footprint: HBM)", big, 65536, krow);
+    run_pc("mode 4: producer / consumer waves, 512 threads (12.8 MB footprint)", small, 1024, krow);
+    run_pc("mode 4: producer / consumer waves, 512 threads (822 MB footprint: HBM)", big, 65536, krow);
     run<2>("mode 2 again (12.8 MB)", small, 1024, krow);
     run_wab("mode 3 again (12.8 MB)", small, 1024, krow);
     return 0;
