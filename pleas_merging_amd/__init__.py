@@ -4,4 +4,4 @@ Host side mirrors the reference's ``pleas.core`` / ``pleas.methods`` API; the
 compute is done by hand-written gfx950 HIP kernels behind the C-ABI declared in
 ``include/pleas_hip.h`` (library ``pleas_merging_amd/csrc/libpleas_hip.so``).
 """
-__version__ = "0.2.0"
+__version__ = "0.3.0"
