@@ -170,6 +170,17 @@ int pleas_bn_act(const float* x, const float* scale, const float* shift, const f
 int pleas_bn_act_tracked(const float* x, const float* scale, const float* shift, const float* res, float* y_bn,
                          float* y_sum, float* y, int64_t n, int channels, int64_t inner, int relu, void* stream);
 
+/* The same map followed by a max pooling window, one pass (a ResNet's stem: bn1 -> relu -> maxpool).
+ *
+ * Replaces: BatchNorm2d -> ReLU -> nn.MaxPool2d(kernel, stride, padding) of a frozen source forward
+ *   (pleas/methods/pleas_merging.py:267-268 runs the whole model; only Conv2d / Linear inputs and outputs are hooked,
+ *   :197-243, so the full-resolution activation between ReLU and the pooling is consumed by nothing and is not written).
+ *   y[n][c][oh][ow] = max over the KH x KW window at (oh * stride - pad, ow * stride - pad) of act(x * scale[c] + shift[c]);
+ *   out-of-range taps never win (torch pads with -inf), a NaN tap does; floor-mode output size, dilation 1.
+ *   scale == NULL: plain max pooling of x.  y: [n][channels][Ho][Wo], must not alias x. */
+int pleas_bn_act_maxpool(const float* x, const float* scale, const float* shift, float* y, int64_t n, int channels, int H,
+                         int W, int KH, int KW, int stride, int pad, int relu, void* stream);
+
 /* Train-mode BatchNorm of the matching forward, folded to the same per-channel affine map.
  *
  * Replaces: the BatchNorm2d modules inside the cross module's forward when the caller's models are in train mode --

@@ -160,6 +160,45 @@ __global__ __launch_bounds__(kEwThreads) void bn_act_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------
+// The same affine map + ReLU followed by a max pooling window (the stem of a ResNet: bn1 -> relu -> maxpool), one pass:
+//   y[n][c][oh][ow] = max over the window of act(x[n][c][ih][iw] * scale[c] + shift[c]),  padding = -inf (never wins)
+// The full-resolution activation between ReLU and the pooling is never written (nothing between two hooked layers is
+// consumed by the PLeaS loop): x is read once, y is a quarter of it.  scale == NULL: plain max pooling of x.
+// A NaN in the window wins, as in the vendor's pooling kernel.  One thread per output element; the rows a window shares
+// with the next output row are re-read from L1/L2 by the same workgroup.
+__global__ __launch_bounds__(kEwThreads) void bn_act_pool_kernel(const float* __restrict__ x,
+                                                                 const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, float* __restrict__ y,
+                                                                 int64_t total, unsigned channels, int H, int W, int Ho,
+                                                                 int Wo, int KH, int KW, int stride, int pad, int relu) {
+    const unsigned plane_o = (unsigned)Ho * (unsigned)Wo;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned row = (unsigned)(idx / plane_o);      // n * channels + c
+        const unsigned at = (unsigned)(idx - (int64_t)row * plane_o);
+        const int oh = (int)(at / (unsigned)Wo), ow = (int)(at % (unsigned)Wo);
+        const unsigned c = row % channels;
+        const float a = scale ? scale[c] : 1.f, b = scale ? shift[c] : 0.f;
+        const float* src = x + (int64_t)row * H * W;
+        const int h0 = oh * stride - pad, w0 = ow * stride - pad;
+        float best = -__builtin_inff();
+        for (int kh = 0; kh < KH; ++kh) {
+            const int ih = h0 + kh;
+            if (ih < 0 || ih >= H) continue;
+            for (int kw = 0; kw < KW; ++kw) {
+                const int iw = w0 + kw;
+                if (iw < 0 || iw >= W) continue;
+                float v = src[ih * W + iw];
+                if (scale) v = fmaf(v, a, b);
+                if (relu) v = fmaxf(v, 0.f);
+                if (v > best || v != v) best = v;
+            }
+        }
+        y[idx] = best;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kEwThreads) void masked_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                                  const float* __restrict__ mask, float* __restrict__ m,
                                                                  float* __restrict__ v, int64_t n, float one_minus_b1,
@@ -311,6 +350,78 @@ extern "C" int pleas_bn_act_tracked(const float* x, const float* scale, const fl
                                     float* y_sum, float* y, int64_t n, int channels, int64_t inner, int relu,
                                     void* stream_) {
     return bn_act_launch(x, scale, shift, res, y_bn, y_sum, y, n, channels, inner, relu, stream_);
+}
+
+// The ResNet stem's window (3 x 3, stride 2, padding 1) on rows of a multiple of 8 columns: one thread = FOUR adjacent
+// outputs of one row = columns 8q-1 .. 8q+7 of three input rows: two 16-byte loads and one scalar per row (9 loads for 4
+// outputs, where the general kernel issues 36), one 16-byte store.  32-bit index arithmetic (`units` < 2^31, host-checked).
+__global__ __launch_bounds__(kEwThreads) void bn_act_pool3s2_kernel(const float* __restrict__ x,
+                                                                    const float* __restrict__ scale,
+                                                                    const float* __restrict__ shift,
+                                                                    float* __restrict__ y, unsigned units,
+                                                                    unsigned channels, int H, int W, int Ho, int relu) {
+    const unsigned Wq = (unsigned)W / 8, per_plane = (unsigned)Ho * Wq;
+    const float ninf = -__builtin_inff();
+    for (unsigned u = blockIdx.x * blockDim.x + threadIdx.x; u < units; u += gridDim.x * blockDim.x) {
+        const unsigned row = u / per_plane, at = u - row * per_plane;
+        const int oh = (int)(at / Wq), q = (int)(at % Wq);
+        const unsigned c = row % channels;
+        const float a = scale ? scale[c] : 1.f, b = scale ? shift[c] : 0.f;
+        const float* src = x + (int64_t)row * H * W + 8 * q;
+        float best[4] = {ninf, ninf, ninf, ninf};
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = 2 * oh - 1 + kh;
+            if (ih < 0 || ih >= H) continue;
+            const float* p = src + ih * W;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
+            float v[9];
+            v[0] = q > 0 ? p[-1] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[1 + e] = lo[e], v[5 + e] = hi[e];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) {
+                if (scale) v[e] = fmaf(v[e], a, b);
+                if (relu) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (q == 0) v[0] = ninf;       // the padding column never wins
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const float w = v[2 * j + t];
+                    if (w > best[j] || w != w) best[j] = w;
+                }
+        }
+        f32x4 o = {best[0], best[1], best[2], best[3]};
+        reinterpret_cast<f32x4*>(y)[u] = o;       // y[row][oh][4q .. 4q+3]: unit order IS the output order
+    }
+}
+
+extern "C" int pleas_bn_act_maxpool(const float* x, const float* scale, const float* shift, float* y, int64_t n,
+                                    int channels, int H, int W, int KH, int KW, int stride, int pad, int relu,
+                                    void* stream_) {
+    if (!x || !y || (scale && !shift)) return bad_arg("null pointer");
+    if (n < 0 || channels <= 0 || H <= 0 || W <= 0) return bad_arg("negative size");
+    if (KH <= 0 || KW <= 0 || stride <= 0 || pad < 0 || 2 * pad > KH || 2 * pad > KW)
+        return bad_arg("pooling window: need kernel > 0, stride > 0, 0 <= pad <= kernel / 2");
+    if (H + 2 * pad < KH || W + 2 * pad < KW) return bad_arg("pooling window larger than the padded input");
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;     // floor mode
+    const int64_t total = n * channels * Ho * Wo;
+    if (total == 0) return PLEAS_OK;
+    if (n * channels >= ((int64_t)1 << 31) || (int64_t)H * W >= ((int64_t)1 << 31)) return bad_arg("tensor too large");
+    hipStream_t stream = (hipStream_t)stream_;
+    ProfScope prof(kProfBnAct, 0.0, ((double)n * channels * H * W + (double)total) * sizeof(float), stream);
+    const bool stem = KH == 3 && KW == 3 && stride == 2 && pad == 1 && W % 8 == 0 && total / 4 < ((int64_t)1 << 31) &&
+                      (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
+    if (stem)
+        hipLaunchKernelGGL(bn_act_pool3s2_kernel, dim3(ew_grid(total / 4)), dim3(kEwThreads), 0, stream, x, scale, shift, y,
+                           (unsigned)(total / 4), (unsigned)channels, H, W, Ho, relu);
+    else
+        hipLaunchKernelGGL(bn_act_pool_kernel, dim3(ew_grid(total)), dim3(kEwThreads), 0, stream, x, scale, shift, y, total,
+                           (unsigned)channels, H, W, Ho, Wo, KH, KW, stride, pad, relu);
+    PLEAS_LAUNCH_CHECK("bn_act_pool_kernel");
+    return PLEAS_OK;
 }
 
 extern "C" int pleas_masked_adam(float* p, const float* g, const float* mask, float* m, float* v, int64_t n, float lr,

@@ -303,6 +303,29 @@ def bn_act(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, res: Optio
     return y
 
 
+def bn_act_maxpool(x: torch.Tensor, scale: Optional[torch.Tensor], shift: Optional[torch.Tensor], kernel: Tuple[int, int],
+                   stride: int, padding: int, relu: bool = True) -> torch.Tensor:
+    """``max_pool2d(act(x * scale[c] + shift[c]), kernel, stride, padding)`` of a contiguous fp32 NCHW tensor in one pass
+    (``pleas_bn_act_maxpool``); ``scale is None``: plain max pooling."""
+    _need_gpu(x) if scale is None else _need_gpu(x, scale, shift)
+    if x.dim() != 4 or x.dtype != torch.float32:
+        raise PleasHipError("bn_act_maxpool needs an fp32 [N, C, H, W] tensor")
+    x = x.contiguous()
+    N, C, H, W = x.shape
+    if scale is not None and (scale.numel() != C or shift.numel() != C or not scale.is_contiguous() or not shift.is_contiguous()):
+        raise PleasHipError("bn_act_maxpool: scale/shift must be contiguous with one entry per channel")
+    KH, KW = kernel
+    if stride <= 0:
+        raise PleasHipError("bn_act_maxpool: stride must be positive")
+    Ho, Wo = (H + 2 * padding - KH) // stride + 1, (W + 2 * padding - KW) // stride + 1
+    y = torch.empty((N, C, max(Ho, 0), max(Wo, 0)), dtype=torch.float32, device=x.device)
+    rc = _lib.lib().pleas_bn_act_maxpool(x.data_ptr(), scale.data_ptr() if scale is not None else None,
+                                         shift.data_ptr() if scale is not None else None, y.data_ptr(), N, C, H, W, KH, KW,
+                                         stride, padding, int(relu), _stream())
+    _lib.check(rc, "pleas_bn_act_maxpool")
+    return y
+
+
 def bn_act_tracked(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, res: Optional[torch.Tensor], relu: bool,
                    keep_bn: bool = True):
     """One pass, every node of the chain kept: returns ``(bn, sum, act)`` = ``(x * scale + shift, bn + res, relu(sum))``;

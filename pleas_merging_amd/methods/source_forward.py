@@ -8,6 +8,8 @@ be fused.  ``fuse_bn_act`` rewrites an fx trace of the model:
     bn(x) -> relu                      =>  bn_act(x, scale, shift, None, relu=True)
     bn(x) -> (+ identity) -> relu      =>  bn_act(x, scale, shift, identity, relu=True)
     bn(x)                              =>  bn_act(x, scale, shift, None, relu=False)
+    bn(x) -> relu -> MaxPool2d         =>  bn_act_maxpool(x, scale, shift, kernel, stride, padding, relu=True)
+                                           (the stem: the full-resolution ReLU output is never written)
 
 ``scale = weight / sqrt(running_var + eps)`` and ``shift = bias - running_mean * scale`` are computed
 once in fp64.  The hooked modules are the SAME objects in the rewritten GraphModule, so hooks
@@ -29,6 +31,28 @@ from .. import hip_ops
 
 def _bn_act(x, scale, shift, res, relu):
     return hip_ops.bn_act(x, scale, shift, res, relu)
+
+
+def _bn_act_pool(x, scale, shift, kernel, stride, padding, relu):
+    return hip_ops.bn_act_maxpool(x, scale, shift, kernel, stride, padding, relu)
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+def _pool_window(node: torch.fx.Node, mods):
+    """``(kernel, stride, padding)`` when ``node`` is an ``nn.MaxPool2d`` call that ``bn_act_maxpool`` computes exactly
+    (floor mode, dilation 1, no indices, one stride and one padding for both axes); None otherwise."""
+    if node.op != "call_module" or len(node.args) != 1 or node.kwargs:
+        return None
+    m = mods.get(node.target)
+    if not isinstance(m, nn.MaxPool2d) or m.ceil_mode or m.return_indices or _pair(m.dilation) != (1, 1):
+        return None
+    kernel, stride, padding = _pair(m.kernel_size), _pair(m.stride if m.stride is not None else m.kernel_size), _pair(m.padding)
+    if stride[0] != stride[1] or padding[0] != padding[1] or 2 * padding[0] > min(kernel):
+        return None
+    return kernel, stride[0], padding[0]
 
 
 def _is_relu(node: torch.fx.Node, mods) -> bool:
@@ -88,7 +112,8 @@ def _train_fold(bn: nn.BatchNorm2d, tag: str) -> Callable:
     return fold
 
 
-def fuse_bn_act(model: nn.Module, op: Callable = _bn_act, train_stats: bool = False) -> Optional[torch.fx.GraphModule]:
+def fuse_bn_act(model: nn.Module, op: Callable = _bn_act, train_stats: bool = False,
+                pool_op: Optional[Callable] = None) -> Optional[torch.fx.GraphModule]:
     """fx copy of ``model`` (sharing its submodules) with every eval-mode BatchNorm2d chain replaced by
     ``op(x, scale, shift, residual_or_None, relu)`` -- the HIP kernel ``hip_ops.bn_act`` unless a test
     passes its own.  Returns None when the model cannot be traced or holds nothing to fold; the caller
@@ -97,7 +122,12 @@ def fuse_bn_act(model: nn.Module, op: Callable = _bn_act, train_stats: bool = Fa
     ``train_stats=True``: BatchNorm2d modules that normalise with the BATCH's statistics (train mode -- the BN-reset pass
     after merging, run_domainnet.py:327-341) are folded as well: ``scale, shift = bn_train_fold(bn, x)`` per batch,
     then the same single ``op`` pass -- x is read twice and written once, where the vendor's train-mode BatchNorm + add +
-    ReLU read or write it seven times."""
+    ReLU read or write it seven times.
+
+    ``pool_op(x, scale, shift, kernel, stride, padding, relu)`` takes a BN -> ReLU chain whose only consumer is a max
+    pooling (``hip_ops.bn_act_maxpool`` with the default ``op``; with a caller's ``op`` only when passed too)."""
+    if pool_op is None and op is _bn_act:
+        pool_op = _bn_act_pool
     try:
         graph = torch.fx.Tracer().trace(model)      # the graph alone: one code generation at the end, not two
     except Exception:  # noqa: BLE001 -- untraceable control flow: nothing to rewrite
@@ -130,6 +160,12 @@ def fuse_bn_act(model: nn.Module, op: Callable = _bn_act, train_stats: bool = Fa
                 res = add.args[1] if add.args[0] is node else add.args[0]
                 chain += [add, add_users[0]]
                 relu = True
+        window = None
+        if pool_op is not None and relu and res is None and len(chain[-1].users) == 1:
+            pool = next(iter(chain[-1].users))
+            window = _pool_window(pool, mods)
+            if window is not None:
+                chain.append(pool)
         last = chain[-1]
         with graph.inserting_before(last):
             # explicit base names: fx would otherwise derive them from the targets character by character
@@ -140,7 +176,10 @@ def fuse_bn_act(model: nn.Module, op: Callable = _bn_act, train_stats: bool = Fa
             else:
                 s = graph.create_node("get_attr", "_pleas_scale_%s" % tag, (), {}, name="bn_scale")
                 t = graph.create_node("get_attr", "_pleas_shift_%s" % tag, (), {}, name="bn_shift")
-            fused = graph.create_node("call_function", op, (node.args[0], s, t, res, relu), {}, name="bn_act")
+            if window is not None:
+                fused = graph.create_node("call_function", pool_op, (node.args[0], s, t) + window + (relu,), {}, name="bn_act_pool")
+            else:
+                fused = graph.create_node("call_function", op, (node.args[0], s, t, res, relu), {}, name="bn_act")
         last.replace_all_uses_with(fused)
         for dead in reversed(chain):
             graph.erase_node(dead)

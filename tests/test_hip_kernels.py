@@ -242,6 +242,75 @@ def test_bn_act_rejects_bad_operands(ops):
         ops.bn_act(x.cpu(), s, s)
 
 
+@pytest.mark.parametrize("shape,kernel,stride,pad", [((3, 16, 16, 16), (3, 3), 2, 1), ((2, 7, 9, 11), (3, 3), 2, 1),
+                                                      ((2, 5, 8, 8), (2, 2), 2, 0), ((1, 4, 7, 7), (3, 2), 1, 1),
+                                                      ((2, 3, 5, 5), (5, 5), 3, 2), ((4, 64, 112, 112), (3, 3), 2, 1),
+                                                      ((2, 3, 9, 8), (3, 3), 2, 1), ((1, 2, 1, 8), (3, 3), 2, 1)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_bn_act_maxpool_is_the_pooled_chain(ops, shape, kernel, stride, pad, relu):
+    """bn -> relu -> max pooling in one pass == vendor max pooling of the bn_act pass, bit for bit (same fma, and a
+    maximum does not round); without scale / shift it is the plain pooling; a NaN tap wins, padding never does."""
+    import torch.nn.functional as F
+
+    g = torch.Generator().manual_seed(33)
+    C = shape[1]
+    scale, shift = (torch.rand(C, generator=g) - 0.3).cuda(), (torch.randn(C, generator=g) - 2.0).cuda()   # mostly negative
+    x = torch.randn(shape, generator=g).cuda()
+    x[0, 0, 0, 0] = float("nan")
+    x[-1, -1, -1, -1] = float("inf")
+    want = F.max_pool2d(ops.bn_act(x, scale, shift, None, relu), kernel, stride, pad)
+    got = ops.bn_act_maxpool(x, scale, shift, kernel, stride, pad, relu)
+    assert got.shape == want.shape
+    assert torch.equal(torch.isnan(got), torch.isnan(want)) and torch.equal(got.nan_to_num(7.0), want.nan_to_num(7.0))
+    plain, plain_want = ops.bn_act_maxpool(x, None, None, kernel, stride, pad, False), F.max_pool2d(x, kernel, stride, pad)
+    assert torch.equal(plain.nan_to_num(7.0), plain_want.nan_to_num(7.0))
+
+
+def test_bn_act_maxpool_rejects_bad_operands(ops):
+    x = torch.randn(2, 4, 6, 6).cuda()
+    s = torch.ones(4).cuda()
+    with pytest.raises(ops.PleasHipError):
+        ops.bn_act_maxpool(x, s[:3], s, (3, 3), 2, 1)
+    with pytest.raises(ops.PleasHipError):
+        ops.bn_act_maxpool(x, s, s, (3, 3), 2, 2)          # padding > kernel / 2
+    with pytest.raises(ops.PleasHipError):
+        ops.bn_act_maxpool(x, s, s, (3, 3), 0, 1)
+    with pytest.raises(ops.PleasHipError):
+        ops.bn_act_maxpool(x[:, :, :2, :2], s, s, (5, 5), 1, 1)      # window larger than the padded input
+    with pytest.raises(ops.PleasHipError):
+        ops.bn_act_maxpool(x.cpu(), s, s, (3, 3), 2, 1)
+
+
+def test_source_forward_pools_the_stem_chain(ops):
+    """fuse_bn_act on a ResNet: conv1 -> bn1 -> relu -> maxpool becomes ONE bn_act_maxpool node; the hooked
+    convolutions see the same inputs / outputs as in the module-by-module forward."""
+    from pleas_merging_amd import resnet as zoo
+    from pleas_merging_amd.methods.source_forward import fuse_bn_act, _bn_act_pool
+
+    torch.manual_seed(5)
+    model = zoo.resnet18(num_classes=10).cuda().eval()
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_()
+            m.running_var.uniform_(0.5, 2.0)
+    gm = fuse_bn_act(model)
+    pooled = [n for n in gm.graph.nodes if n.op == "call_function" and n.target is _bn_act_pool]
+    assert len(pooled) == 1 and pooled[0].args[3:] == ((3, 3), 2, 1, True)
+    assert not [n for n in gm.graph.nodes if n.op == "call_module" and n.target == "maxpool"]
+    seen = {}
+    handles = [m.register_forward_hook(lambda m, i, o, n=n: seen.setdefault(n, []).append((i[0].clone(), o.clone())))
+               for n, m in model.named_modules() if isinstance(m, (torch.nn.Conv2d, torch.nn.Linear))]
+    x = torch.randn(4, 3, 64, 64, device="cuda")
+    with torch.no_grad():
+        a, b = model(x), gm(x)
+    for h in handles:
+        h.remove()
+    assert torch.allclose(a, b, rtol=1e-4, atol=1e-4)
+    for name, (first, second) in seen.items():
+        assert torch.allclose(first[0], second[0], rtol=1e-4, atol=1e-4), name
+        assert torch.allclose(first[1], second[1], rtol=1e-4, atol=1e-4), name
+
+
 def test_fwd_batch_rejects_kpos_major_with_ragged_channels(ops):
     x = torch.randn(1, 24, 4, 4).cuda()
     w = torch.randn(8, 3, 3, 24).cuda()

@@ -433,6 +433,29 @@ def test_source_forward_rewrite_keeps_values_and_hooks(tiny_bottleneck):
     for name, (first, second) in seen.items():
         assert torch.allclose(first[0], second[0], rtol=1e-4, atol=1e-5), name
         assert torch.allclose(first[1], second[1], rtol=1e-4, atol=1e-5), name
+    # a BN -> ReLU chain consumed by a max pooling alone (a ResNet's stem) becomes ONE pooled op -- only when the caller
+    # supplies it next to its own `op`
+    from pleas_merging_amd import resnet as zoo
+
+    def pool(x, s, t, kernel, stride, padding, relu):
+        return torch.nn.functional.max_pool2d(op(x, s, t, None, relu), kernel, stride, padding)
+
+    torch.manual_seed(3)
+    rn = zoo.resnet18(num_classes=10).eval()
+    for m in rn.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_()
+            m.running_var.uniform_(0.5, 2.0)
+    plain, pooled = fuse_bn_act(rn, op), fuse_bn_act(rn, op, pool_op=pool)
+    assert [n.target for n in plain.graph.nodes if n.op == "call_module" and n.target == "maxpool"] == ["maxpool"]
+    calls = [n for n in pooled.graph.nodes if n.op == "call_function" and n.target is pool]
+    assert len(calls) == 1 and calls[0].args[3:] == ((3, 3), 2, 1, True)
+    assert not [n for n in pooled.graph.nodes if n.op == "call_module" and n.target == "maxpool"]
+    xs = torch.randn(2, 3, 64, 64)
+    with torch.no_grad():
+        assert torch.allclose(rn(xs), pooled(xs), rtol=1e-4, atol=1e-5)
+    rn.maxpool.ceil_mode = True                 # a window the kernel does not compute: left to the module
+    assert not [n for n in fuse_bn_act(rn, op, pool_op=pool).graph.nodes if n.op == "call_function" and n.target is pool]
     model.train()
     assert fuse_bn_act(model, op) is None   # training-mode BN updates running stats: never folded
     model.eval()
