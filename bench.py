@@ -676,6 +676,11 @@ def main():
             "roofline": roofline,
             "roofline_other": other,
         }
+        if os.environ.get("PLEAS_GRAM_SPLIT_BF16", "0") == "1":      # the study arithmetic of the matching contraction
+            out["study"] = ("matching contraction on bf16 MFMA (three-way split of the fp32 operands, DESIGN.md 4.0): "
+                            "NOT the headline path, not a benchmark result")
+            out["metric"] = "STUDY " + out["metric"]
+            out["dtype"] = "f32 operands as 3 x bf16 (matching contraction only)"
         if args.emulate_world > 1:
             out["emulated"] = ("rank 0's share of a %d-rank job, collectives %s: NOT a benchmark result"
                                % (args.emulate_world, "replaced by a %.0f us stall of the update stream" % args.emulate_allreduce_us

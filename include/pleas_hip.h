@@ -369,6 +369,11 @@ int pleas_prof_collect(int kernel, int64_t* launches, double* total_ms, double* 
 /* Tuning hook for experiments: split-K target workgroup count and minimum K chunks per split. */
 void pleas_gram_tune(int target_blocks, int min_chunks_per_split);
 void pleas_gram_batch_tune(int item_chunks, int xcd_order);
+/* STUDY switch, off by default (also PLEAS_GRAM_SPLIT_BF16=1 in the environment, read once): the contraction kernels'
+ * 16-byte variants compute every fp32 product as six bf16-MFMA products of a three-way bf16 split of both operands
+ * (fp32 accumulate) instead of on the fp32 MFMA.  The headline path and every parity test run with it OFF; results and
+ * timings with it ON are reported as a study only (tools/probe_gram_split.py). */
+void pleas_gram_split_bf16(int on);
 void pleas_wgrad_tune(int item_chunks);
 
 #ifdef __cplusplus

@@ -27,6 +27,7 @@ namespace pleas {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kBK = 32;      // K chunk (floats) staged per step
 constexpr int kLds = 36;     // padded LDS row stride: 16-B aligned rows, conflict-free ds_read_b128
@@ -53,8 +54,34 @@ struct Stage {
     float v[PASSES][VEC];
 };
 
+// STUDY arithmetic (SPLIT = 1, off unless pleas_gram_split_bf16(1) / PLEAS_GRAM_SPLIT_BF16=1): an fp32 value as the exact
+// sum of three bf16 values, v = h1 + h2 + h3 (8 + 8 + 8 significant bits, each the round-to-nearest bf16 of what the
+// previous ones left; the exponent range of bf16 is fp32's), so that an fp32 product becomes bf16-MFMA products:
+//   x * y = x1 y1 + (x1 y2 + x2 y1) + (x2 y2 + x1 y3 + x3 y1)  + terms <= 2^-26 |x y| (dropped)
+// Six v_mfma_f32_32x32x16_bf16 (32 cycles each, K = 16) replace eight v_mfma_f32_32x32x2_f32 (64 cycles each, K = 2).
+// The split is done ONCE per element, when a K chunk goes from registers to LDS (three bf16 planes per row, the bytes
+// of an fp32 row and a half); splitting at fragment-read time instead -- every element once per wave that uses it -- was
+// bound by the conversions' issue slots (measured: 0.88 of the fp32 peak).  LDS is single-buffered here (two barriers per
+// chunk, the next chunk waits in registers); two workgroups per CU alternate between converting and multiplying.
+// Not for inf / NaN operands (inf - inf in the residual).
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int kSplitLd = 104;   // bf16 per LDS row of the split image: 3 planes x 32 k + 8 pad = 208 B (13 16-byte slots:
+                                // odd, so the 16 rows of a ds_read_b128 lane group fall on 16 different slots)
+__device__ __forceinline__ void split3(const float (&v)[4], bf16x4 (&h)[3]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 h1 = (__bf16)v[e];
+        const float r1 = v[e] - (float)h1;
+        const __bf16 h2 = (__bf16)r1;
+        const float r2 = r1 - (float)h2;
+        h[0][e] = h1;
+        h[1][e] = h2;
+        h[2][e] = (__bf16)r2;
+    }
+}
+
 // One workgroup's share: output tile (tm, tn) over K chunks [c_begin, c_end) -> slab `split`.
-template <int TILE, int VEC>
+template <int TILE, int VEC, int SPLIT = 0>
 __device__ __forceinline__ void gram_tile(const GramGeom& g, float* smem, const int tm, const int tn, const int split,
                                           const int c_begin, const int c_end) {
     constexpr int MT = TILE / 64;                    // 32x32 MFMA tiles per wave per side
@@ -63,6 +90,8 @@ __device__ __forceinline__ void gram_tile(const GramGeom& g, float* smem, const 
     constexpr int PASSES = TILE / ROWS_PER_PASS;
     float* As = smem;                         // [2][TILE][kLds]
     float* Bs = smem + 2 * TILE * kLds;       // [2][TILE][kLds]
+    __bf16* As16 = reinterpret_cast<__bf16*>(smem);      // SPLIT: [TILE][kSplitLd], one buffer per operand
+    __bf16* Bs16 = As16 + TILE * kSplitLd;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -137,7 +166,17 @@ __device__ __forceinline__ void gram_tile(const GramGeom& g, float* smem, const 
                 ra.v[q][e] = oka ? ra.v[q][e] : 0.f;
                 rb.v[q][e] = okb ? rb.v[q][e] : 0.f;
             }
-            if constexpr (VEC == 4) {
+            if constexpr (SPLIT) {
+                static_assert(!SPLIT || VEC == 4, "the split image is written four k at a time");
+                bf16x4 ha[3], hb[3];
+                split3(ra.v[q], ha);
+                split3(rb.v[q], hb);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    *reinterpret_cast<bf16x4*>(As16 + row * kSplitLd + p * kBK + scol) = ha[p];
+                    *reinterpret_cast<bf16x4*>(Bs16 + row * kSplitLd + p * kBK + scol) = hb[p];
+                }
+            } else if constexpr (VEC == 4) {
                 f32x4 va = {ra.v[q][0], ra.v[q][1], ra.v[q][2], ra.v[q][3]};
                 f32x4 vb = {rb.v[q][0], rb.v[q][1], rb.v[q][2], rb.v[q][3]};
                 *reinterpret_cast<f32x4*>(a + row * kLds + scol) = va;
@@ -169,6 +208,36 @@ __device__ __forceinline__ void gram_tile(const GramGeom& g, float* smem, const 
     auto compute = [&](int buf) {
         const float* a = As + buf * TILE * kLds + (wm * (TILE / 2) + (lane & 31)) * kLds + 4 * (lane >> 5);
         const float* b = Bs + buf * TILE * kLds + (wn * (TILE / 2) + (lane & 31)) * kLds + 4 * (lane >> 5);
+        if constexpr (SPLIT) {
+            // lane (r, h) of k group g reads k = 16 g + 8 h .. + 7 of its row from each plane: the operand map of the MFMA
+            const __bf16* a16 = As16 + (wm * (TILE / 2) + (lane & 31)) * kSplitLd + 8 * (lane >> 5);
+            const __bf16* b16 = Bs16 + (wn * (TILE / 2) + (lane & 31)) * kSplitLd + 8 * (lane >> 5);
+#pragma unroll
+            for (int g16 = 0; g16 < kBK / 16; ++g16) {
+                bf16x8 sa[MT][3], sb[MT][3];
+#pragma unroll
+                for (int s = 0; s < MT; ++s)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        sa[s][p] = *reinterpret_cast<const bf16x8*>(a16 + s * 32 * kSplitLd + p * kBK + g16 * 16);
+                        sb[s][p] = *reinterpret_cast<const bf16x8*>(b16 + s * 32 * kSplitLd + p * kBK + g16 * 16);
+                    }
+#pragma unroll
+                for (int sm = 0; sm < MT; ++sm)
+#pragma unroll
+                    for (int sn = 0; sn < MT; ++sn) {
+                        f32x16 c = acc[sm][sn];      // smallest terms first
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[sm][0], sb[sn][2], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[sm][2], sb[sn][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[sm][1], sb[sn][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[sm][0], sb[sn][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[sm][1], sb[sn][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[sm][0], sb[sn][0], c, 0, 0, 0);
+                        acc[sm][sn] = c;
+                    }
+            }
+            return;
+        }
 #pragma unroll
         for (int kk = 0; kk < kBK / 8; ++kk) {
             f32x4 fa[MT], fb[MT];
@@ -197,6 +266,16 @@ __device__ __forceinline__ void gram_tile(const GramGeom& g, float* smem, const 
 #ifndef PLEAS_GRAM_ABLATE
 #define PLEAS_GRAM_ABLATE 0
 #endif
+    if constexpr (SPLIT) {
+        for (int c = c_begin; c < c_end; ++c) {
+            const bool more = c + 1 < c_end;
+            if (more) load_chunk(c + 1);      // stays in registers while this chunk is multiplied
+            compute(0);
+            __syncthreads();                  // every wave is done reading the image
+            if (more) store_chunk(0);
+            __syncthreads();
+        }
+    } else
     for (int c = c_begin; c < c_end; ++c) {
         const int buf = (c - c_begin) & 1;
         const bool more = c + 1 < c_end;
@@ -268,6 +347,18 @@ __global__ __launch_bounds__(kThreads) void gram_partial_kernel(const GramGeom g
     gram_tile<TILE, VEC>(g, smem, tm, tn, split, c_begin, min(c_begin + g.chunks_per_split, g.nchunks));
 }
 
+template <int TILE, int VEC>
+__global__ __launch_bounds__(kThreads) void gram_partial_split_kernel(const GramGeom g) {      // study arithmetic
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int bid = blockIdx.x;
+    const int tn = bid % g.tiles;
+    bid /= g.tiles;
+    const int tm = bid % g.tiles;
+    const int split = bid / g.tiles;
+    const int c_begin = split * g.chunks_per_split;
+    gram_tile<TILE, VEC, 1>(g, smem, tm, tn, split, c_begin, min(c_begin + g.chunks_per_split, g.nchunks));
+}
+
 // ---- grouped launch: every tracked node of a batch in ONE grid --------------------------------
 struct GramNodeDev {      // device node table entry
     const float* x;
@@ -315,6 +406,35 @@ __global__ __launch_bounds__(kThreads, 2) void gram_batch_kernel(const GramNodeD
         case 0: gram_tile<128, 4>(g, smem, it.tm, it.tn, it.split, it.c_begin, it.c_end); break;
         case 1: gram_tile<128, 1>(g, smem, it.tm, it.tn, it.split, it.c_begin, it.c_end); break;
         case 2: gram_tile<64, 4>(g, smem, it.tm, it.tn, it.split, it.c_begin, it.c_end); break;
+        default: gram_tile<64, 1>(g, smem, it.tm, it.tn, it.split, it.c_begin, it.c_end); break;
+    }
+}
+
+// The same grid with the study arithmetic on the 128-wide 16-byte variant (every MFMA-bound node of a ResNet); a kernel of
+// its own so that the exact kernel's register allocation does not depend on it.
+__global__ __launch_bounds__(kThreads, 2) void gram_batch_split_kernel(const GramNodeDev* __restrict__ nodes,
+                                                                    const GramItemDev* __restrict__ items) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const GramItemDev it = items[blockIdx.x];
+    if (it.node < 0) return;
+    const GramNodeDev nd = nodes[it.node];
+    GramGeom g;
+    g.x = nd.x;
+    g.y = nd.y;
+    g.gpart = nd.gpart;
+    g.npart = nd.npart;
+    g.spart = nd.spart;
+    g.sums = nd.sums;
+    g.C = nd.C;
+    g.HW = nd.HW;
+    g.Ktot = nd.Ktot;
+    g.nchunks = 0;
+    g.chunks_per_split = 0;
+    g.tiles = 0;
+    switch (nd.variant) {
+        case 0: gram_tile<128, 4, 1>(g, smem, it.tm, it.tn, it.split, it.c_begin, it.c_end); break;
+        case 1: gram_tile<128, 1>(g, smem, it.tm, it.tn, it.split, it.c_begin, it.c_end); break;
+        case 2: gram_tile<64, 4, 1>(g, smem, it.tm, it.tn, it.split, it.c_begin, it.c_end); break;
         default: gram_tile<64, 1>(g, smem, it.tm, it.tn, it.split, it.c_begin, it.c_end); break;
     }
 }
@@ -448,6 +568,17 @@ extern "C" void pleas_gram_tune(int target_blocks, int min_chunks_per_split) {
     if (min_chunks_per_split > 0) g_min_chunks = min_chunks_per_split;
 }
 
+// Study switch: -1 = not set yet (read PLEAS_GRAM_SPLIT_BF16 once), 0 = exact fp32 MFMA (default).
+static int g_split_bf16 = -1;
+static bool split_bf16() {
+    if (g_split_bf16 < 0) {
+        const char* e = std::getenv("PLEAS_GRAM_SPLIT_BF16");
+        g_split_bf16 = (e && e[0] == '1') ? 1 : 0;
+    }
+    return g_split_bf16 == 1;
+}
+extern "C" void pleas_gram_split_bf16(int on) { g_split_bf16 = on ? 1 : 0; }
+
 extern "C" size_t pleas_gram_ws_bytes(int B, int C, int64_t HW) {
     if (B <= 0 || C <= 0 || HW <= 0) return 0;
     return make_plan(B, C, HW, true).ws_bytes;  // alignment does not change the size
@@ -484,7 +615,13 @@ extern "C" int pleas_gram_accum(const float* x, const float* y, int B, int C, in
     const double kk = (double)B * (double)HW;
     {
     ProfScope prof(kProfGramPartial, 2.0 * C * (double)C * kk, 2.0 * C * kk * sizeof(float), stream);
-    if (p.tile == 128 && p.vec == 4)
+    if (p.vec == 4 && split_bf16()) {
+        const size_t lds16 = (size_t)2 * p.tile * kSplitLd * sizeof(__bf16);      // 52 KB at tile 128
+        if (p.tile == 128)
+            hipLaunchKernelGGL((gram_partial_split_kernel<128, 4>), grid, dim3(kThreads), lds16, stream, g);
+        else
+            hipLaunchKernelGGL((gram_partial_split_kernel<64, 4>), grid, dim3(kThreads), lds16, stream, g);
+    } else if (p.tile == 128 && p.vec == 4)
         hipLaunchKernelGGL((gram_partial_kernel<128, 4>), grid, dim3(kThreads), lds, stream, g);
     else if (p.tile == 128)
         hipLaunchKernelGGL((gram_partial_kernel<128, 1>), grid, dim3(kThreads), lds, stream, g);
@@ -776,8 +913,12 @@ extern "C" int pleas_gram_batch(const pleas_gram_node* nodes, int n_nodes, float
     }
     {
         ProfScope prof(kProfGramPartial, P.flops, P.bytes, stream);
-        hipLaunchKernelGGL(gram_batch_kernel, dim3((unsigned)P.items.size()), dim3(kThreads), P.lds, stream, dnodes,
-                           reinterpret_cast<const GramItemDev*>(base + P.off_items));
+        if (split_bf16())
+            hipLaunchKernelGGL(gram_batch_split_kernel, dim3((unsigned)P.items.size()), dim3(kThreads), P.lds, stream, dnodes,
+                               reinterpret_cast<const GramItemDev*>(base + P.off_items));
+        else
+            hipLaunchKernelGGL(gram_batch_kernel, dim3((unsigned)P.items.size()), dim3(kThreads), P.lds, stream, dnodes,
+                               reinterpret_cast<const GramItemDev*>(base + P.off_items));
     }
     PLEAS_LAUNCH_CHECK("gram_batch_kernel");
     {

@@ -186,6 +186,31 @@ def test_merge_blocks_one_axis_activation(ops):
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("shape,axis", [((16, 256, 14, 14), 1), ((2, 64, 28, 28), 1), ((5, 132, 6, 6), 1), ((2, 64, 112, 112), 1)])
+def test_gram_split_bf16_study_switch(ops, shape, axis):
+    """The STUDY arithmetic of the contraction (three-way bf16 split, six bf16 MFMAs per fp32 product; off by default,
+    DESIGN.md): within the exact path's own distance from fp64 (x2 + a floor) on 16-byte-loadable shapes, and the switch
+    really goes back to the exact path (bit-identical results before and after)."""
+    from pleas_merging_amd import _lib
+
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(shape, generator=g)
+    y = 0.7 * x + 0.5 * torch.randn(shape, generator=g)
+    xd, yd = x.cuda(), y.cuda()
+    want = orc.cross_features_inner_product(x.double(), y.double(), axis)
+    exact = ops.cross_features_inner_product(xd, yd, axis).cpu()
+    try:
+        _lib.lib().pleas_gram_split_bf16(1)
+        study = ops.cross_features_inner_product(xd, yd, axis).cpu()
+        study_d = ops.cross_features_cdist(xd, yd, axis).cpu()
+    finally:
+        _lib.lib().pleas_gram_split_bf16(0)
+    assert not torch.equal(study, exact)          # another arithmetic did run
+    assert _rel(study, want) < max(2 * _rel(exact, want), 5e-7), (_rel(study, want), _rel(exact, want))
+    assert _rel(study_d, orc.cross_features_cdist_f64(x, y, axis)) < 2e-6
+    assert torch.equal(ops.cross_features_inner_product(xd, yd, axis).cpu(), exact)
+
+
 @pytest.mark.parametrize("shape", [(3, 16, 8, 8), (2, 7, 7, 7), (4, 64, 14, 14), (1, 5, 3, 1)])
 @pytest.mark.parametrize("with_res,relu", [(False, True), (True, True), (False, False)])
 def test_bn_act_matches_eval_batchnorm(ops, shape, with_res, relu):
