@@ -147,12 +147,6 @@ typedef struct pleas_merge_item {
     const int32_t* row2;
     int64_t outer, inner;
     int rows_out, rows_src, n_merged;
-    /* unfold_k > 0 (strided layers; 0 = plain merge): `out` is the im2col image of the merged tensor for an unfold_k x
-     * unfold_k window -- out[outer][unfold_k^2 * rows_out][Ho * Wo], row = kpos * rows_out + r (kernel-position-major, the
-     * K order of PLEAS_FWD_KPOS_MAJOR weights), value = merged[o][r][oh * stride - pad + kh][ow * stride - pad + kw] or 0
-     * outside; inner must be Hin * Win.  A strided convolution then IS a 1 x 1 convolution of `out` (the gather replaces
-     * the index arithmetic of torch's strided conv2d inside get_model_orig_activations' consumers, pleas_merging.py:271-284). */
-    int unfold_k, unfold_stride, unfold_pad, Hin, Win;
 } pleas_merge_item;
 size_t pleas_merge_batch_ws_bytes(const pleas_merge_item* items, int n_items);
 int pleas_merge_batch(const pleas_merge_item* items, int n_items, void* ws, size_t ws_bytes, int ws_fresh, void* stream);

@@ -76,8 +76,7 @@ SIGNATURES = {
 class MergeItem(ctypes.Structure):
     """struct pleas_merge_item"""
     _fields_ = [("w1", c_void_p), ("w2", c_void_p), ("out", c_void_p), ("row1", c_void_p), ("row2", c_void_p),
-                ("outer", c_int64), ("inner", c_int64), ("rows_out", c_int), ("rows_src", c_int), ("n_merged", c_int),
-                ("unfold_k", c_int), ("unfold_stride", c_int), ("unfold_pad", c_int), ("Hin", c_int), ("Win", c_int)]
+                ("outer", c_int64), ("inner", c_int64), ("rows_out", c_int), ("rows_src", c_int), ("n_merged", c_int)]
 
 
 class FwdLayer(ctypes.Structure):

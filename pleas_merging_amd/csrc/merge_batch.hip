@@ -32,52 +32,12 @@ struct MergeItemDev {
     uint32_t rows_out, rows_src;
     int n_merged, vec;     // vec: 4 (16-B pieces) or 1
     int first_block, pad;
-    // unfold_k > 0: the output is the im2col image of the merged tensor, out[o][kpos * rows_out + r][oh * Wo + ow] =
-    // merged[o][r][oh * stride - upad + kh][ow * stride - upad + kw] (0 outside); inner_v counts OUTPUT pieces per row
-    int unfold_k, stride, upad, Hin, Win, Wo;
 };
 
 __global__ __launch_bounds__(mThreads) void merge_batch_kernel(const MergeItemDev* __restrict__ items,
                                                                const int* __restrict__ block_item) {
     const MergeItemDev it = items[block_item[blockIdx.x]];
     const uint32_t base = (uint32_t)(blockIdx.x - it.first_block) * mSpan + threadIdx.x;
-    if (it.unfold_k > 0) {      // block-uniform: strided layers' inputs, gathered element by element (scalar loads, vec-wide stores)
-        const uint32_t rows_total = it.rows_out * (uint32_t)(it.unfold_k * it.unfold_k);
-        const uint32_t plane = (uint32_t)it.Hin * (uint32_t)it.Win;
-#pragma unroll
-        for (int u = 0; u < mUnroll; ++u) {
-            const uint32_t id = base + u * mThreads;
-            if (id >= it.total_v) continue;
-            const uint32_t t = id / it.inner_v, iv = id - t * it.inner_v;
-            const uint32_t o = t / rows_total, rr = t - o * rows_total;
-            const uint32_t kpos = rr / it.rows_out, r = rr - kpos * it.rows_out;
-            const int kh = (int)kpos / it.unfold_k, kw = (int)kpos - kh * it.unfold_k;
-            const int ra = PLEAS_GLOBAL_I(it.row1)[r], rb = PLEAS_GLOBAL_I(it.row2)[r];
-            const float coef = (int)r < it.n_merged ? 0.5f : 1.0f;
-            const cgfloat* pa = PLEAS_GLOBAL(it.w1) + ((size_t)o * it.rows_src + max(ra, 0)) * plane;
-            const cgfloat* pb = PLEAS_GLOBAL(it.w2) + ((size_t)o * it.rows_src + max(rb, 0)) * plane;
-            const uint32_t p0 = iv * (uint32_t)it.vec;
-            const int oh = (int)(p0 / (uint32_t)it.Wo), ow0 = (int)(p0 - (uint32_t)oh * (uint32_t)it.Wo);   // vec == 4: Wo % 4 == 0
-            const int ih = oh * it.stride - it.upad + kh;
-            const bool row_ok = ih >= 0 && ih < it.Hin;
-            float q[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int iw = (ow0 + e) * it.stride - it.upad + kw;
-                const bool ok = row_ok && e < it.vec && iw >= 0 && iw < it.Win;
-                const int at = ok ? ih * it.Win + iw : 0;
-                const float a = pa[at], b = pb[at];
-                q[e] = ok ? ((ra >= 0 ? a : 0.f) + (rb >= 0 ? b : 0.f)) * coef : 0.f;
-            }
-            if (it.vec == 4) {
-                const f32x4 v = {q[0], q[1], q[2], q[3]};
-                reinterpret_cast<__attribute__((address_space(1))) f32x4*>(PLEAS_GLOBAL_W(it.out))[id] = v;
-            } else {
-                PLEAS_GLOBAL_W(it.out)[id] = q[0];
-            }
-        }
-        return;
-    }
     // all loads of the unrolled pieces are issued before the first store
     uint32_t idx[mUnroll];
     int r1[mUnroll], r2[mUnroll];
@@ -168,20 +128,9 @@ static int build_merge_plan(MergePlan& P, const pleas_merge_item* it, int n) {
         const pleas_merge_item& m = it[i];
         if (m.outer < 0 || m.rows_out < 0 || m.inner <= 0 || m.rows_src <= 0 || m.n_merged < 0)
             return bad_arg("merge_batch: tensor geometry");
-        int64_t out_inner = m.inner, out_rows = m.rows_out;
-        int Wo = 0;
-        if (m.unfold_k != 0) {
-            if (m.unfold_k < 0 || m.unfold_k > 7 || m.unfold_stride <= 0 || m.unfold_pad < 0 || m.Hin <= 0 || m.Win <= 0 ||
-                (int64_t)m.Hin * m.Win != m.inner || m.Hin + 2 * m.unfold_pad < m.unfold_k || m.Win + 2 * m.unfold_pad < m.unfold_k)
-                return bad_arg("merge_batch: unfold geometry (window 1..7, stride > 0, inner == Hin * Win)");
-            const int Ho = (m.Hin + 2 * m.unfold_pad - m.unfold_k) / m.unfold_stride + 1;
-            Wo = (m.Win + 2 * m.unfold_pad - m.unfold_k) / m.unfold_stride + 1;
-            out_inner = (int64_t)Ho * Wo;
-            out_rows = (int64_t)m.rows_out * m.unfold_k * m.unfold_k;
-        }
-        const bool vec = m.unfold_k ? Wo % 4 == 0 : m.inner % 4 == 0;   // pointer alignment is checked per call
-        const int64_t inner_v = vec ? out_inner / 4 : out_inner;
-        const int64_t total_v = m.outer * out_rows * inner_v;
+        const bool vec = m.inner % 4 == 0;   // pointer alignment is checked per call
+        const int64_t inner_v = vec ? m.inner / 4 : m.inner;
+        const int64_t total_v = m.outer * m.rows_out * inner_v;
         if (total_v >= (1ll << 32) || inner_v >= (1ll << 32)) return bad_arg("merge_batch: tensor too large");
         MergeItemDev& d = P.items[i];
         d.total_v = (uint32_t)total_v;
@@ -190,11 +139,10 @@ static int build_merge_plan(MergePlan& P, const pleas_merge_item* it, int n) {
         d.rows_src = (uint32_t)m.rows_src;
         d.n_merged = m.n_merged;
         d.vec = vec ? 4 : 1;
-        d.unfold_k = m.unfold_k; d.stride = m.unfold_stride; d.upad = m.unfold_pad; d.Hin = m.Hin; d.Win = m.Win; d.Wo = Wo;
         d.first_block = (int)P.block_item.size();
         const int64_t nb = ceil_div(total_v, mSpan);
         for (int64_t b = 0; b < nb; ++b) P.block_item.push_back(i);
-        P.bytes += (2.0 * (double)(m.outer * m.rows_out * m.inner) + (double)(m.outer * out_rows * out_inner)) * sizeof(float);
+        P.bytes += 3.0 * (double)(m.outer * m.rows_out * m.inner) * sizeof(float);
     }
     P.off_items = 0;
     P.off_blocks = malign(P.items.size() * sizeof(MergeItemDev));
@@ -220,9 +168,8 @@ extern "C" int pleas_merge_batch(const pleas_merge_item* items, int n_items, voi
     for (int i = 0; i < n_items; ++i) {
         const pleas_merge_item& m = items[i];
         if (!m.w1 || !m.w2 || !m.out || !m.row1 || !m.row2) return bad_arg("merge_batch: null pointer");
-        if (m.unfold_k ? (((uintptr_t)m.out & 15) != 0)
-                       : (m.inner % 4 == 0 && ((((uintptr_t)m.w1 | (uintptr_t)m.w2 | (uintptr_t)m.out) & 15) != 0)))
-            return bad_arg("merge_batch: tensors with inner % 4 == 0 (and every unfold output) must be 16-byte aligned");
+        if (m.inner % 4 == 0 && ((((uintptr_t)m.w1 | (uintptr_t)m.w2 | (uintptr_t)m.out) & 15) != 0))
+            return bad_arg("merge_batch: tensors with inner % 4 == 0 must be 16-byte aligned");
     }
     hipStream_t stream = (hipStream_t)stream_;
     std::lock_guard<std::mutex> lk(g_mplan_mu);
@@ -231,9 +178,7 @@ extern "C" int pleas_merge_batch(const pleas_merge_item* items, int n_items, voi
     key.push_back((int64_t)(uintptr_t)ws);
     for (int i = 0; i < n_items; ++i) {
         const pleas_merge_item& m = items[i];
-        for (int64_t v : {m.outer, m.inner, (int64_t)m.rows_out, (int64_t)m.rows_src, (int64_t)m.n_merged, (int64_t)m.unfold_k,
-                          (int64_t)m.unfold_stride, (int64_t)m.unfold_pad, (int64_t)m.Hin, (int64_t)m.Win})
-            key.push_back(v);
+        for (int64_t v : {m.outer, m.inner, (int64_t)m.rows_out, (int64_t)m.rows_src, (int64_t)m.n_merged}) key.push_back(v);
     }
     MergePlan* hit = g_mplans.find(key);
     if (!hit) {

@@ -547,11 +547,7 @@ class MergeBatch:
         self._fresh = 1
 
     def add(self, w1: torch.Tensor, w2: torch.Tensor, row_axis: int, row1: torch.Tensor, row2: torch.Tensor,
-            n_merged_rows: int, out: Optional[torch.Tensor] = None,
-            unfold: Optional[Tuple[int, int, int]] = None) -> torch.Tensor:
-        """``unfold=(k, stride, padding)`` (NCHW sources, ``row_axis`` 1): the output is the im2col image of the merged
-        tensor, ``[N, k * k * rows, Ho, Wo]`` with channel ``kpos * rows + r`` -- a convolution of that window and stride
-        is then the 1 x 1 convolution of the output with kernel-position-major weights ``[Cout, k * k * rows]``."""
+            n_merged_rows: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if w1.shape != w2.shape or not w1.is_cuda or w1.dtype != torch.float32 or w2.dtype != torch.float32:
             raise PleasHipError("MergeBatch.add: fp32 CUDA sources of equal shape expected")
         w1, w2 = w1.contiguous(), w2.contiguous()
@@ -559,21 +555,13 @@ class MergeBatch:
         row_axis = row_axis % w1.dim()
         rows_out = int(row1.numel())
         want = shape[:row_axis] + [rows_out] + shape[row_axis + 1:]
-        geo_unfold = (0, 0, 0, 0, 0)
-        if unfold is not None:
-            k, stride, padding = (int(v) for v in unfold)
-            if w1.dim() != 4 or row_axis != 1 or k < 1 or stride < 1 or padding < 0:
-                raise PleasHipError("MergeBatch.add: unfold needs NCHW sources merged along dim 1, k >= 1, stride >= 1")
-            H, W = shape[2], shape[3]
-            want = [shape[0], k * k * rows_out, (H + 2 * padding - k) // stride + 1, (W + 2 * padding - k) // stride + 1]
-            geo_unfold = (k, stride, padding, H, W)
         if out is None:
             out = torch.empty(want, dtype=torch.float32, device=w1.device)
         elif list(out.shape) != want or out.dtype != torch.float32 or not out.is_contiguous() or out.device != w1.device:
             raise PleasHipError("MergeBatch.add: out must be a contiguous fp32 tensor of shape %s" % (want,))
         self._keep.append((w1, w2, out, row1, row2))
         self._geo.append((math.prod(shape[:row_axis]), math.prod(shape[row_axis + 1:]), rows_out, shape[row_axis],
-                          int(n_merged_rows)) + geo_unfold)
+                          int(n_merged_rows)))
         return out
 
     def flush(self) -> None:
@@ -585,7 +573,7 @@ class MergeBatch:
         for i, ((w1, w2, out, row1, row2), geo) in enumerate(zip(self._keep, self._geo)):
             a = self._arr[i]
             a.w1, a.w2, a.out, a.row1, a.row2 = w1.data_ptr(), w2.data_ptr(), out.data_ptr(), row1.data_ptr(), row2.data_ptr()
-            a.outer, a.inner, a.rows_out, a.rows_src, a.n_merged, a.unfold_k, a.unfold_stride, a.unfold_pad, a.Hin, a.Win = geo
+            a.outer, a.inner, a.rows_out, a.rows_src, a.n_merged = geo
         lib = _lib.lib()
         if self._ws is None:
             need = int(lib.pleas_merge_batch_ws_bytes(self._arr, n))

@@ -31,7 +31,6 @@ from __future__ import annotations
 import collections
 import contextlib
 import math
-import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -640,16 +639,6 @@ class PleasFitter:
             raise NotImplementedError("layer %s: the grouped HIP kernels take dense, undilated Conv2d layers with a square "
                                       "kernel / stride / padding and Linear layers on 2-D inputs" % name)
         geo = (tuple(mod.kernel_size), mod.stride[0], mod.padding[0]) if plan.is_conv else ((1, 1), 1, 0)
-        # STRIDED convolutions (a ResNet's downsample 1 x 1 and first 3 x 3 of a stage): the grouped merge writes the
-        # merged input as its im2col image [N, k * k * Cin, Ho, Wo] (kernel-position-major channels, the K order of the
-        # layer's weights in the arena), and the layer is a 1 x 1 convolution of that image for the forward AND the weight
-        # gradient -- the 16-byte flat tile forms instead of the general gather tile.  PLEAS_UNFOLD_STRIDED=0: general tile.
-        unfold = None
-        if (plan.is_conv and geo[1] > 1 and (plan.kpos or geo[0] == (1, 1)) and ip1.shape[1] % 32 == 0
-                and os.environ.get("PLEAS_UNFOLD_STRIDED", "1") != "0"):
-            unfold = (geo[0][0], geo[1], geo[2])
-            geo = ((1, 1), 1, 0)
-        w, kpos = (plan.w.view(cout, -1, 1, 1), False) if unfold else (plan.w, plan.kpos)
         halves = len(plan.halves)
         for h, (in_maps, (r1, r2, nm)) in enumerate(plan.halves):
             if cout != r1.numel():
@@ -658,20 +647,18 @@ class PleasFitter:
                 raise RuntimeError("layer %s: %d merged inputs vs %d input blocks" % (name, plan.w_shape[1], in_maps[0].numel()))
             # merged input: queued for the ONE grouped merge launch that precedes the grouped forward (merge.flush)
             kept = self._bufs.get((idx, h))
-            ip = self.merge.add(ip1, ip2, 1, *in_maps, out=kept[0] if kept else None, unfold=unfold)
+            ip = self.merge.add(ip1, ip2, 1, *in_maps, out=kept[0] if kept else None)
             resid = kept[1] if kept else torch.empty((ip.shape[0], cout) + tuple(o1.shape[2:]), dtype=torch.float32,
                                                      device=ip.device)
             if kept is None:
                 self._bufs[(idx, h)] = (ip, resid)
             n = resid.numel() * halves * self.world    # the mean runs over the full (global, stacked) batch
-            self.fwd.add(ip, w, plan.b, o1, o2, r1, r2, nm, resid, 2.0 / n, 1.0 / n, *geo,
-                         flags=ops.FwdBatch.KPOS_MAJOR if kpos else 0)
+            self.fwd.add(ip, plan.w, plan.b, o1, o2, r1, r2, nm, resid, 2.0 / n, 1.0 / n, *geo,
+                         flags=ops.FwdBatch.KPOS_MAJOR if plan.kpos else 0)
             self._fwd_rows.append(idx)
             gw, gb = (plan.gw, plan.gb) if h == 0 else (plan.gw2, plan.gb2)   # second half: its own arena, added in _step
-            if unfold:
-                gw = gw.view(cout, -1, 1, 1)
             if ip.shape[1] >= 16 or linear:
-                self.wgrad.add(resid, ip, gw, *geo, flags=ops.WgradBatch.KPOS_MAJOR if kpos else 0)
+                self.wgrad.add(resid, ip, gw, *geo, flags=ops.WgradBatch.KPOS_MAJOR if plan.kpos else 0)
             else:   # the stem (3 input channels): narrower than the tile's 16-channel chunks -> vendor weight gradient
                 self._vendor_wgrad.append((resid, ip, plan, gw))
             if gb is not None:

@@ -347,37 +347,6 @@ def test_fwd_batch_rejects_kpos_major_with_ragged_channels(ops):
         batch.flush(torch.zeros(1, device="cuda"))
 
 
-@pytest.mark.parametrize("shape,k,stride,pad", [((3, 40, 8, 8), 1, 2, 0), ((2, 32, 8, 8), 3, 2, 1), ((2, 9, 7, 7), 3, 2, 1),
-                                                 ((2, 16, 14, 14), 3, 2, 1), ((1, 5, 9, 6), 1, 2, 0), ((2, 6, 6, 6), 3, 1, 1),
-                                                 ((2, 4, 11, 11), 5, 3, 2)])
-def test_merge_batch_unfold_is_im2col_of_the_merged_tensor(ops, shape, k, stride, pad):
-    """unfold=(k, stride, pad): out[n][kpos * rows + r][oh][ow] = merged[n][r][oh * stride - pad + kh][ow * stride - pad + kw]
-    (0 outside) -- torch's unfold of the plain merge, channels regrouped kernel-position-major; then a strided convolution
-    is the 1 x 1 convolution of it with kernel-position-major weights."""
-    import torch.nn.functional as F
-    from pleas_merging_amd.methods.partial_matching import block_maps
-
-    g = torch.Generator().manual_seed(43)
-    N, C, H, W = shape
-    w1, w2 = torch.randn(shape, generator=g).cuda(), torch.randn(shape, generator=g).cuda()
-    p1, p2, m = torch.randperm(C, generator=g), torch.randperm(C, generator=g), C // 2
-    blocks = (p1[:m], p2[:m], p1[m:], p2[m:])           # [merged | only model 1 | only model 2]
-    r1, r2, nm = block_maps(blocks, torch.device("cuda"))
-    batch = ops.MergeBatch(torch.device("cuda"))
-    plain = batch.add(w1, w2, 1, r1, r2, nm)
-    image = batch.add(w1, w2, 1, r1, r2, nm, unfold=(k, stride, pad))
-    batch.flush()
-    rows = plain.shape[1]
-    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-    assert tuple(image.shape) == (N, k * k * rows, Ho, Wo)
-    want = F.unfold(plain, k, padding=pad, stride=stride).view(N, rows, k * k, Ho, Wo).transpose(1, 2).reshape(N, k * k * rows, Ho, Wo)
-    assert torch.equal(image, want)
-    weight = torch.randn(7, rows, k, k, generator=g).cuda()
-    conv = F.conv2d(plain, weight, None, stride, pad)
-    as_1x1 = F.conv2d(image, weight.permute(0, 2, 3, 1).reshape(7, k * k * rows, 1, 1))
-    assert torch.allclose(conv, as_1x1, rtol=1e-4, atol=1e-4)
-
-
 def test_merge_batch_equals_single_tensor_launches(ops):
     """Grouped block merge of many tensors == pleas_merge_blocks per tensor, bit for bit: 16-B and scalar pieces,
     ragged tails, 2-D tensors, absent rows that must not leak (NaN planted in the row an absent source is read from)."""
