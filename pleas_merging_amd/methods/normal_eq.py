@@ -4,7 +4,8 @@
 ``mean((L(ip) - op)^2)`` (pleas/methods/pleas_merging.py:281-291, :357-358); the minimiser of the
 same objective summed over the batches is ``W^T = A^-1 B`` with ``U = im2col(ip)``,
 ``A = sum U^T U`` and ``B = sum U^T op``.  (With equal batch sizes the per-batch ``mean`` only
-rescales the objective.)  Frozen entries of the reference's gradient mask (:57-58) stay at their
+rescales the objective.)  The stacked objectives (``merging`` = reg_mean / perm_separatels / perm_mixedls, :125-145) sum both
+half-batches into the same ``A`` and ``B``.  Frozen entries of the reference's gradient mask (:57-58) stay at their
 initial value and move to the right-hand side.
 
 MI355X design: per batch, ONE grouped fp32-MFMA launch accumulates ``U^T U`` of every layer
@@ -68,54 +69,60 @@ class NormalEqFitter(PleasFitter):
         ops = self.ops
         self._begin_update(x, next_x)
         KP = ops.WgradBatch.ACCUMULATE | ops.WgradBatch.KPOS_MAJOR
-        for idx, plan in enumerate(self.plans):
-            name = plan.name
-            if name not in self.t1_in or name not in self.t2_in:
-                print("Key error on %s" % name)
-                continue
-            mod = plan.mod
-            grouped = self._hip_geometry_ok(plan, self.t1_in[name]) and plan.b is None
-            merge = self.merge.add if grouped else ops.merge_blocks     # grouped: filled by merge.flush() below
-            ip = merge(self.t1_in[name], self.t2_in[name], 1, *plan.in_maps)
-            op = merge(self.t1_out[name], self.t2_out[name], 1, *plan.out_maps)
-            if self._hip_geometry_ok(plan, ip):
-                if plan.is_conv:
-                    geo = (tuple(mod.kernel_size), mod.stride[0], mod.padding[0])
-                    self.neq.add(ip, self.A[idx], *geo)
-                    self.wgrad.add(op, ip, self.Bt[idx], *geo, flags=KP)
-                else:
-                    self.neq.add(ip, self.A[idx])
-                    self.wgrad.add(op, ip, self.Bt[idx], flags=KP)
-            else:  # stem (3 input channels) / exotic geometry: tiny K, vendor GEMM on an explicit im2col
-                U = F.unfold(ip, mod.kernel_size, mod.dilation, mod.padding, mod.stride)      # B, (ci,kh,kw), L
-                cin, r = ip.shape[1], mod.kernel_size[0] * mod.kernel_size[1]
-                U = U.view(U.shape[0], cin, r, -1).permute(0, 3, 2, 1).reshape(-1, r * cin)    # rows x (r, ci)
-                Y = op.reshape(op.shape[0], op.shape[1], -1).permute(0, 2, 1).reshape(-1, op.shape[1])
-                self.A[idx].addmm_(U.t(), U)
-                self.Bt[idx].addmm_(Y.t(), U)
-            if plan.b is not None:
-                # bias = one more column of ones in U: its normal-equation entries are the column sums of U, the column
-                # sums of the target and the row count
-                s = self.bias_stats[idx]
-                if plan.is_conv:
-                    kh, kw = mod.kernel_size
-                    st, pd = mod.stride[0], mod.padding[0]
-                    ho, wo = op.shape[2], op.shape[3]
-                    ipp = F.pad(ip, (pd, pd, pd, pd)) if pd else ip
-                    # column sums of im2col(ip) in kernel-position-major order k = (kh * KW + kw) * Cin + ci
-                    cols = [ipp[:, :, a:a + st * (ho - 1) + 1:st, b:b + st * (wo - 1) + 1:st].sum((0, 2, 3))
-                            for a in range(kh) for b in range(kw)]
-                    s[0].add_(torch.cat(cols))
-                    s[1].add_(op.sum((0, 2, 3)))
-                    s[2].add_(float(op.shape[0] * ho * wo))
-                else:
-                    rows_u = ip.reshape(-1, ip.shape[-1])
-                    s[0].add_(rows_u.sum(0))
-                    s[1].add_(op.reshape(-1, op.shape[-1]).sum(0))
-                    s[2].add_(float(rows_u.shape[0]))
-        self.merge.flush()
-        self.neq.flush()
-        self.wgrad.flush()
+        # The stacked objectives (reg_mean / perm_separatels / perm_mixedls, reference :125-145) put TWO half-batches under
+        # the same weights: A and B are the sums over both.  Each half is its own round of grouped launches (two entries of
+        # one launch may not accumulate into the same A).
+        for h in range(len(self.plans[0].halves) if self.plans else 0):
+            for idx, plan in enumerate(self.plans):
+                name = plan.name
+                if name not in self.t1_in or name not in self.t2_in:
+                    if h == 0:
+                        print("Key error on %s" % name)
+                    continue
+                mod = plan.mod
+                in_maps, out_maps = plan.halves[h]
+                grouped = self._hip_geometry_ok(plan, self.t1_in[name]) and plan.b is None
+                merge = self.merge.add if grouped else ops.merge_blocks     # grouped: filled by merge.flush() below
+                ip = merge(self.t1_in[name], self.t2_in[name], 1, *in_maps)
+                op = merge(self.t1_out[name], self.t2_out[name], 1, *out_maps)
+                if self._hip_geometry_ok(plan, ip):
+                    if plan.is_conv:
+                        geo = (tuple(mod.kernel_size), mod.stride[0], mod.padding[0])
+                        self.neq.add(ip, self.A[idx], *geo)
+                        self.wgrad.add(op, ip, self.Bt[idx], *geo, flags=KP)
+                    else:
+                        self.neq.add(ip, self.A[idx])
+                        self.wgrad.add(op, ip, self.Bt[idx], flags=KP)
+                else:  # stem (3 input channels) / exotic geometry: tiny K, vendor GEMM on an explicit im2col
+                    U = F.unfold(ip, mod.kernel_size, mod.dilation, mod.padding, mod.stride)      # B, (ci,kh,kw), L
+                    cin, r = ip.shape[1], mod.kernel_size[0] * mod.kernel_size[1]
+                    U = U.view(U.shape[0], cin, r, -1).permute(0, 3, 2, 1).reshape(-1, r * cin)    # rows x (r, ci)
+                    Y = op.reshape(op.shape[0], op.shape[1], -1).permute(0, 2, 1).reshape(-1, op.shape[1])
+                    self.A[idx].addmm_(U.t(), U)
+                    self.Bt[idx].addmm_(Y.t(), U)
+                if plan.b is not None:
+                    # bias = one more column of ones in U: its normal-equation entries are the column sums of U, the
+                    # column sums of the target and the row count
+                    s = self.bias_stats[idx]
+                    if plan.is_conv:
+                        kh, kw = mod.kernel_size
+                        st, pd = mod.stride[0], mod.padding[0]
+                        ho, wo = op.shape[2], op.shape[3]
+                        ipp = F.pad(ip, (pd, pd, pd, pd)) if pd else ip
+                        # column sums of im2col(ip) in kernel-position-major order k = (kh * KW + kw) * Cin + ci
+                        cols = [ipp[:, :, a:a + st * (ho - 1) + 1:st, b:b + st * (wo - 1) + 1:st].sum((0, 2, 3))
+                                for a in range(kh) for b in range(kw)]
+                        s[0].add_(torch.cat(cols))
+                        s[1].add_(op.sum((0, 2, 3)))
+                        s[2].add_(float(op.shape[0] * ho * wo))
+                    else:
+                        rows_u = ip.reshape(-1, ip.shape[-1])
+                        s[0].add_(rows_u.sum(0))
+                        s[1].add_(op.reshape(-1, op.shape[-1]).sum(0))
+                        s[2].add_(float(rows_u.shape[0]))
+            self.merge.flush()
+            self.neq.flush()
+            self.wgrad.flush()
         self.batches_seen += 1
         self._end_update()
 
@@ -222,13 +229,13 @@ def _spd_solve_fp64(A: torch.Tensor, rhs_rows: torch.Tensor, ridge: float) -> to
 
 
 def train_normal_eq(dataloader, model1, model2, model3, spec, perm, costs, budget_ratios, MAX_STEPS, separate_classifier,
-                    num_classes, model_type, verbose, ridge: float = 1e-6):
+                    num_classes, model_type, verbose, ridge: float = 1e-6, merging: str = "perm_gradmask"):
     """Same data consumption as the Adam loop (``MAX_STEPS + 1`` batches of one pass, reference :368-373);
     with ``torch.distributed`` initialised, rank r accumulates batches ``b % world == r``."""
     from .activation_matching import _dist_info
 
     fit = NormalEqFitter(model1, model2, model3, spec, perm, costs, budget_ratios, MAX_STEPS, 5e-4, separate_classifier,
-                         num_classes, model_type, ridge=ridge)
+                         num_classes, model_type, merging=merging, ridge=ridge)
     fit.rank, fit.world = _dist_info()
     def inputs():
         for idx, batch in enumerate(dataloader):

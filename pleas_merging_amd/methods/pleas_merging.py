@@ -893,13 +893,11 @@ def train(dataloader, model1, model2, model3, spec, perm, costs, budget_ratios, 
     single pass over ``dataloader`` and performs ``MAX_STEPS + 1`` updates if it is long enough.
     Puts ``model1``/``model2`` in eval mode (as the reference), mutates and returns ``model3``.
     """
-    if solver == "normal_eq" and merging_mode(merging) != "perm_gradmask":
-        raise NotImplementedError("solver='normal_eq' fits the channel-merged objective (merging='perm_gradmask') only")
     if solver == "normal_eq":
         from .normal_eq import train_normal_eq
 
         return train_normal_eq(dataloader, model1, model2, model3, spec, perm, costs, budget_ratios, MAX_STEPS,
-                               separate_classifier, num_classes, model_type, verbose)
+                               separate_classifier, num_classes, model_type, verbose, merging=merging)
     if solver != "adam":
         raise ValueError("solver must be 'adam' or 'normal_eq'")
     fit = PleasFitter(model1, model2, model3, spec, perm, costs, budget_ratios, MAX_STEPS, lr, separate_classifier,

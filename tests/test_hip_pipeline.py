@@ -262,7 +262,7 @@ def test_matching_with_fused_bn_chains_equals_module_chains(fx, request):
         assert torch.equal(d[k], c[k]), k
 
 
-def _layer_objective(t, m3, ratio, perm, costs, batches):
+def _layer_objective(t, m3, ratio, perm, costs, batches, merging="perm_gradmask"):
     """Reference objective sum_layers mean((L(ip) - op)^2) summed over batches, on the CPU oracle."""
     blocks = orc.spread_blocks(t.spec, orc.get_blocks(t.spec, perm, costs, ratio))
     a1, a2 = {}, {}
@@ -275,7 +275,7 @@ def _layer_objective(t, m3, ratio, perm, costs, batches):
             for name, layer in m3.named_modules():
                 if isinstance(layer, (torch.nn.Conv2d, torch.nn.Linear)):
                     ip, op = orc.layer_targets(orc.get_attr(t.m1, name.split(".")), orc.get_attr(t.m2, name.split(".")),
-                                               blocks, name, a1[name], a2[name], num_classes=10)
+                                               blocks, name, a1[name], a2[name], num_classes=10, merging=merging)
                     total += float(((layer(ip) - op) ** 2).mean())
     for hh in h:
         hh.remove()
@@ -888,6 +888,59 @@ def test_other_merging_modes_bottleneck_vs_oracle(tiny_bottleneck):
         for (k, a), (_, b) in zip(m3.state_dict().items(), o3.state_dict().items()):
             if k != DEGENERATE and a.dtype.is_floating_point:
                 assert _rel(a, b) < 1e-4, (mode, k, _rel(a, b))
-    with pytest.raises(NotImplementedError):
-        train(data, m1, m2, m3, t.spec, perm, costs, 0.5, False, 6, None, merging="perm_mixedls", num_classes=10,
-              solver="normal_eq")
+
+
+@pytest.mark.parametrize("mode,ratio", [("perm_separatels", 0.0), ("perm_mixedls", 0.0), ("reg_mean", 0.0),
+                                        ("perm_separatels", 0.5), ("perm_mixedls", 0.5)])
+def test_normal_eq_stacked_modes_vs_oracle(tiny_basic, mode, ratio):
+    """solver="normal_eq" on the stacked objectives (two half-batches under the same weights, reference :125-145): A and
+    B are the sums over both halves.  Every fully free layer against the fp64 oracle (normal equations of the stacked
+    ``layer_targets`` + lstsq) on the same batches, and the reference objective no higher than Adam's."""
+    from pleas.methods.partial_matching import partial_merge
+    from pleas.methods.pleas_merging import train
+
+    t = tiny_basic
+    perm, costs_c = t.per_key("am_perm"), t.per_key("am_cost")
+    costs = {k: v.cuda() for k, v in costs_c.items()}
+    data = t.batches("xt")[:21]
+    m1, m2 = _cuda_pair(t)
+    m3 = partial_merge(t.spec, m1, m2, perm, costs, ratio)
+    m_adam = train(data, m1, m2, copy.deepcopy(m3), t.spec, perm, costs, ratio, False, 20, None, num_classes=10, merging=mode)
+    m_neq = train(data, m1, m2, m3, t.spec, perm, costs, ratio, False, 20, None, num_classes=10, merging=mode,
+                  solver="normal_eq")
+    f_adam = _layer_objective(t, m_adam.cpu(), ratio, perm, costs_c, data, merging=mode)
+    f_neq = _layer_objective(t, m_neq.cpu(), ratio, perm, costs_c, data, merging=mode)
+    assert f_neq <= f_adam * (1 + 1e-4), (mode, f_adam, f_neq)
+    blocks = orc.spread_blocks(t.spec, orc.get_blocks(t.spec, perm, costs_c, ratio))
+    from pleas.methods.partial_matching import get_blocks, spread_blocks
+    from pleas.methods.pleas_merging import get_gradient_mask
+
+    layers = {n: m for n, m in m_neq.named_modules() if isinstance(m, (torch.nn.Conv2d, torch.nn.Linear))}
+    masks = get_gradient_mask(spread_blocks(t.spec, get_blocks(t.spec, perm, costs_c, ratio, False)), layers)
+    free, k = {}, 0
+    for n, m in layers.items():
+        free[n] = bool((masks[k] != 0).all())
+        k += len(list(m.named_parameters()))
+    a1, a2 = {}, {}
+    h = orc._hook_inputs(t.m1, a1) + orc._hook_inputs(t.m2, a2)
+    ips, ops_ = {n: [] for n in layers}, {n: [] for n in layers}
+    with torch.no_grad():
+        for x, _ in data:
+            t.m1(x)
+            t.m2(x)
+            for n in layers:
+                ip, op = orc.layer_targets(orc.get_attr(t.m1, n.split(".")), orc.get_attr(t.m2, n.split(".")), blocks, n,
+                                           a1[n], a2[n], num_classes=10, merging=mode)
+                ips[n].append(ip)
+                ops_[n].append(op)
+    for hh in h:
+        hh.remove()
+    checked = 0
+    for n, layer in layers.items():
+        if n == "conv1" or not free[n] or getattr(layer, "bias", None) is not None:
+            continue
+        A, Bm = orc.normal_equations(ips[n], ops_[n], layer)
+        want = orc.solve_normal_equations(A, Bm, ridge=1e-6).t().reshape(layer.weight.shape)
+        assert _rel(layer.weight, want.float()) < 1e-3, (mode, n, _rel(layer.weight, want.float()))
+        checked += 1
+    assert checked >= (3 if ratio == 0.0 else 0), (mode, checked)      # partial merges freeze blocks of most layers
