@@ -109,7 +109,7 @@ int pleas_gram_batch(const pleas_gram_node* nodes, int n_nodes, float* const* gr
  * tie rule are those of scipy's shortest-augmenting-path solver, so the output is the same
  * assignment scipy returns, including on degenerate (tied) inputs.
  */
-#define PLEAS_LSAP_MAX_N 2048
+#define PLEAS_LSAP_MAX_N 4096
 int pleas_lsap_batched(const float* const* cost, const int* n, int nprob, int maximize, int64_t* const* col_ind,
                        void* stream);
 /* The same solver for ONE problem whose cost matrix is in HOST memory (fp32 when is_double == 0, else fp64; n >= 1, no

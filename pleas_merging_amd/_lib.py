@@ -13,7 +13,7 @@ _LIB: Optional[ctypes.CDLL] = None
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libpleas_hip.so")
 
 EPI_INNER, EPI_NEG_CDIST = 0, 1
-LSAP_MAX_N = 2048
+LSAP_MAX_N = 4096
 
 # name -> (restype, argtypes); one row per symbol declared in include/pleas_hip.h
 SIGNATURES = {

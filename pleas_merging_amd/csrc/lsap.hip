@@ -42,7 +42,7 @@ struct LsapBatch {
 
 struct Cand {
     double val;
-    int key;    // (tie key << 11) | column ; smaller wins
+    int key;    // (tie key << kColBits) | column ; smaller wins
     int owner;  // row assigned to that column (-1: free), filled in for the per-wave candidates only
 };
 
@@ -109,11 +109,13 @@ __device__ __forceinline__ int col_of(int tid, int k) {
 }
 
 constexpr int kDeadKey = 0x7fffffff;
+constexpr int kColBits = 12;      // column field of the tie key: n <= 4096; the rank field above it is < 2 n (13 bits)
+constexpr int kColMask = (1 << kColBits) - 1;
 
-// Tie key of a live column: (rank in scipy's scan order << 11) | column; smaller wins among equal path lengths.
+// Tie key of a live column: (rank in scipy's scan order << kColBits) | column; smaller wins among equal path lengths.
 __device__ __forceinline__ int tie_key(int n, int pos, int r4c, int j) {
     const int tie = r4c < 0 ? (n - 1 - pos) : (n + pos);
-    return (tie << 11) | j;
+    return (tie << kColBits) | j;
 }
 
 template <int COLS>
@@ -209,7 +211,7 @@ __device__ void lsap_solve(const LsapShared sh, const float* __restrict__ cost, 
             }
             best = wave_min(best);
             {   // the row this wave's candidate leads to: read now, beside the barrier wait, not after it
-                const int jw = best.key & 2047;
+                const int jw = best.key & kColMask;
                 best.owner = (best.key != kDeadKey && jw < n) ? sh.row4col[jw] : -1;
             }
             if ((tid & 63) == 0) wave_best[parity][tid >> 6] = best;
@@ -235,8 +237,8 @@ __device__ void lsap_solve(const LsapShared sh, const float* __restrict__ cost, 
             // Every thread holds the same winner and replays the same bookkeeping; each LDS word
             // has one writer, and `remaining` slots written here are not read before the next barrier.
             dist = best.val;
-            const int j = best.key & 2047;
-            const int tie = best.key >> 11;
+            const int j = best.key & kColMask;
+            const int tie = best.key >> kColBits;
             const int pj = tie < n ? (n - 1 - tie) : (tie - n);
             const int owner = best.owner;
             if (owner >= 0) load_row(owner);   // the next row's loads fly while the bookkeeping below runs
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(kLsapThreads) void lsap_kernel(const LsapBatch batc
     else if (n <= 8 * kLsapThreads)
         lsap_solve<8>(sh, cost, n, sign, out, wave_best);
     else
-        lsap_solve<16>(sh, cost, n, sign, out, wave_best);   // only reachable with fewer than 256 threads (experiments)
+        lsap_solve<16>(sh, cost, n, sign, out, wave_best);   // n <= 4096: sixteen columns per thread, 144 KB of LDS state
 }
 
 }  // namespace pleas

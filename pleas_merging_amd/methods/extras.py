@@ -54,7 +54,8 @@ def reset_bn_stats(model: nn.Module, dataloader: Iterable, num_batches: int = 10
     A train-mode forward normalises with the batch's own statistics, so batches are independent, and the running
     statistics after n sequential updates are the fixed linear combination
     ``(1-m)^n r0 + sum_b m (1-m)^(n-1-b) stat_b``: every rank accumulates its share of the sum and ONE all-reduce of
-    a flat buffer per statistic gives every rank the sequential result.
+    a flat buffer per statistic gives every rank the sequential result (``momentum=None``, the cumulative average: the
+    plain mean of the batches' statistics).
     """
     from .activation_matching import _dist_info
 
@@ -76,9 +77,7 @@ def reset_bn_stats(model: nn.Module, dataloader: Iterable, num_batches: int = 10
     import torch.distributed as dist
 
     tracked = [m for m in bns if m.track_running_stats and m.running_mean is not None]
-    if any(m.momentum is None for m in tracked):
-        raise NotImplementedError("sharded reset_bn_stats: cumulative-average BatchNorm (momentum=None)")
-    saved = [m.momentum for m in tracked]
+    saved = [m.momentum for m in tracked]      # None = cumulative average: the running statistics are the plain mean
     sizes = [m.num_features for m in tracked]
     acc = torch.zeros(2, sum(sizes), dtype=torch.float64, device=device)     # weighted sums of batch means / variances
     n = 0
@@ -94,7 +93,7 @@ def reset_bn_stats(model: nn.Module, dataloader: Iterable, num_batches: int = 10
             runner(batch[0].to(device).float())
             off = 0
             for m, mom, c in zip(tracked, saved, sizes):
-                wgt = (1.0 - mom) ** (-i)                                    # common factor m (1-m)^(n-1) applied at the end
+                wgt = 1.0 if mom is None else (1.0 - mom) ** (-i)            # common factor m (1-m)^(n-1) applied at the end
                 acc[0, off:off + c].add_(m.running_mean.double(), alpha=wgt)
                 acc[1, off:off + c].add_(m.running_var.double(), alpha=wgt)
                 off += c
@@ -104,7 +103,7 @@ def reset_bn_stats(model: nn.Module, dataloader: Iterable, num_batches: int = 10
     dist.all_reduce(acc, op=dist.ReduceOp.SUM)
     off = 0
     for m, mom, c in zip(tracked, saved, sizes):
-        scale, keep = mom * (1.0 - mom) ** (n - 1), (1.0 - mom) ** n
+        scale, keep = (1.0 / max(n, 1), 0.0) if mom is None else (mom * (1.0 - mom) ** (n - 1), (1.0 - mom) ** n)
         m.running_mean.copy_((acc[0, off:off + c] * scale).float())           # r0 = 0
         m.running_var.copy_((acc[1, off:off + c] * scale + keep).float())     # r0 = 1
         m.num_batches_tracked.fill_(n)

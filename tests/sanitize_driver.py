@@ -112,7 +112,7 @@ def main():
     expect(lib.pleas_fwd_batch_ws_bytes(None, 0) == 0 and lib.pleas_wgrad_batch_ws_bytes(None, 3) == 0, "NULL layer lists")
     # ---- compute entry points with arguments their validation refuses (nothing is launched)
     expect(lib.pleas_gram_accum(None, None, 1, 4, 4, 0, 0, None, None, 0, None) == -22, "gram_accum(NULL)")
-    n1 = (ctypes.c_int * 1)(4096)
+    n1 = (ctypes.c_int * 1)(4097)
     ptr = (ctypes.c_void_p * 1)(8)
     expect(lib.pleas_lsap_batched(ptr, n1, 1, 1, ptr, None) == -22, "lsap_batched(n > max)")
     expect(lib.pleas_bn_act_maxpool(ptr, None, None, ptr, 2, 4, 8, 8, 3, 3, 2, 2, 1, None) == -22, "bn_act_maxpool(pad > kernel / 2)")

@@ -79,6 +79,19 @@ def _bn_reset_worker(rank, world, port, q):
             ok &= bool(torch.allclose(a, b, rtol=1e-5, atol=1e-6))
         elif "num_batches_tracked" in k:
             ok &= int(a) == int(b) == 6
+    # cumulative-average BatchNorm (momentum=None): the running statistics are the plain mean over the batches
+    cum = copy.deepcopy(t.m1)
+    for m in cum.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.momentum = None
+    seq = reset_bn_stats(copy.deepcopy(cum), data, 6, shard=False)
+    par = reset_bn_stats(copy.deepcopy(cum), data, 6, shard=True)
+    for (k, a), (_, b) in zip(seq.state_dict().items(), par.state_dict().items()):
+        if "running" in k:
+            ok &= bool(torch.allclose(a, b, rtol=1e-5, atol=1e-6))
+        elif "num_batches_tracked" in k:
+            ok &= int(a) == int(b) == 6
+    ok &= all(m.momentum is None for m in par.modules() if isinstance(m, torch.nn.BatchNorm2d))
     q.put((rank, ok))
     dist.destroy_process_group()
 

@@ -115,7 +115,7 @@ def test_lsap_bit_exact_vs_scipy_batched(ops, maximize):
         assert (o.cpu().numpy() == want).all(), (m.shape, maximize)
 
 
-@pytest.mark.parametrize("n", [1024, 2048])
+@pytest.mark.parametrize("n", [1024, 2048, 2049, 3000, 4096])
 def test_lsap_large(ops, n):
     rng = np.random.default_rng(n)
     cases = _lap_cases(n, rng)
@@ -149,7 +149,7 @@ def test_lsap_rejects_bad_sizes(ops):
     with pytest.raises(ops.PleasHipError):
         ops.solve_lsa_batched([torch.zeros(3, 4).cuda()])
     with pytest.raises(ops.PleasHipError):
-        ops.solve_lsa_batched([torch.zeros(2049, 2049).cuda()])
+        ops.solve_lsa_batched([torch.zeros(4097, 4097).cuda()])
 
 
 # ------------------------------------------------------------------------------------------ merge / adam / sqerr

@@ -307,7 +307,7 @@ def test_argument_errors_without_gpu():
     assert b"null" in lib.pleas_last_error()
     assert lib.pleas_gram_ws_bytes(16, 256, 196) >= 256 * 256 * 4
     assert lib.pleas_gram_ws_bytes(0, 256, 196) == 0
-    n = (ctypes.c_int * 1)(4096)
+    n = (ctypes.c_int * 1)(4097)
     ptr = (ctypes.c_void_p * 1)(8)
     assert lib.pleas_lsap_batched(ptr, n, 1, 1, ptr, None) == -22  # n > PLEAS_LSAP_MAX_N
     assert lib.pleas_masked_adam(None, None, None, None, None, 4, 1e-3, 0.9, 0.999, 1e-8, 1, None) == -22
