@@ -65,9 +65,9 @@ def parse(argv=None):
                     help="updates PER RANK whose batches go through the frozen sources as ONE forward (128 samples per "
                          "forward at 8: the vendor convolutions run 15-30 %% faster per sample than at 32); 0 = the fitter's "
                          "default of 2; the prefetch takes --prefetch-groups forwards of that size")
-    ap.add_argument("--match-per-forward", type=int, default=4,
+    ap.add_argument("--match-per-forward", type=int, default=10,
                     help="matching batches per twin forward (every tracked node is still contracted per batch): the vendor "
-                         "convolutions run faster per sample at 64 samples than at 16; 0 = the library's default of 2")
+                         "convolutions run faster per sample at 64-160 samples than at 16; 0 = the library's default of 2")
     ap.add_argument("--miopen-find", type=int, default=0, help="1: torch.backends.cudnn.benchmark = True, i.e. the vendor "
                     "library times its candidate convolution kernels per configuration (Find mode) instead of taking the "
                     "immediate-mode pick; costs seconds per new configuration in the first warm-up job")
