@@ -67,17 +67,26 @@ struct Stage {
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int kSplitLd = 104;   // bf16 per LDS row of the split image: 3 planes x 32 k + 8 pad = 208 B (13 16-byte slots:
                                 // odd, so the 16 rows of a ds_read_b128 lane group fall on 16 different slots)
-__device__ __forceinline__ void split3(const float (&v)[4], bf16x4 (&h)[3]) {
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// Two values at a time: one v_cvt_pk_bf16_f32 per pair and plane, the bf16 values back as floats by a shift / a mask
+// (11 vector instructions per pair; element by element the compiler spent 15).
+__device__ __forceinline__ uint32_t bf16_pair(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));      // a in the low half
+}
+__device__ __forceinline__ void split3_pair(float a, float b, uint32_t (&p)[3]) {
+    p[0] = bf16_pair(a, b);
+    const float ra = a - __builtin_bit_cast(float, p[0] << 16), rb = b - __builtin_bit_cast(float, p[0] & 0xffff0000u);
+    p[1] = bf16_pair(ra, rb);
+    p[2] = bf16_pair(ra - __builtin_bit_cast(float, p[1] << 16), rb - __builtin_bit_cast(float, p[1] & 0xffff0000u));
+}
+__device__ __forceinline__ void split3(const float (&v)[4], uint2 (&h)[3]) {      // h[plane] = four bf16, k order kept
+    uint32_t lo[3], hi[3];
+    split3_pair(v[0], v[1], lo);
+    split3_pair(v[2], v[3], hi);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const __bf16 h1 = (__bf16)v[e];
-        const float r1 = v[e] - (float)h1;
-        const __bf16 h2 = (__bf16)r1;
-        const float r2 = r1 - (float)h2;
-        h[0][e] = h1;
-        h[1][e] = h2;
-        h[2][e] = (__bf16)r2;
-    }
+    for (int p = 0; p < 3; ++p) h[p] = make_uint2(lo[p], hi[p]);
 }
 
 // One workgroup's share: output tile (tm, tn) over K chunks [c_begin, c_end) -> slab `split`.
@@ -130,9 +139,12 @@ __device__ __forceinline__ void gram_tile(const GramGeom& g, float* smem, const 
         row_off_b[q] = (size_t)min(gj, g.C - 1) * g.HW;
     }
     bool staged_kin = false;
+    bool staged_full = false;                                         // SPLIT: the staged chunk lies inside K (block-uniform)
+    const bool interior = i0 + TILE <= g.C && j0 + TILE <= g.C;       // SPLIT: every row of both operand tiles exists
     auto load_chunk = [&](int c) {
         const uint32_t k = (uint32_t)c * kBK + scol;
         const bool kin = k < g.Ktot;
+        if constexpr (SPLIT) staged_full = (uint32_t)(c + 1) * kBK <= g.Ktot;
         const uint32_t n = kin ? k / g.HW : 0u;
         const uint32_t p = kin ? k - n * g.HW : 0u;
         const size_t base = (size_t)n * g.C * g.HW + p;
@@ -161,20 +173,23 @@ __device__ __forceinline__ void gram_tile(const GramGeom& g, float* smem, const 
             const int row = srow + q * ROWS_PER_PASS;
             const bool oka = staged_kin && ((rows_ok_a >> q) & 1u);
             const bool okb = staged_kin && ((rows_ok_b >> q) & 1u);
+            // SPLIT: a tile inside the matrix on a chunk inside K needs no masking (block-uniform test, no selects)
+            if (!(SPLIT && interior && staged_full)) {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                ra.v[q][e] = oka ? ra.v[q][e] : 0.f;
-                rb.v[q][e] = okb ? rb.v[q][e] : 0.f;
+                for (int e = 0; e < VEC; ++e) {
+                    ra.v[q][e] = oka ? ra.v[q][e] : 0.f;
+                    rb.v[q][e] = okb ? rb.v[q][e] : 0.f;
+                }
             }
             if constexpr (SPLIT) {
                 static_assert(!SPLIT || VEC == 4, "the split image is written four k at a time");
-                bf16x4 ha[3], hb[3];
+                uint2 ha[3], hb[3];
                 split3(ra.v[q], ha);
                 split3(rb.v[q], hb);
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {
-                    *reinterpret_cast<bf16x4*>(As16 + row * kSplitLd + p * kBK + scol) = ha[p];
-                    *reinterpret_cast<bf16x4*>(Bs16 + row * kSplitLd + p * kBK + scol) = hb[p];
+                    *reinterpret_cast<uint2*>(As16 + row * kSplitLd + p * kBK + scol) = ha[p];
+                    *reinterpret_cast<uint2*>(Bs16 + row * kSplitLd + p * kBK + scol) = hb[p];
                 }
             } else if constexpr (VEC == 4) {
                 f32x4 va = {ra.v[q][0], ra.v[q][1], ra.v[q][2], ra.v[q][3]};
