@@ -591,8 +591,17 @@ __device__ __forceinline__ void fwd_flat_tile(const FwdLayerDev& L, const FwdIte
         }
         const float* a = As + abuf * TM * fLdsA + (wm * (TM / 2) + (lane & 31)) * fLdsA + 4 * (lane >> 5);
         const float* bb = Bs + bbuf * fBK * Lr + 4 * (lane >> 5) * Lr;     // half-wave h takes k = 8 kk + e + 4 h
-        const float* b0 = bb + (((tapok[0] >> r) & 1u) ? jb[0] + delta : jz);
-        const float* b1 = bb + (((tapok[1] >> r) & 1u) ? jb[1] + delta : jz);
+        // A lane whose tap falls outside the image takes 0: by a select on the value it read at its own (always valid:
+        // the halo is part of the image) address.  Reading the row's zero column instead put that lane on the bank of
+        // some other lane of its half-wave: 22 % of the k x k forms' LDS cycles were such 2-way conflicts
+        // (profiles/r03_lds_fwd_batch_rn101_before.txt).  PLEAS_FWD_ZEROCOL=1 at build time restores the zero-column read.
+#ifndef PLEAS_FWD_ZEROCOL
+#define PLEAS_FWD_ZEROCOL 0
+#endif
+        const bool ok0 = (tapok[0] >> r) & 1u, ok1 = (tapok[1] >> r) & 1u;
+        constexpr bool zero_col = PLEAS_FWD_ZEROCOL || KIND != 2;      // 1 x 1 forms: only pixels past the tensor's end
+        const float* b0 = bb + ((zero_col && !ok0) ? jz : jb[0] + delta);
+        const float* b1 = bb + ((zero_col && !ok1) ? jz : jb[1] + delta);
 #pragma unroll
         for (int kk = 0; kk < fBK / 8; ++kk) {
             f32x4 fa[MTM];
@@ -600,7 +609,11 @@ __device__ __forceinline__ void fwd_flat_tile(const FwdLayerDev& L, const FwdIte
             for (int s = 0; s < MTM; ++s) fa[s] = *reinterpret_cast<const f32x4*>(a + s * 32 * fLdsA + kk * 8);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float f0 = b0[(kk * 8 + e) * Lr], f1 = b1[(kk * 8 + e) * Lr];
+                float f0 = b0[(kk * 8 + e) * Lr], f1 = b1[(kk * 8 + e) * Lr];
+                if constexpr (!zero_col) {
+                    f0 = ok0 ? f0 : 0.f;
+                    f1 = ok1 ? f1 : 0.f;
+                }
 #pragma unroll
                 for (int sm = 0; sm < MTM; ++sm) {
                     acc[sm][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sm][e], f0, acc[sm][0], 0, 0, 0);
