@@ -27,11 +27,16 @@ for b in range(100):
     data.append((torch.randn(16, 3, 224, 224, generator=gen, device=dev), None))
 results = {}
 for name, train, kw in (("eval, fused + derived", False, {}), ("eval, vendor BatchNorm modules", False, {"fuse_bn": False}),
+                        ("eval, fused + derived, 10 batches per forward", False, {"batches_per_forward": 10}),
+                        ("train, fused + derived, ONE batch per forward", True, {"batches_per_forward": 1}),
+                        ("train, fused + derived, 4 batches per forward", True, {"batches_per_forward": 4}),
+                        ("train, fused + derived, 10 batches per forward", True, {"batches_per_forward": 10}),
                         ("train, fused + derived (pleas_bn_train_fold)", True, {}),
                         ("train, fused, BatchNorm nodes contracted", True, {"derive_bn": False}),
                         ("train, vendor BatchNorm modules", True, {"fuse_bn": False})):
     ms = [copy.deepcopy(m).train(train) for m in models]
-    accumulate_costs_fused(spec, ms[0], ms[1], data[:3], 3, hip_ops.EPI_NEG_CDIST, **kw)       # warm-up (vendor find, plans)
+    warm = max(3, 2 * (kw.get("batches_per_forward") or 2))      # two forwards of the timed size: vendor find, plans
+    accumulate_costs_fused(spec, ms[0], ms[1], data[:warm], warm, hip_ops.EPI_NEG_CDIST, **kw)
     torch.cuda.synchronize()
     ms = [copy.deepcopy(m).train(train) for m in models]
     t0 = time.perf_counter()
@@ -45,3 +50,7 @@ a, b = results["train, fused + derived (pleas_bn_train_fold)"], results["train, 
 flips = sum(int((a[1][k] != b[1][k]).sum()) for k in spec)
 rel = max(float((a[2][k] - b[2][k]).norm() / b[2][k].norm()) for k in spec)
 print("train mode, fused vs vendor modules: worst cost rel-fro %.2e, differing assignments %d of %d units" % (rel, flips, sum(g.size for g in spec.values())))
+a, b = results["train, fused + derived, 10 batches per forward"], results["train, fused + derived, ONE batch per forward"]
+flips = sum(int((a[1][k] != b[1][k]).sum()) for k in spec)
+rel = max(float((a[2][k] - b[2][k]).norm() / b[2][k].norm()) for k in spec)
+print("train mode, 10 batches per forward vs one: worst cost rel-fro %.2e, differing assignments %d of %d units" % (rel, flips, sum(g.size for g in spec.values())))
