@@ -3,7 +3,7 @@
 (1) Weights trained BY THE REFERENCE for 6 / 21 / 401 updates on the two tiny fixtures (tests/golden/
     tiny_bottleneck_train.npz, make_golden_bottleneck_train.py) against the HIP path: the north-star gate, 1e-4 rel-fro
     per tensor; the Bottleneck fixture had no reference-trained golden before.
-(2) A ResNet-50 pair at 224 x 224, batch 2, 401 updates: HIP path against the oracle (which follows the reference to
+(2) A ResNet-50 pair and a ResNet-101 pair (BASELINE.json's headline depth) at 224 x 224, batch 2, 401 updates: HIP path against the oracle (which follows the reference to
     1e-5 over 401 updates on the tiny fixtures), snapshots after 1 / 3 / 21 / 101 / 401 updates.  Gate per layer at
     update 401: objective within 1 %, weights within max(1e-4, 3 x the oracle's disagreement with ITSELF at that
     update) (tests/golden/long_horizon_resnet50_spread.json: same run with oneDNN convolutions off).  The trajectory of
@@ -69,13 +69,24 @@ def _fit_weights(fit):
 
 
 def test_rn50_401_updates_vs_oracle():
+    _long_horizon_vs_oracle("resnet50")
+
+
+@pytest.mark.skipif(os.environ.get("PLEAS_SKIP_LONG_RN101", "0") == "1",
+                    reason="ResNet-101 over 401 updates: ~2 minutes, most of it the oracle on the host cores "
+                           "(trajectory of the last run: profiles/r03_long_horizon_rn101.json)")
+def test_rn101_401_updates_vs_oracle():
+    _long_horizon_vs_oracle("resnet101")
+
+
+def _long_horizon_vs_oracle(arch):
     from oracle import pleas_oracle as orc
     from pleas.methods.partial_matching import partial_merge
     from pleas.methods.pleas_merging import PleasFitter
 
-    spread = json.load(open(os.path.join(GOLDEN, "long_horizon_resnet50_spread.json")))
-    assert spread["batch"] == lh.BATCH and tuple(spread["snapshots"]) == lh.SNAPSHOTS
-    m1, m2, spec, match, train = lh.build_pair("resnet50")
+    spread = json.load(open(os.path.join(GOLDEN, "long_horizon_%s_spread.json" % arch)))
+    assert spread["arch"] == arch and spread["batch"] == lh.BATCH and tuple(spread["snapshots"]) == lh.SNAPSHOTS
+    m1, m2, spec, match, train = lh.build_pair(arch)
     perm, costs = orc.activation_matching(spec, m1, m2, match, 2, accumulate=True)
 
     # ---- HIP path (from the ORACLE's permutation and costs, so that both sides merge the same blocks)
@@ -126,11 +137,11 @@ def test_rn50_401_updates_vs_oracle():
                                                   trajectory[-1]["tensors_above_1e-4"], loss_rel))
     out_dir = os.path.join(REPO, "gpurun_out")
     if os.path.isdir(out_dir):
-        with open(os.path.join(out_dir, "r03_long_horizon_rn50.json"), "w") as f:
-            json.dump({"arch": "resnet50", "batch": lh.BATCH, "trajectory": trajectory}, f, indent=1)
+        with open(os.path.join(out_dir, "r03_long_horizon_%s.json" % arch.replace("resnet", "rn")), "w") as f:
+            json.dump({"arch": arch, "batch": lh.BATCH, "trajectory": trajectory}, f, indent=1)
     # ---- the gate, at the end of the drivers' horizon
     last = trajectory[-1]
     assert last["tensors_above_gate"] == 0, (last, over)
     assert last["worst_layer_objective_rel"] < 1e-2, last
     gate_stem(got[lh.N_UPDATES][DEGENERATE], merged_stem, [want[lh.N_UPDATES][DEGENERATE]],
-              lambda w: stem_objective(m1, m2, w, spec, perm, costs, 0.0, train[:8], 1000), what="rn50 stem, 401 updates")
+              lambda w: stem_objective(m1, m2, w, spec, perm, costs, 0.0, train[:8], 1000), what="%s stem, 401 updates" % arch)
