@@ -67,7 +67,8 @@ def parse(argv=None):
                          "default of 2; the prefetch takes --prefetch-groups forwards of that size")
     ap.add_argument("--match-per-forward", type=int, default=10,
                     help="matching batches per twin forward (every tracked node is still contracted per batch): the vendor "
-                         "convolutions run faster per sample at 64-160 samples than at 16; 0 = the library's default of 2")
+                         "convolutions run faster per sample at 64-160 samples than at 16; 0 = the library's default (forwards of up to 64 "
+                         "samples, at most 4 batches)")
     ap.add_argument("--miopen-find", type=int, default=0, help="1: torch.backends.cudnn.benchmark = True, i.e. the vendor "
                     "library times its candidate convolution kernels per configuration (Find mode) instead of taking the "
                     "immediate-mode pick; costs seconds per new configuration in the first warm-up job")

@@ -170,6 +170,14 @@ int pleas_bn_act(const float* x, const float* scale, const float* shift, const f
 int pleas_bn_act_tracked(const float* x, const float* scale, const float* shift, const float* res, float* y_bn,
                          float* y_sum, float* y, int64_t n, int channels, int64_t inner, int relu, void* stream);
 
+/* The tracked pass on a tensor that holds `batches` batches back to back along n, each with its OWN affine map: scale /
+ * shift are [batches][channels] (pleas_bn_train_fold_batches).  Replaces the same module chains when the twin forward of
+ * activation_matching.py:49-100 carries several matching batches and the models are in train mode (batch statistics are
+ * per batch: run_domainnet.py:172-186 never calls .eval()). */
+int pleas_bn_act_tracked_batches(const float* x, const float* scale, const float* shift, const float* res, float* y_bn,
+                                 float* y_sum, float* y, int64_t n_per_batch, int batches, int channels, int64_t inner,
+                                 int relu, void* stream);
+
 /* The same map followed by a max pooling window, one pass (a ResNet's stem: bn1 -> relu -> maxpool).
  *
  * Replaces: BatchNorm2d -> ReLU -> nn.MaxPool2d(kernel, stride, padding) of a frozen source forward
@@ -202,6 +210,13 @@ int pleas_bn_train_fold(const float* x, int64_t n, int channels, int64_t inner, 
                         double eps, double momentum, float* running_mean, float* running_var,
                         int64_t* num_batches_tracked, float* scale, float* shift, void* ws, size_t ws_bytes,
                         void* stream);
+/* `batches` batches of n samples each, back to back along the sample axis: every batch is folded on its own samples, IN
+ * ORDER -- scale / shift are [batches][channels]; running statistics and counter end where `batches` successive forwards
+ * of the module leave them.  ws: batches * pleas_bn_train_ws_bytes(n, channels) bytes. */
+int pleas_bn_train_fold_batches(const float* x, int64_t n, int batches, int channels, int64_t inner, const float* gamma,
+                                const float* beta, double eps, double momentum, float* running_mean, float* running_var,
+                                int64_t* num_batches_tracked, float* scale, float* shift, void* ws, size_t ws_bytes,
+                                void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Fused masked Adam step over a flat parameter arena.

@@ -33,6 +33,11 @@ SIGNATURES = {
                                      c_int64, c_int, c_void_p]),
     "pleas_bn_act_maxpool": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int,
                                      c_int, c_int, c_void_p]),
+    "pleas_bn_act_tracked_batches": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
+                                             c_int, c_int64, c_int, c_void_p]),
+    "pleas_bn_train_fold_batches": (c_int, [c_void_p, c_int64, c_int, c_int, c_int64, c_void_p, c_void_p, ctypes.c_double,
+                                            ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            c_size_t, c_void_p]),
     "pleas_bn_train_ws_bytes": (c_size_t, [c_int64, c_int]),
     "pleas_bn_train_fold": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, ctypes.c_double, ctypes.c_double,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -26,6 +26,9 @@ __global__ __launch_bounds__(kBnThreads) void bn_stats_partial_kernel(const floa
                                                                       int channels, int64_t inner, int vec,
                                                                       double* __restrict__ part) {
     const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
+    // blockIdx.z: which of the batches that lie back to back along the sample axis (each has its own statistics)
+    x += (int64_t)blockIdx.z * n_samples * channels * inner;
+    part += (int64_t)blockIdx.z * S * channels * 2;
     double a = 0.0, b = 0.0;
     for (int n = s; n < n_samples; n += S) {
         const float* row = x + ((int64_t)n * channels + c) * inner;
@@ -72,36 +75,44 @@ __global__ __launch_bounds__(kBnThreads) void bn_stats_partial_kernel(const floa
 }
 
 __global__ __launch_bounds__(1024) void bn_train_finalize_kernel(const double* __restrict__ part, int S, int channels,
-                                                                 double count, const float* __restrict__ gamma,
+                                                                 int batches, double count,
+                                                                 const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, double eps,
                                                                  double momentum, float* __restrict__ running_mean,
                                                                  float* __restrict__ running_var,
                                                                  int64_t* __restrict__ num_batches_tracked,
                                                                  float* __restrict__ scale, float* __restrict__ shift) {
-    // exponential factor as torch.nn.BatchNorm2d.forward: `momentum`, or 1 / (batches seen including this one)
-    double factor = momentum;
-    if (momentum < 0.0) factor = num_batches_tracked ? 1.0 / (double)(*num_batches_tracked + 1) : 0.0;
+    // exponential factor as torch.nn.BatchNorm2d.forward: `momentum`, or 1 / (batches seen including this one).  Several
+    // batches are folded IN ORDER: scale / shift [batch][channel], the running statistics move on batch by batch.
+    const int64_t seen = (momentum < 0.0 && num_batches_tracked) ? *num_batches_tracked : 0;
     for (int c = threadIdx.x; c < channels; c += blockDim.x) {
-        double a = 0.0, b = 0.0;
-        for (int s = 0; s < S; ++s) {
-            a += part[((int64_t)s * channels + c) * 2 + 0];
-            b += part[((int64_t)s * channels + c) * 2 + 1];
-        }
-        const double mean = a / count;
-        double var = b / count - mean * mean;
-        var = var > 0.0 ? var : 0.0;
-        const double g = gamma ? (double)gamma[c] : 1.0;
-        const double sc = g / sqrt(var + eps);
-        scale[c] = (float)sc;
-        shift[c] = (float)((beta ? (double)beta[c] : 0.0) - mean * sc);
-        if (running_mean) running_mean[c] = (float)((1.0 - factor) * (double)running_mean[c] + factor * mean);
-        if (running_var) {
+        double rm = running_mean ? (double)running_mean[c] : 0.0, rv = running_var ? (double)running_var[c] : 0.0;
+        for (int bt = 0; bt < batches; ++bt) {
+            const double* pb = part + (int64_t)bt * S * channels * 2;
+            double factor = momentum;
+            if (momentum < 0.0) factor = num_batches_tracked ? 1.0 / (double)(seen + bt + 1) : 0.0;
+            double a = 0.0, b = 0.0;
+            for (int s = 0; s < S; ++s) {
+                a += pb[((int64_t)s * channels + c) * 2 + 0];
+                b += pb[((int64_t)s * channels + c) * 2 + 1];
+            }
+            const double mean = a / count;
+            double var = b / count - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            const double g = gamma ? (double)gamma[c] : 1.0;
+            const double sc = g / sqrt(var + eps);
+            scale[(int64_t)bt * channels + c] = (float)sc;
+            shift[(int64_t)bt * channels + c] = (float)((beta ? (double)beta[c] : 0.0) - mean * sc);
+            // the module stores fp32 after every forward: round like it does, batch by batch
+            rm = (double)(float)((1.0 - factor) * rm + factor * mean);
             const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-            running_var[c] = (float)((1.0 - factor) * (double)running_var[c] + factor * unbiased);
+            rv = (double)(float)((1.0 - factor) * rv + factor * unbiased);
         }
+        if (running_mean) running_mean[c] = (float)rm;
+        if (running_var) running_var[c] = (float)rv;
     }
     __syncthreads();   // every thread has read the old count
-    if (threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
+    if (threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += batches;
 }
 
 static inline int bn_splits(int64_t n, int channels) {
@@ -119,26 +130,34 @@ extern "C" size_t pleas_bn_train_ws_bytes(int64_t n, int channels) {
     return (size_t)bn_splits(n, channels) * channels * 2 * sizeof(double);
 }
 
-extern "C" int pleas_bn_train_fold(const float* x, int64_t n, int channels, int64_t inner, const float* gamma,
-                                   const float* beta, double eps, double momentum, float* running_mean,
-                                   float* running_var, int64_t* num_batches_tracked, float* scale, float* shift,
-                                   void* ws, size_t ws_bytes, void* stream_) {
+extern "C" int pleas_bn_train_fold_batches(const float* x, int64_t n, int batches, int channels, int64_t inner,
+                                           const float* gamma, const float* beta, double eps, double momentum,
+                                           float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                           float* scale, float* shift, void* ws, size_t ws_bytes, void* stream_) {
     if (!x || !scale || !shift) return bad_arg("null pointer");
-    if (n <= 0 || channels <= 0 || inner <= 0) return bad_arg("empty batch");
+    if (n <= 0 || channels <= 0 || inner <= 0 || batches <= 0) return bad_arg("empty batch");
     if ((running_mean == nullptr) != (running_var == nullptr)) return bad_arg("running_mean / running_var: both or neither");
-    if (n >= ((int64_t)1 << 31) || channels > 65535) return bad_arg("tensor too large");
-    if (!ws || ws_bytes < pleas_bn_train_ws_bytes(n, channels)) return PLEAS_ENOMEM;
+    if (n >= ((int64_t)1 << 31) || channels > 65535 || batches > 65535) return bad_arg("tensor too large");
+    if (!ws || ws_bytes < (size_t)batches * pleas_bn_train_ws_bytes(n, channels)) return PLEAS_ENOMEM;
     if ((uintptr_t)ws & 7) return bad_arg("workspace must be 8-byte aligned");
     hipStream_t stream = (hipStream_t)stream_;
     const int S = bn_splits(n, channels);
     const int vec = (inner % 4 == 0 && ((uintptr_t)x & 15) == 0) ? 1 : 0;
-    ProfScope prof(kProfBnAct, 0.0, (double)n * channels * inner * sizeof(float), stream);
-    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(channels, S), dim3(kBnThreads), 0, stream, x, (int)n, channels, inner,
-                       vec, (double*)ws);
+    ProfScope prof(kProfBnAct, 0.0, (double)batches * n * channels * inner * sizeof(float), stream);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(channels, S, batches), dim3(kBnThreads), 0, stream, x, (int)n, channels,
+                       inner, vec, (double*)ws);
     PLEAS_LAUNCH_CHECK("bn_stats_partial_kernel");
-    hipLaunchKernelGGL(bn_train_finalize_kernel, dim3(1), dim3(1024), 0, stream, (const double*)ws, S, channels,
+    hipLaunchKernelGGL(bn_train_finalize_kernel, dim3(1), dim3(1024), 0, stream, (const double*)ws, S, channels, batches,
                        (double)n * (double)inner, gamma, beta, eps, momentum, running_mean, running_var,
                        num_batches_tracked, scale, shift);
     PLEAS_LAUNCH_CHECK("bn_train_finalize_kernel");
     return PLEAS_OK;
+}
+
+extern "C" int pleas_bn_train_fold(const float* x, int64_t n, int channels, int64_t inner, const float* gamma,
+                                   const float* beta, double eps, double momentum, float* running_mean,
+                                   float* running_var, int64_t* num_batches_tracked, float* scale, float* shift,
+                                   void* ws, size_t ws_bytes, void* stream_) {
+    return pleas_bn_train_fold_batches(x, n, 1, channels, inner, gamma, beta, eps, momentum, running_mean, running_var,
+                                       num_batches_tracked, scale, shift, ws, ws_bytes, stream_);
 }

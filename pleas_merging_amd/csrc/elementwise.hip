@@ -122,6 +122,9 @@ __global__ __launch_bounds__(kEwThreads) void merge_blocks_kernel(
 // One pass over x (and res): replaces the vendor BN + in-place add + in-place ReLU chain (3 kernels, 7 tensor passes)
 // of a frozen source model.  `y_act` is always written; `y_bn` / `y_sum` (nullable) are the intermediate values for
 // callers that track them (activation matching measures every node).  `inner_v` = HW / VEC.
+// `rows_per_map` != 0: the tensor is several batches back to back along n, each with its own affine map
+// (scale / shift [batch][channel]; rows_per_map = samples per batch * channels) -- train-mode BatchNorm of a forward that
+// carries several matching batches.
 template <int VEC>
 __global__ __launch_bounds__(kEwThreads) void bn_act_kernel(const float* __restrict__ x,
                                                             const float* __restrict__ scale,
@@ -129,11 +132,12 @@ __global__ __launch_bounds__(kEwThreads) void bn_act_kernel(const float* __restr
                                                             const float* __restrict__ res, float* __restrict__ y_bn,
                                                             float* __restrict__ y_sum, float* __restrict__ y,
                                                             int64_t total_v, unsigned inner_v, unsigned channels,
-                                                            int relu) {
+                                                            int relu, unsigned rows_per_map) {
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total_v;
          idx += (int64_t)gridDim.x * blockDim.x) {
         const unsigned row = (unsigned)(idx / inner_v);   // n * channels + c  (< 2^31, checked by the host)
-        const unsigned c = row % channels;
+        unsigned c = row % channels;
+        if (rows_per_map) c += (row / rows_per_map) * channels;      // kernel-uniform test
         const float a = scale[c], b = shift[c];
         if constexpr (VEC == 4) {
             const f32x4 q = reinterpret_cast<const f32x4*>(x)[idx];
@@ -320,9 +324,12 @@ extern "C" int pleas_merge_blocks(const float* w1, const float* w2, float* out, 
 }
 
 static int bn_act_launch(const float* x, const float* scale, const float* shift, const float* res, float* y_bn,
-                         float* y_sum, float* y, int64_t n, int channels, int64_t inner, int relu, void* stream_) {
+                         float* y_sum, float* y, int64_t n, int channels, int64_t inner, int relu, void* stream_,
+                         int64_t n_per_map = 0) {
     if (!x || !scale || !shift || !y) return bad_arg("null pointer");
     if (n < 0 || channels <= 0 || inner <= 0) return bad_arg("negative size");
+    if (n_per_map < 0 || (n_per_map > 0 && n % n_per_map != 0)) return bad_arg("samples do not split into whole batches");
+    const unsigned rows_per_map = (n_per_map > 0 && n_per_map < n) ? (unsigned)(n_per_map * channels) : 0u;
     const int64_t total = n * channels * inner;
     if (total == 0) return PLEAS_OK;
     if (n * channels >= ((int64_t)1 << 31) || inner >= ((int64_t)1 << 31)) return bad_arg("tensor too large");
@@ -333,10 +340,10 @@ static int bn_act_launch(const float* x, const float* scale, const float* shift,
     ProfScope prof(kProfBnAct, 0.0, passes * total * sizeof(float), stream);
     if (vec)
         hipLaunchKernelGGL((bn_act_kernel<4>), dim3(ew_grid(total / 4)), dim3(kEwThreads), 0, stream, x, scale, shift, res,
-                           y_bn, y_sum, y, total / 4, (unsigned)(inner / 4), (unsigned)channels, relu);
+                           y_bn, y_sum, y, total / 4, (unsigned)(inner / 4), (unsigned)channels, relu, rows_per_map);
     else
         hipLaunchKernelGGL((bn_act_kernel<1>), dim3(ew_grid(total)), dim3(kEwThreads), 0, stream, x, scale, shift, res,
-                           y_bn, y_sum, y, total, (unsigned)inner, (unsigned)channels, relu);
+                           y_bn, y_sum, y, total, (unsigned)inner, (unsigned)channels, relu, rows_per_map);
     PLEAS_LAUNCH_CHECK("bn_act_kernel");
     return PLEAS_OK;
 }
@@ -422,6 +429,14 @@ extern "C" int pleas_bn_act_maxpool(const float* x, const float* scale, const fl
                            (unsigned)channels, H, W, Ho, Wo, KH, KW, stride, pad, relu);
     PLEAS_LAUNCH_CHECK("bn_act_pool_kernel");
     return PLEAS_OK;
+}
+
+extern "C" int pleas_bn_act_tracked_batches(const float* x, const float* scale, const float* shift, const float* res,
+                                            float* y_bn, float* y_sum, float* y, int64_t n_per_batch, int batches,
+                                            int channels, int64_t inner, int relu, void* stream_) {
+    if (batches <= 0 || n_per_batch < 0) return bad_arg("batches");
+    return bn_act_launch(x, scale, shift, res, y_bn, y_sum, y, n_per_batch * batches, channels, inner, relu, stream_,
+                         n_per_batch);
 }
 
 extern "C" int pleas_masked_adam(float* p, const float* g, const float* mask, float* m, float* v, int64_t n, float lr,

@@ -339,18 +339,22 @@ def bn_act_tracked(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, re
             raise PleasHipError("bn_act_tracked: residual shape/dtype differs from x")
         res = res.contiguous()
     C = x.shape[1]
-    if scale.numel() != C or shift.numel() != C:
-        raise PleasHipError("bn_act_tracked: scale/shift must hold one entry per channel")
+    # scale / shift [batches][C]: x holds that many batches back to back along dim 0, each with its own affine map
+    batches = scale.shape[0] if scale.dim() == 2 else 1
+    if scale.numel() != batches * C or shift.shape != scale.shape or not scale.is_contiguous() or not shift.is_contiguous():
+        raise PleasHipError("bn_act_tracked: scale/shift must hold one entry per channel (and batch)")
+    if x.shape[0] % batches:
+        raise PleasHipError("bn_act_tracked: %d samples do not split into %d batches" % (x.shape[0], batches))
     # the last value of the chain goes to `y`; earlier ones to the optional outputs
     y_bn = torch.empty_like(x) if ((res is not None or relu) and keep_bn) else None
     y_sum = torch.empty_like(x) if (res is not None and relu) else None
     y = torch.empty_like(x)
-    rc = _lib.lib().pleas_bn_act_tracked(x.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                         res.data_ptr() if res is not None else None,
-                                         y_bn.data_ptr() if y_bn is not None else None,
-                                         y_sum.data_ptr() if y_sum is not None else None, y.data_ptr(), x.shape[0], C,
-                                         math.prod(x.shape[2:]), int(relu), _stream())
-    check(rc, "pleas_bn_act_tracked")
+    rc = _lib.lib().pleas_bn_act_tracked_batches(x.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                                 res.data_ptr() if res is not None else None,
+                                                 y_bn.data_ptr() if y_bn is not None else None,
+                                                 y_sum.data_ptr() if y_sum is not None else None, y.data_ptr(),
+                                                 x.shape[0] // batches, batches, C, math.prod(x.shape[2:]), int(relu), _stream())
+    check(rc, "pleas_bn_act_tracked_batches")
     if res is None:
         return (y_bn, None, y) if relu else (y, None, None)
     return (y_bn, y_sum, y) if relu else (y_bn, y, None)
@@ -398,9 +402,11 @@ class BnTrainFold:
         self.bn = bn
         self._shape = None
 
-    def _prepare(self, x: torch.Tensor) -> None:
+    def _prepare(self, x: torch.Tensor, batches: int) -> None:
         bn = self.bn
-        n, C = x.shape[0], x.shape[1]
+        if x.shape[0] % batches:
+            raise PleasHipError("bn_train_fold: %d samples do not split into %d batches" % (x.shape[0], batches))
+        n, C = x.shape[0] // batches, x.shape[1]
         inner = math.prod(x.shape[2:])
         if n * inner <= 1:
             raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(x.shape),))
@@ -408,30 +414,33 @@ class BnTrainFold:
         for t in (bn.weight, bn.bias, bn.running_mean if track else None, bn.running_var if track else None):
             if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.device != x.device):
                 raise PleasHipError("bn_train_fold: BatchNorm parameters / buffers must be contiguous fp32 on x's device")
-        need = int(_lib.lib().pleas_bn_train_ws_bytes(n, C))
+        need = batches * int(_lib.lib().pleas_bn_train_ws_bytes(n, C))
         self._ws = torch.empty(need // 8, dtype=torch.float64, device=x.device)
-        self._out = torch.empty(2, C, dtype=torch.float32, device=x.device)
+        self._out = torch.empty(2, batches, C, dtype=torch.float32, device=x.device)
         ptr = lambda t: t.data_ptr() if t is not None else None
         self._tensors = (bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked)   # identity check below
-        self._args = (n, C, inner, ptr(bn.weight), ptr(bn.bias), float(bn.eps),
+        self._args = (n, batches, C, inner, ptr(bn.weight), ptr(bn.bias), float(bn.eps),
                       ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
                       ptr(bn.num_batches_tracked) if (track and bn.num_batches_tracked is not None) else None,
                       self._out[0].data_ptr(), self._out[1].data_ptr(), self._ws.data_ptr(), need)
-        self._shape = (tuple(x.shape), x.device)
+        self._shape = (tuple(x.shape), x.device, batches)
 
-    def __call__(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    def __call__(self, x: torch.Tensor, batches: int = 1) -> Tuple[torch.Tensor, torch.Tensor]:
+        """``batches`` > 1: ``x`` is that many batches back to back along dim 0; each is folded on its own samples, in
+        order (running statistics and counter as after that many forwards); returns ``[batches, C]`` scale and shift."""
         if not x.is_cuda or x.dtype != torch.float32 or x.dim() < 2:
             raise PleasHipError("bn_train_fold needs an fp32 [N, C, ...] tensor on the GPU")
         x = x.contiguous()
         bn = self.bn
-        if self._shape != (tuple(x.shape), x.device) or any(a is not b for a, b in zip(
+        if self._shape != (tuple(x.shape), x.device, batches) or any(a is not b for a, b in zip(
                 self._tensors, (bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked))):
-            self._prepare(x)
-        n, C, inner, w, b, eps, rm, rv, nbt, o0, o1, ws, need = self._args
-        rc = _lib.lib().pleas_bn_train_fold(x.data_ptr(), n, C, inner, w, b, eps, -1.0 if bn.momentum is None else float(bn.momentum),
-                                            rm, rv, nbt, o0, o1, ws, need, _stream())
-        check(rc, "pleas_bn_train_fold")
-        return self._out[0], self._out[1]
+            self._prepare(x, batches)
+        n, nb, C, inner, w, b, eps, rm, rv, nbt, o0, o1, ws, need = self._args
+        rc = _lib.lib().pleas_bn_train_fold_batches(x.data_ptr(), n, nb, C, inner, w, b, eps,
+                                                    -1.0 if bn.momentum is None else float(bn.momentum), rm, rv, nbt, o0, o1,
+                                                    ws, need, _stream())
+        check(rc, "pleas_bn_train_fold_batches")
+        return (self._out[0, 0], self._out[1, 0]) if batches == 1 else (self._out[0], self._out[1])
 
 
 # ---------------------------------------------------------------------------------------- merge blocks

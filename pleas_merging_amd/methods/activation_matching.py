@@ -199,13 +199,14 @@ def _bn_chains(traced: _Trace, model1: nn.Module, model2: nn.Module):
     return at, absorbed
 
 
-def _train_fold(mod: nn.BatchNorm2d, side: int, name: str) -> Callable:
+def _train_fold(mod: nn.BatchNorm2d, side: int, name: str, streams=None) -> Callable:
     """Graph callable of a train-mode BatchNorm: ``x -> (scale, shift)`` of THIS batch (and the module's running
-    statistics move on, as in the module's own forward)."""
+    statistics move on, as in the module's own forward).  When the forward carries several batches back to back
+    (``streams.parts`` > 1) every batch is folded on its own samples, in order, by the same launch: ``[parts, C]`` maps."""
     folder = hip_ops.BnTrainFold(mod)     # workspace / output vectors / addresses looked up once per input shape
 
     def fold(x):
-        return folder(x)
+        return folder(x, getattr(streams, "parts", 1))
 
     fold.__name__ = fold.__qualname__ = "bn_train_fold_%d_%s" % (side, name)
     return fold
@@ -269,7 +270,7 @@ def _build_split_twin(model1: nn.Module, model2: nn.Module, axes: Iterable[Axis]
                         root.register_buffer(nm_, buf, persistent=False)
                     attrs = (_node(twin, "get_attr", names[0], (), "bn_scale"), _node(twin, "get_attr", names[1], (), "bn_shift"))
                 else:                       # train mode (the reference drivers' mode): this batch's statistics, one pass
-                    fold = _node(twin, "call_function", _train_fold(mod, side, bn.name), (env[side][bn.args[0]],), "bn_stats")
+                    fold = _node(twin, "call_function", _train_fold(mod, side, bn.name, streams), (env[side][bn.args[0]],), "bn_stats")
                     attrs = (_node(twin, "call_function", operator.getitem, (fold, 0), "bn_scale"),
                              _node(twin, "call_function", operator.getitem, (fold, 1), "bn_shift"))
                 fold_attrs[side][bn] = attrs
@@ -378,8 +379,10 @@ class _FusedSink:
         """Sink of an eval-mode BatchNorm node whose input ``source_name`` is tracked on the same axis: nothing is
         contracted, the group's reduce pass derives the node from the source's products, norms and row sums."""
         def sink(scale1, shift1, scale2, shift2, a, _name=node_name, _src=source_name):
-            for src in self.index[_src, a]:      # one derived node per batch of the forward, like its source
-                self.batch.add_derived(src, scale1, shift1, scale2, shift2, self.group_index[self.node_group[Axis(_name, a)]])
+            pick = lambda v, g: v[g] if v.dim() == 2 else v      # train mode: one affine map per batch of the forward
+            for g, src in enumerate(self.index[_src, a]):      # one derived node per batch of the forward, like its source
+                self.batch.add_derived(src, pick(scale1, g), pick(shift1, g), pick(scale2, g), pick(shift2, g),
+                                       self.group_index[self.node_group[Axis(_name, a)]])
             return None
 
         sink.__name__ = sink.__qualname__ = "gram_derived_sink_%s" % node_name
@@ -430,11 +433,16 @@ def _force_collectives() -> bool:
     return os.environ.get("PLEAS_FORCE_COLLECTIVES", "0") not in ("", "0") and _collectives_on()
 
 
-def _uses_batch_statistics(model: nn.Module) -> bool:
-    """Does any normalisation layer of ``model`` depend on which samples share its batch (BatchNorm in train mode or
-    without running statistics)?  Then batches must not be concatenated for a forward."""
-    return any(isinstance(m, nn.modules.batchnorm._BatchNorm) and (m.training or m.running_mean is None)
-               for m in model.modules())
+def _unfolded_batch_statistics(gm: nn.Module) -> bool:
+    """Does the twin graph still CALL a normalisation module that uses batch statistics?  The fused chains fold a
+    train-mode BatchNorm2d per batch (``pleas_bn_train_fold_batches``: exact on a concatenated forward); a module that is
+    called as it is would normalise the concatenated batch as one."""
+    for node in gm.graph.nodes:
+        if node.op == "call_module":
+            m = gm.get_submodule(node.target)
+            if isinstance(m, nn.modules.batchnorm._BatchNorm) and (m.training or m.running_mean is None):
+                return True
+    return False
 
 
 def _model_device(model: nn.Module) -> torch.device:
@@ -518,12 +526,15 @@ def accumulate_costs_fused(spec: PermutationSpec, model1: nn.Module, model2: nn.
     104 of ResNet-101's 344 tracked nodes, i.e. ~30 % of the contraction's flops, and the BatchNorm tensors are not
     written at all.
 
-    ``batches_per_forward`` (default 2): that many consecutive batches of equal shape go through the twin forward as ONE
+    ``batches_per_forward`` (default: forwards of up to 64 samples, at most 4 batches): that many consecutive batches of equal shape go through the twin forward as ONE
     forward of the concatenated batch -- the vendor convolutions run 10-25 % faster per sample at 32-128 samples than at
     16 -- while every tracked node is still contracted PER BATCH (sample slices of its activations; the distance epilogue
-    is per batch), all batches of the forward in one grouped launch.  Only when no BatchNorm of either model
-    normalises with batch statistics (train mode: the statistics of a concatenated batch are not the batches') and costs
-    are summed over batches; otherwise one batch per forward.
+    is per batch), all batches of the forward in one grouped launch.  Train-mode models (the reference drivers'
+    mode) take part: the fused chains fold a train-mode BatchNorm2d on every batch's own samples, in order, in ONE
+    launch (``pleas_bn_train_fold_batches``; statistics, running statistics and counter as after k separate forwards) and
+    apply each batch's map to its sample range (``pleas_bn_act_tracked_batches``).  One batch per forward remains when a
+    normalisation module with batch statistics is still CALLED by the twin graph (``fuse_bn=False``, or a module the
+    chains do not cover), and when costs are not summed over batches.
 
     ``presharded=True`` (data parallel): ``dataloader`` already yields THIS rank's batches only (a loader over a
     ``DistributedSampler``-style partition) and ``num_batches`` counts them; nothing is skipped here and the arena is still
@@ -543,14 +554,17 @@ def accumulate_costs_fused(spec: PermutationSpec, model1: nn.Module, model2: nn.
     caller = torch.cuda.current_stream(device)
     work = hip_ops.role_stream(device, "model1") if sinks.streams is not None else caller
     work.wait_stream(caller)
-    per_forward = 2 if batches_per_forward is None else max(1, int(batches_per_forward))
-    if accumulate is not True or sinks.batch is None or _uses_batch_statistics(model1) or _uses_batch_statistics(model2):
-        per_forward = 1
+    # default: forwards of up to 64 samples, at most 4 batches (the gain is the vendor convolutions' at small batches; the
+    # tracked activations of a forward stay alive until its contraction) -- fixed when the first batch shows its size
+    per_forward = None if batches_per_forward is None else max(1, int(batches_per_forward))
+    single = accumulate is not True or sinks.batch is None or _unfolded_batch_statistics(gm)
 
     def forward(xs):
         if accumulate is not True:
             arena.zero_()
         sinks.parts = len(xs)
+        if sinks.streams is not None:
+            sinks.streams.parts = len(xs)       # read by the train-mode BatchNorm folds of the twin graph
         x = xs[0] if len(xs) == 1 else torch.cat(xs, 0)
         try:
             gm(x)
@@ -560,6 +574,8 @@ def accumulate_costs_fused(spec: PermutationSpec, model1: nn.Module, model2: nn.
             raise
         finally:
             sinks.parts = 1
+            if sinks.streams is not None:
+                sinks.streams.parts = 1
         if sinks.batch is not None:
             sinks.batch.flush(accumulate=True)
 
@@ -567,6 +583,10 @@ def accumulate_costs_fused(spec: PermutationSpec, model1: nn.Module, model2: nn.
         run: List[torch.Tensor] = []
         for x, _ in shard_batches(dataloader, num_batches, *take):
             x = x.to(device, non_blocking=True)
+            if single:
+                per_forward = 1
+            elif per_forward is None:
+                per_forward = max(1, min(4, 64 // max(1, int(x.shape[0]))))
             if run and (x.shape != run[0].shape or len(run) == per_forward):
                 forward(run)
                 run = []

@@ -118,6 +118,9 @@ def main():
     expect(lib.pleas_bn_act_maxpool(ptr, None, None, ptr, 2, 4, 8, 8, 3, 3, 2, 2, 1, None) == -22, "bn_act_maxpool(pad > kernel / 2)")
     expect(lib.pleas_bn_act_maxpool(ptr, ptr, None, ptr, 2, 4, 8, 8, 3, 3, 2, 1, 1, None) == -22, "bn_act_maxpool(scale without shift)")
     expect(lib.pleas_bn_act_maxpool(ptr, None, None, ptr, 2, 4, 2, 2, 7, 7, 1, 1, 1, None) == -22, "bn_act_maxpool(window > input)")
+    expect(lib.pleas_bn_train_fold_batches(None, 4, 2, 8, 16, None, None, 1e-5, 0.1, None, None, None, None, None, None, 0, None) == -22,
+           "bn_train_fold_batches(NULL)")
+    expect(lib.pleas_bn_act_tracked_batches(ptr, ptr, ptr, None, None, None, ptr, 4, 0, 8, 16, 1, None) == -22, "bn_act_tracked_batches(0 batches)")
     expect(lib.pleas_masked_adam(None, None, None, None, None, 4, 1e-3, 0.9, 0.999, 1e-8, 1, None) == -22, "masked_adam(NULL)")
     # ---- host LAP: random, tie-heavy, all-equal, n = 1; fp32 and fp64; result must be a permutation of maximal value
     for n in (1, 2, 3, 17, 64, 129):

@@ -256,6 +256,43 @@ def test_bn_act_tracked_keeps_every_node_of_the_chain(ops, shape, with_res, relu
     assert torch.equal(ops.bn_act(x, scale, shift, res if with_res else None, relu), act if relu else last)
 
 
+@pytest.mark.parametrize("with_res,relu", [(True, True), (False, True), (False, False)])
+@pytest.mark.parametrize("momentum,shape", [(0.1, (12, 24, 6, 6)), (None, (6, 5, 3, 3)), (0.3, (9, 130, 7, 7))])
+def test_bn_fold_and_act_per_batch_of_a_concatenated_forward(ops, with_res, relu, momentum, shape):
+    """Three batches back to back in one tensor: ONE ``pleas_bn_train_fold_batches`` launch folds train-mode BatchNorm on
+    every batch's own samples, in order, and ONE ``pleas_bn_act_tracked_batches`` pass applies each batch's map to its
+    sample range -- equal to three separate train-mode forwards of the module chain (values, running statistics, counter;
+    momentum 0.1 / 0.3 and the cumulative average)."""
+    g = torch.Generator().manual_seed(35)
+    parts, C = 3, shape[1]
+    n = shape[0] // parts
+    x = (torch.randn(shape, generator=g) * 2 + 0.5).cuda()
+    res = torch.randn(shape, generator=g).cuda()
+    bn = torch.nn.BatchNorm2d(C, momentum=momentum).cuda().train()
+    bn.weight.data.uniform_(0.5, 1.5)
+    bn.bias.data.normal_()
+    ref = copy.deepcopy(bn)
+    scales, shifts = ops.BnTrainFold(bn)(x, parts)
+    assert tuple(scales.shape) == tuple(shifts.shape) == (parts, C)
+    outs = ops.bn_act_tracked(x, scales, shifts, res if with_res else None, relu)
+    want_bn = torch.cat([ref(x[i * n:(i + 1) * n]) for i in range(parts)])
+    assert torch.allclose(outs[0], want_bn, rtol=1e-4, atol=1e-5)
+    last = want_bn + res if with_res else want_bn
+    if with_res:
+        assert torch.allclose(outs[1], last, rtol=1e-4, atol=1e-5)
+    if relu:
+        assert torch.allclose(outs[2], torch.relu(last), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(bn.running_mean, ref.running_mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(bn.running_var, ref.running_var, rtol=1e-5, atol=1e-6)
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == parts
+    # one batch through the same entry points: the old single-map call
+    one = ops.BnTrainFold(copy.deepcopy(ref))(x[:n])
+    assert one[0].dim() == 1 and torch.allclose(ops.bn_act_tracked(x[:n], one[0], one[1], None, False)[0],
+                                               copy.deepcopy(ref)(x[:n]), rtol=1e-4, atol=1e-5)
+    with pytest.raises(ops.PleasHipError):
+        ops.bn_act_tracked(x[:-1], scales, shifts, None, relu)          # samples do not split into 3 batches
+
+
 def test_bn_act_rejects_bad_operands(ops):
     x = torch.randn(2, 4, 3, 3).cuda()
     s = torch.ones(4).cuda()

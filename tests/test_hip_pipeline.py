@@ -391,8 +391,10 @@ def test_matching_several_batches_per_forward_equals_one_by_one(tiny_bottleneck)
     """``batches_per_forward``: k batches go through the twin forward as ONE forward of the concatenated batch, every
     tracked node (and every derived BatchNorm node) is still contracted per batch -- the distance epilogue is per batch
     (reference activation_matching.py:31-46, :123-134).  Same costs as one forward per batch up to the vendor kernels'
-    rounding at another batch size, same assignments; 7 batches, so every group size leaves a smaller last forward.  Models
-    whose BatchNorm uses batch statistics are never concatenated: bit-identical to one forward per batch."""
+    rounding at another batch size, same assignments; 7 batches, so every group size leaves a smaller last forward.  Train
+    mode (the drivers' mode): the fused chains fold BatchNorm on every batch's own samples, so concatenation is exact there
+    too -- same costs, assignments, running statistics and counters as one forward per batch; with the vendor modules
+    (``fuse_bn=False``) train-mode batches are never concatenated: bit-identical."""
     from pleas_merging_amd import hip_ops
     from pleas_merging_amd.core.solvers import hip_solve_lsa
     from pleas_merging_amd.methods.activation_matching import accumulate_costs_fused, solve_all
@@ -412,13 +414,36 @@ def test_matching_several_batches_per_forward_equals_one_by_one(tiny_bottleneck)
             assert torch.equal(perm[k], want_perm[k]), (per, k)
     for m in (m1, m2):
         m.train()
+
+    def restart():          # a pass moves the running statistics (not used in train mode): same start for the next one
+        for m in (m1, m2):
+            m.load_state_dict({k: v.cuda() for k, v in (t.m1 if m is m1 else t.m2).state_dict().items()})
+
+    def stats():
+        return {"%d.%s" % (i, k): v.clone() for i, m in enumerate((m1, m2)) for k, v in m.state_dict().items()
+                if "running" in k or "num_batches" in k}
+
     a = accumulate_costs_fused(t.spec, m1, m2, data, 7, hip_ops.EPI_NEG_CDIST, batches_per_forward=1)
-    a = {k: v.clone() for k, v in a.items()}
-    for m in (m1, m2):          # the first pass moved the running statistics (not used in train mode) -- same start again
-        m.load_state_dict({k: v.cuda() for k, v in (t.m1 if m is m1 else t.m2).state_dict().items()})
-    b = accumulate_costs_fused(t.spec, m1, m2, data, 7, hip_ops.EPI_NEG_CDIST, batches_per_forward=4)
-    for k in t.spec:
-        assert torch.equal(a[k], b[k]), k
+    a, a_perm, a_stats = {k: v.clone() for k, v in a.items()}, solve_all(a, hip_solve_lsa), stats()
+    for per in (2, 4, None):
+        restart()
+        b = accumulate_costs_fused(t.spec, m1, m2, data, 7, hip_ops.EPI_NEG_CDIST, batches_per_forward=per)
+        b_perm = solve_all(b, hip_solve_lsa)
+        for k in t.spec:
+            assert _rel(b[k], a[k]) < 1e-5, (per, k, _rel(b[k], a[k]))
+            assert torch.equal(b_perm[k], a_perm[k]), (per, k)
+        for k, v in stats().items():
+            if "num_batches" in k:
+                assert int(v) == int(a_stats[k]) == 7, k
+            else:
+                assert torch.allclose(v, a_stats[k], rtol=1e-5, atol=1e-6), (per, k)
+    restart()
+    c = accumulate_costs_fused(t.spec, m1, m2, data, 7, hip_ops.EPI_NEG_CDIST, batches_per_forward=1, fuse_bn=False)
+    c = {k: v.clone() for k, v in c.items()}
+    restart()
+    d = accumulate_costs_fused(t.spec, m1, m2, data, 7, hip_ops.EPI_NEG_CDIST, batches_per_forward=4, fuse_bn=False)
+    for k in t.spec:        # vendor BatchNorm modules in train mode: one batch per forward whatever is asked
+        assert torch.equal(c[k], d[k]), k
 
 
 def test_fused_source_forwards_match_module_forwards(tiny_bottleneck):
