@@ -355,7 +355,7 @@ def time_bn_reset(m3, pool, n_batches=101):
     out = {}
     for name, fused in (("hip_s", True), ("vendor_modules_s", False)):
         model = copy.deepcopy(m3)
-        reset_bn_stats(model, loader[:3], 3, fused=fused)
+        reset_bn_stats(model, loader[:8], 8, fused=fused)      # two forwards of the timed size on the HIP path
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         reset_bn_stats(model, loader, n_batches, fused=fused)
@@ -363,7 +363,8 @@ def time_bn_reset(m3, pool, n_batches=101):
         out[name] = round(time.perf_counter() - t0, 3)
         del model
     out["note"] = ("BN-statistics reset of the merged model, %d batches of %d (not in `value`: the reference's `train` ends "
-                   "before it); hip = statistics folded per batch on the device + one bn_act pass per chain" % (n_batches, pool.items[0].shape[0]))
+                   "before it); hip = four batches per forward, statistics folded per batch on the device (one launch per "
+                   "BatchNorm and forward) + one bn_act pass per chain" % (n_batches, pool.items[0].shape[0]))
     return out
 
 

@@ -294,11 +294,21 @@ def bn_act(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, res: Optio
             raise PleasHipError("bn_act: residual shape/dtype differs from x")
         res = res.contiguous()
     C = x.shape[1]
-    if scale.numel() != C or shift.numel() != C or not scale.is_contiguous() or not shift.is_contiguous():
-        raise PleasHipError("bn_act: scale/shift must be contiguous with one entry per channel")
+    # scale / shift [batches][C]: x holds that many batches back to back along dim 0, each with its own affine map
+    batches = scale.shape[0] if scale.dim() == 2 else 1
+    if scale.numel() != batches * C or shift.shape != scale.shape or not scale.is_contiguous() or not shift.is_contiguous():
+        raise PleasHipError("bn_act: scale/shift must be contiguous with one entry per channel (and batch)")
+    if x.shape[0] % batches:
+        raise PleasHipError("bn_act: %d samples do not split into %d batches" % (x.shape[0], batches))
     y = torch.empty_like(x)
-    rc = _lib.lib().pleas_bn_act(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), res.data_ptr() if res is not None else None,
-                                 y.data_ptr(), x.shape[0], C, math.prod(x.shape[2:]), int(relu), _stream())
+    ptr = res.data_ptr() if res is not None else None
+    if batches == 1:
+        rc = _lib.lib().pleas_bn_act(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), ptr, y.data_ptr(), x.shape[0], C,
+                                     math.prod(x.shape[2:]), int(relu), _stream())
+    else:      # the tracked pass without its optional outputs is this pass
+        rc = _lib.lib().pleas_bn_act_tracked_batches(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), ptr, None, None,
+                                                     y.data_ptr(), x.shape[0] // batches, batches, C,
+                                                     math.prod(x.shape[2:]), int(relu), _stream())
     _lib.check(rc, "pleas_bn_act")
     return y
 

@@ -34,7 +34,18 @@ def _bn_act(x, scale, shift, res, relu):
 
 
 def _bn_act_pool(x, scale, shift, kernel, stride, padding, relu):
+    if scale is not None and scale.dim() == 2 and scale.shape[0] > 1:
+        # several batches with their own maps in one forward (BN-statistics reset): the pooled pass takes one map
+        return F.max_pool2d(hip_ops.bn_act(x, scale, shift, None, relu), kernel, stride, padding)
+    if scale is not None and scale.dim() == 2:
+        scale, shift = scale[0], shift[0]
     return hip_ops.bn_act_maxpool(x, scale, shift, kernel, stride, padding, relu)
+
+
+class BatchesPerForward:
+    """How many batches lie back to back in the tensor a rewritten graph is forwarding right now (read by its train-mode
+    BatchNorm folds); the caller sets ``parts`` around the call."""
+    parts = 1
 
 
 def _pair(v):
@@ -100,13 +111,15 @@ def fold_bn(bn: nn.BatchNorm2d):
     return scale64.float().contiguous(), shift64.float().contiguous()
 
 
-def _train_fold(bn: nn.BatchNorm2d, tag: str) -> Callable:
+def _train_fold(bn: nn.BatchNorm2d, tag: str, state: Optional[BatchesPerForward] = None) -> Callable:
     """Graph callable of a train-mode BatchNorm: ``x -> (scale, shift)`` of THIS batch; the module's running statistics
-    and batch counter move on exactly as in the module's own forward (``hip_ops.bn_train_fold``: one streaming pass)."""
+    and batch counter move on exactly as in the module's own forward (``hip_ops.bn_train_fold``: one streaming pass).
+    ``state.parts`` > 1: the tensor holds that many batches back to back, each folded on its own samples, in order, by
+    the same launch (``[parts, C]`` maps)."""
     folder = hip_ops.BnTrainFold(bn)      # workspace / output vectors / addresses looked up once per input shape
 
     def fold(x):
-        return folder(x)
+        return folder(x, state.parts if state is not None else 1)
 
     fold.__name__ = fold.__qualname__ = "bn_train_fold_%s" % tag
     return fold
@@ -134,6 +147,7 @@ def fuse_bn_act(model: nn.Module, op: Callable = _bn_act, train_stats: bool = Fa
         return None
     mods = dict(model.named_modules())
     constants = {}                                    # get_attr targets of the folded scale / shift vectors
+    state = BatchesPerForward()                       # train_stats: batches per forwarded tensor, set by the caller
     folded = 0
     for node in list(graph.nodes):
         if node.op != "call_module" or len(node.args) != 1 or node.kwargs:
@@ -170,7 +184,7 @@ def fuse_bn_act(model: nn.Module, op: Callable = _bn_act, train_stats: bool = Fa
         with graph.inserting_before(last):
             # explicit base names: fx would otherwise derive them from the targets character by character
             if per_batch:
-                stats = graph.create_node("call_function", _train_fold(bn, tag), (node.args[0],), {}, name="bn_stats")
+                stats = graph.create_node("call_function", _train_fold(bn, tag, state), (node.args[0],), {}, name="bn_stats")
                 s = graph.create_node("call_function", operator.getitem, (stats, 0), {}, name="bn_scale")
                 t = graph.create_node("call_function", operator.getitem, (stats, 1), {}, name="bn_shift")
             else:
@@ -200,4 +214,9 @@ def fuse_bn_act(model: nn.Module, op: Callable = _bn_act, train_stats: bool = Fa
             root[node.target] = obj
     gm = torch.fx.GraphModule(root, graph, class_name=type(model).__name__)
     gm.train(model.training)
+    gm.batches_per_forward = state      # reset_bn_stats: `gm.batches_per_forward.parts = k` around a k-batch forward
+    # does every normalisation layer with batch statistics go through a per-batch fold?  (only then may batches share a forward)
+    gm.all_batch_statistics_folded = not any(
+        n.op == "call_module" and isinstance(mods.get(n.target), nn.modules.batchnorm._BatchNorm)
+        and (mods[n.target].training or mods[n.target].running_mean is None) for n in graph.nodes)
     return gm

@@ -64,10 +64,11 @@ def test_bn_reset_on_the_merged_cuda_model_equals_the_drivers_loop(tiny_basic):
     assert checked >= 10
 
 
-@pytest.mark.parametrize("fused", [True, False])
-def test_bn_reset_rn50_size_vs_the_drivers_loop(fused):
+@pytest.mark.parametrize("fused,per_forward", [(True, None), (True, 1), (True, 3), (False, None)])
+def test_bn_reset_rn50_size_vs_the_drivers_loop(fused, per_forward):
     """The same pass at ResNet-50 size (53 BatchNorm2d, merged widths 1.5x, 224 x 224): HIP BatchNorm path
-    (``pleas_bn_train_fold`` + ``pleas_bn_act`` through the fx rewrite) and vendor modules, each against the drivers'
+    (``pleas_bn_train_fold_batches`` + ``pleas_bn_act`` through the fx rewrite; batches sharing a forward or not) and
+    vendor modules, each against the drivers'
     loop (run_domainnet.py:327-341) on the CPU: running statistics, batch counters, train mode left on."""
     from pleas.core.compiler import get_permutation_spec
     from pleas.core.utils import make_identity_perm
@@ -87,7 +88,9 @@ def test_bn_reset_rn50_size_vs_the_drivers_loop(fused):
     costs = {k: torch.eye(grp.size) + 0.01 * torch.rand(grp.size, grp.size, generator=g) for k, grp in spec.items()}
     ref = orc.partial_merge(spec, models[0], models[1], perm, costs, 0.5)
     got = copy.deepcopy(ref).cuda()
-    got = reset_bn_stats(got, data, 4, fused=fused)
+    # HIP path: by default the four batches (of 4 samples) share ONE forward, every BatchNorm folding each batch on its own
+    # samples in order; 3 per forward leaves a forward of one; 1 is the drivers' one forward per batch
+    got = reset_bn_stats(got, data, 4, fused=fused, batches_per_forward=per_forward)
     assert got.training and next(got.parameters()).is_cuda
     ref.train()
     n_bn = 0
