@@ -74,7 +74,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_stats_partial_kernel(const floa
     }
 }
 
-__global__ __launch_bounds__(1024) void bn_train_finalize_kernel(const double* __restrict__ part, int S, int channels,
+__global__ __launch_bounds__(1024) void bn_train_finalize_kernel(double* __restrict__ part, int S, int channels,
                                                                  int batches, double count,
                                                                  const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, double eps,
@@ -82,36 +82,46 @@ __global__ __launch_bounds__(1024) void bn_train_finalize_kernel(const double* _
                                                                  float* __restrict__ running_var,
                                                                  int64_t* __restrict__ num_batches_tracked,
                                                                  float* __restrict__ scale, float* __restrict__ shift) {
-    // exponential factor as torch.nn.BatchNorm2d.forward: `momentum`, or 1 / (batches seen including this one).  Several
-    // batches are folded IN ORDER: scale / shift [batch][channel], the running statistics move on batch by batch.
+    // (1) every (batch, channel) pair on its own thread: combine the S partials in a fixed order, write scale / shift
+    //     [batch][channel], leave (mean, unbiased variance) in the workspace's tail [batch][channel][2];
+    // (2) per channel, the batches IN ORDER: the running statistics move on as after that many forwards of the module --
+    //     exponential factor as torch.nn.BatchNorm2d.forward: `momentum`, or 1 / (batches seen including this one).
+    double* moments = part + (int64_t)batches * S * channels * 2;
     const int64_t seen = (momentum < 0.0 && num_batches_tracked) ? *num_batches_tracked : 0;
-    for (int c = threadIdx.x; c < channels; c += blockDim.x) {
-        double rm = running_mean ? (double)running_mean[c] : 0.0, rv = running_var ? (double)running_var[c] : 0.0;
-        for (int bt = 0; bt < batches; ++bt) {
-            const double* pb = part + (int64_t)bt * S * channels * 2;
-            double factor = momentum;
-            if (momentum < 0.0) factor = num_batches_tracked ? 1.0 / (double)(seen + bt + 1) : 0.0;
-            double a = 0.0, b = 0.0;
-            for (int s = 0; s < S; ++s) {
-                a += pb[((int64_t)s * channels + c) * 2 + 0];
-                b += pb[((int64_t)s * channels + c) * 2 + 1];
-            }
-            const double mean = a / count;
-            double var = b / count - mean * mean;
-            var = var > 0.0 ? var : 0.0;
-            const double g = gamma ? (double)gamma[c] : 1.0;
-            const double sc = g / sqrt(var + eps);
-            scale[(int64_t)bt * channels + c] = (float)sc;
-            shift[(int64_t)bt * channels + c] = (float)((beta ? (double)beta[c] : 0.0) - mean * sc);
-            // the module stores fp32 after every forward: round like it does, batch by batch
-            rm = (double)(float)((1.0 - factor) * rm + factor * mean);
-            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-            rv = (double)(float)((1.0 - factor) * rv + factor * unbiased);
+    for (int idx = threadIdx.x; idx < batches * channels; idx += blockDim.x) {
+        const int bt = idx / channels, c = idx - bt * channels;
+        const double* pb = part + (int64_t)bt * S * channels * 2;
+        double a = 0.0, b = 0.0;
+        for (int s = 0; s < S; ++s) {
+            a += pb[((int64_t)s * channels + c) * 2 + 0];
+            b += pb[((int64_t)s * channels + c) * 2 + 1];
         }
-        if (running_mean) running_mean[c] = (float)rm;
-        if (running_var) running_var[c] = (float)rv;
+        const double mean = a / count;
+        double var = b / count - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const double g = gamma ? (double)gamma[c] : 1.0;
+        const double sc = g / sqrt(var + eps);
+        scale[idx] = (float)sc;
+        shift[idx] = (float)((beta ? (double)beta[c] : 0.0) - mean * sc);
+        moments[(int64_t)idx * 2 + 0] = mean;
+        moments[(int64_t)idx * 2 + 1] = count > 1.0 ? var * count / (count - 1.0) : var;
     }
-    __syncthreads();   // every thread has read the old count
+    __syncthreads();   // one workgroup: the moments are visible, and every thread has read the old count
+    if (running_mean && running_var) {
+        for (int c = threadIdx.x; c < channels; c += blockDim.x) {
+            double rm = (double)running_mean[c], rv = (double)running_var[c];
+            for (int bt = 0; bt < batches; ++bt) {
+                double factor = momentum;
+                if (momentum < 0.0) factor = num_batches_tracked ? 1.0 / (double)(seen + bt + 1) : 0.0;
+                const double* m = moments + ((int64_t)bt * channels + c) * 2;
+                // the module stores fp32 after every forward: round like it does, batch by batch
+                rm = (double)(float)((1.0 - factor) * rm + factor * m[0]);
+                rv = (double)(float)((1.0 - factor) * rv + factor * m[1]);
+            }
+            running_mean[c] = (float)rm;
+            running_var[c] = (float)rv;
+        }
+    }
     if (threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += batches;
 }
 
@@ -127,7 +137,7 @@ using namespace pleas;
 
 extern "C" size_t pleas_bn_train_ws_bytes(int64_t n, int channels) {
     if (n <= 0 || channels <= 0) return 0;
-    return (size_t)bn_splits(n, channels) * channels * 2 * sizeof(double);
+    return (size_t)(bn_splits(n, channels) + 1) * channels * 2 * sizeof(double);      // S partial slabs + the moments
 }
 
 extern "C" int pleas_bn_train_fold_batches(const float* x, int64_t n, int batches, int channels, int64_t inner,
@@ -147,7 +157,7 @@ extern "C" int pleas_bn_train_fold_batches(const float* x, int64_t n, int batche
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(channels, S, batches), dim3(kBnThreads), 0, stream, x, (int)n, channels,
                        inner, vec, (double*)ws);
     PLEAS_LAUNCH_CHECK("bn_stats_partial_kernel");
-    hipLaunchKernelGGL(bn_train_finalize_kernel, dim3(1), dim3(1024), 0, stream, (const double*)ws, S, channels, batches,
+    hipLaunchKernelGGL(bn_train_finalize_kernel, dim3(1), dim3(1024), 0, stream, (double*)ws, S, channels, batches,
                        (double)n * (double)inner, gamma, beta, eps, momentum, running_mean, running_var,
                        num_batches_tracked, scale, shift);
     PLEAS_LAUNCH_CHECK("bn_train_finalize_kernel");
