@@ -1,0 +1,153 @@
+"""The configuration ``bench.py`` TIMES, under the oracle at full size (missing 1).
+
+ResNet-101 pair, batch 16 x 3 x 224 x 224, the bench's knobs: ten matching batches through ONE twin forward
+(``batches_per_forward=10``, 160 samples) -> batched LAP with the frozen sources' first group prefetched from
+``while_solving`` (``FrozenSources.prefetch``, exactly ``bench.run_job``) -> full merge -> eight PLeaS updates whose
+batches go through the sources as ONE forward (``sources_per_forward=8``, 128 samples), cosine schedule of the 401-update
+job.  Compared with ``oracle/pleas_oracle.py`` on the same batches (reference: activation_matching.py:119-134,
+pleas_merging.py:265-291, :367-375): group costs, assignments (near-tie rule of test_hip_fullsize._check_matching),
+merged state dict bit-equal, trained tensors by the gate of test_hip_fullsize._merge_and_train.
+"""
+import copy
+import json
+import os
+
+import pytest
+import torch
+
+from conftest import REPO, _usable_cores
+from oracle import pleas_oracle as orc
+from stem_gate import gate_stem, stem_objective
+import test_hip_fullsize as fs
+
+pytestmark = pytest.mark.gpu
+
+BATCH, N_MATCH, N_UPDATES = 16, 10, 8
+T_MAX = 400                      # CosineAnnealingLR(T_max=MAX_STEPS) of the 401-update job (pleas_merging.py:358)
+
+
+class _Want:
+    pass
+
+
+def test_rn101_timed_configuration_vs_oracle():
+    from pleas.methods.activation_matching import activation_matching
+    from pleas.methods.partial_matching import partial_merge
+    from pleas_merging_amd import resnet as zoo
+    from pleas_merging_amd.core.compiler import get_permutation_spec
+    from pleas_merging_amd.methods.pleas_merging import FrozenSources, PleasFitter
+
+    threads = torch.get_num_threads()
+    torch.set_num_threads(max(threads, min(16, _usable_cores())))
+    try:
+        # batch b = N(0, 1) seeded 1000 + b; matching takes batches 0..9, PLeaS batches 0..7
+        data = [(torch.randn(BATCH, 3, 224, 224, generator=torch.Generator().manual_seed(1000 + b)), None)
+                for b in range(N_MATCH)]
+        models = []
+        for seed in (0, 1):
+            torch.manual_seed(seed)
+            m = zoo.MODELS["resnet101"](num_classes=1000)
+            zoo.calibrate_bn(m, [torch.randn(BATCH, 3, 224, 224, generator=torch.Generator().manual_seed(900 + i))
+                                 for i in range(2)])
+            models.append(m.eval())
+        m1, m2 = models
+        spec = get_permutation_spec(m1, ((1, 3, 224, 224),))
+        g1, g2 = copy.deepcopy(m1).cuda(), copy.deepcopy(m2).cuda()
+        gdata = [(x.cuda(), None) for x, _ in data]
+        inputs = [x for x, _ in gdata[:N_UPDATES]]
+
+        # ---- HIP path, as bench.run_job drives it
+        early = {}
+
+        def while_solving():
+            early["sources"] = src = FrozenSources(g1, g2)
+            early["taken"] = src.prefetch(inputs, group=8, max_groups=2, memory_fraction=0.7)
+
+        perm, costs = activation_matching(spec, g1, g2, gdata, N_MATCH, output_costs=True, while_solving=while_solving,
+                                          batches_per_forward=10)
+        assert early["taken"] == 8, early["taken"]         # one 128-sample group was forwarded beside the LAP kernel
+
+        # ---- oracle: matching on the same ten batches
+        w = _Want()
+        w.spec = spec
+        w.want_perm, w.want_costs = orc.activation_matching(spec, m1, m2, data, N_MATCH, accumulate=True)
+        flips = fs._check_matching(w, perm, costs)
+        worst_cost = max(fs._rel(costs[k], w.want_costs[k]) for k in spec)
+        print("timed configuration, matching: worst group cost rel-fro %.2e, flipped groups %r" % (worst_cost, flips))
+
+        # ---- merge + 8 updates from the ORACLE's assignment (both sides merge the same blocks); the prefetched sources
+        # do not depend on it
+        gcosts = {k: v.cuda() for k, v in w.want_costs.items()}
+        m3 = partial_merge(spec, g1, g2, w.want_perm, gcosts, 0.0, device=torch.device("cuda"))
+        o3 = orc.partial_merge(spec, m1, m2, w.want_perm, w.want_costs, 0.0)
+        merged = {k: v.clone() for k, v in o3.state_dict().items()}
+        for k, v in m3.state_dict().items():
+            if v.dtype.is_floating_point:
+                assert torch.equal(v.cpu(), merged[k]), k
+        fit = PleasFitter(g1, g2, m3, spec, w.want_perm, gcosts, 0.0, T_MAX, sources=early["sources"])
+        n = 0
+        for _ in fit.steps(inputs, sources_per_forward=8):
+            n += 1
+        assert n == N_UPDATES and fit.fast_updates == N_UPDATES - 1
+        got = {k: v.cpu() for k, v in fit.finish().state_dict().items()}
+
+        o3, losses = orc.train(data[:N_UPDATES], m1, m2, o3, spec, w.want_perm, w.want_costs, 0.0, T_MAX)
+        assert len(losses) == N_UPDATES
+        want = {k: v.clone() for k, v in o3.state_dict().items()}
+        with torch.backends.mkldnn.flags(enabled=False):      # the oracle against itself: the yardstick at this depth
+            v3 = orc.partial_merge(spec, m1, m2, w.want_perm, w.want_costs, 0.0)
+            v3, _ = orc.train(data[:N_UPDATES], m1, m2, v3, spec, w.want_perm, w.want_costs, 0.0, T_MAX)
+        variant = v3.state_dict()
+    finally:
+        torch.set_num_threads(threads)
+
+    # ---- the gate.  A tensor's yardstick is ONE draw of "two correct implementations apart" (the oracle with oneDNN
+    # convolutions on / off), and so is the HIP path's distance -- whose 128-sample source forwards run the vendor's WINOGRAD
+    # 3 x 3 kernels.  Measured on the MI355X (profiles/r04_timed_config_parity*.json): with them, one tensor of 521
+    # (layer3.8.conv2.weight) sits at 5.7e-4 = 7 x its own yardstick and 0.34 % of its coordinates took the opposite first
+    # Adam step; with MIOPEN_DEBUG_CONV_WINOGRAD=0 (the vendor's direct kernels) no tensor is above 3 x its yardstick and the
+    # worst share is 0.14 % -- below the oracle's own 0.21 %.  The spread is the vendor's convolution arithmetic, not the
+    # update's kernels (those are held to fp64 on identical taps in test_hip_fullsize.py).  So, as for the long horizon
+    # (tests/test_hip_long_horizon.py): at most one tensor per 150 above 3 x its own yardstick, none above 3 x the model's
+    # LARGEST yardstick; the share of coordinates with a visibly different Adam step within 3 x the oracle's worst share;
+    # all other coordinates together within max(1e-4, 2 x the oracle's worst).
+    rows = {}
+    for k in want:
+        if k == fs.DEGENERATE or not want[k].dtype.is_floating_point:
+            continue
+        if torch.equal(want[k], merged[k]):       # not trained (BatchNorm): must simply still be the merged tensor
+            assert torch.equal(got[k], merged[k]), k
+            continue
+        r, yard = fs._rel(got[k], want[k]), fs._rel(variant[k], want[k])
+        stats = []
+        for other in (got[k], variant[k]):
+            d = (other.double() - want[k].double()).abs()
+            affected = d > fs.LR / 10
+            stats.append((float(affected.double().mean()), float((d * ~affected).norm() / (want[k].double().norm() + 1e-30))))
+        rows[k] = (r, yard) + stats[0] + stats[1]
+    worst = max(rows, key=lambda k: rows[k][0])
+    yard_max = max(v[1] for v in rows.values())
+    over = {k: v[:2] for k, v in rows.items() if v[0] > max(fs.TOL, 3 * v[1])}
+    above = {k: v[:2] for k, v in rows.items() if v[0] > fs.TOL}
+    summary = {"batch": BATCH, "matching_batches_per_forward": N_MATCH, "sources_per_forward": N_UPDATES, "updates": N_UPDATES,
+               "worst_group_cost_rel_fro": worst_cost, "flipped_groups": {k: list(v) for k, v in flips.items()},
+               "tensors": len(rows), "worst_tensor": worst, "worst_rel_fro": rows[worst][0],
+               "oracle_self_spread_of_that_tensor": rows[worst][1], "oracle_self_spread_worst": yard_max,
+               "tensors_above_1e-4": len(above), "tensors_above_3x_own_yardstick": {k: list(v) for k, v in over.items()},
+               "worst_share_of_flipped_adam_steps": max(v[2] for v in rows.values()),
+               "oracle_worst_share_of_flipped_adam_steps": max(v[4] for v in rows.values()),
+               "worst_rest_rel_fro": max(v[3] for v in rows.values()),
+               "oracle_worst_rest_rel_fro": max(v[5] for v in rows.values()),
+               "vendor_winograd": os.environ.get("MIOPEN_DEBUG_CONV_WINOGRAD", "1") != "0"}
+    print("timed configuration, %d updates: %s" % (N_UPDATES, json.dumps(summary, indent=1)))
+    out_dir = os.path.join(REPO, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "r04_timed_config_parity.json"), "w") as f:
+            json.dump(summary, f, indent=1)
+    assert len(over) <= max(1, len(rows) // 150), over
+    assert all(r <= max(fs.TOL, 3 * yard_max) for r, _ in over.values()), (over, yard_max)
+    share_max, rest_max = max(v[4] for v in rows.values()), max(v[5] for v in rows.values())
+    for k, (r, yard, frac, rest, yfrac, yrest) in rows.items():
+        assert frac <= max(3 * share_max, fs.SHARE) and rest <= max(fs.TOL, 2 * rest_max), (k, rows[k], share_max, rest_max)
+    gate_stem(got[fs.DEGENERATE], merged[fs.DEGENERATE], [want[fs.DEGENERATE], variant[fs.DEGENERATE]],
+              lambda t: stem_objective(m1, m2, t, spec, w.want_perm, w.want_costs, 0.0, data[:N_UPDATES], 1000), what="stem")
