@@ -20,11 +20,13 @@ arena, so every rank applies the identical update.
 Besides the contract's keys the JSON line carries
   roofline      the own kernel with the most time in the timed jobs: algorithmic flop per launch / HIP-event time of
                 its launches inside the timed region, against the 157.3 TFLOP/s fp32 matrix peak (+ roofline_other);
-  cpu_baseline  the CPU oracle (restatement of the reference) on this box's host cores, bounded sample, N = 1 only;
+  cpu_baseline  the CPU oracle (restatement of the reference) on this box's host cores, on the job's own first batches
+                at the job's batch size (bounded count), N = 1 only; the same sample gives checks.parity_vs_oracle;
   phases_s      one more (untimed, synchronised) job split into spec / matching / LAP / merge + set-up / updates;
   alt_solver    the closed-form PLeaS phase (solver="normal_eq": MFMA normal equations + batched Cholesky), N = 1;
   vendor        the frozen source forwards of the PLeaS phase (vendor convolutions + pleas_bn_act) timed alone;
-  checks        invariants of the last timed job's result (permutations valid, losses fell, weights finite).
+  checks        invariants of the last timed job's result (permutations valid, losses fell, weights finite) and
+                parity_vs_oracle: the HIP job with the timed knobs against the oracle on the same batches (exit 3 on failure).
 """
 import argparse
 import gc
@@ -82,7 +84,10 @@ def parse(argv=None):
                     "one GPU, 1 under data parallelism (fills the all-reduce gaps)")
     ap.add_argument("--profile-all", action="store_true", help="also bracket the many-launch elementwise kernel "
                     "(bn_act) with events: complete kernels_ms, slightly slower timed region")
-    ap.add_argument("--cpu-sample-batch", type=int, default=8)
+    ap.add_argument("--cpu-match-batches", type=int, default=10, help="cpu_baseline / parity sample: matching batches of the "
+                    "job's own (default 10 = one twin forward of the timed size)")
+    ap.add_argument("--cpu-updates", type=int, default=8, help="cpu_baseline / parity sample: PLeaS updates on the job's own "
+                    "first batches (default 8 = one source forward of the timed size)")
     ap.add_argument("--gc", default="lap", choices=("lap", "auto"),
                     help="lap (default): Python's cyclic garbage collector is switched off while a job runs and called once "
                          "per job where the host has nothing to do -- while the batched LAP kernel runs; auto: the "
@@ -192,9 +197,11 @@ class Phases:
         self.t = now
 
 
-def run_job(cfg, spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, phases=None):
+def run_job(cfg, spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, phases=None, after_matching=None):
     """The timed hot path: activation matching (+ LAP) -> partial merge -> PLeaS updates.  Returns a dict with the merged
-    model, the permutation, the costs and the per-layer losses of the first and last update (device tensors)."""
+    model, the permutation, the costs and the per-layer losses of the first and last update (device tensors).
+    ``after_matching(perm, costs) -> (perm, costs)`` (parity leg only, never in a timed job): lets the checker look at the
+    job's assignment and hand back the one the merge and the updates shall continue from."""
     from pleas_merging_amd.core.solvers import hip_solve_lsa
     from pleas_merging_amd import hip_ops
     from pleas_merging_amd.methods.activation_matching import accumulate_costs_fused, activation_matching, solve_all
@@ -227,6 +234,9 @@ def run_job(cfg, spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, phases
     else:
         perm, costs = activation_matching(spec, m1, m2, match_loader, len(match_loader), output_costs=True,
                                           while_solving=while_solving, batches_per_forward=cfg["match_per_forward"])
+    hip_perm, hip_costs = perm, costs
+    if after_matching is not None:
+        perm, costs = after_matching(perm, costs)
     m3 = partial_merge(spec, m1, m2, perm, costs, cfg["ratio"], device=next(m1.parameters()).device)   # stays on the GPU
     # Data parallel: each rank's share of an update is small (batch / world samples); the frozen sources therefore forward
     # 2 * world updates' samples at once (steps() default), which keeps their host dispatch off the per-update path.
@@ -243,7 +253,8 @@ def run_job(cfg, spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, phases
     phases.mark("finish")
     if cfg.get("gc") == "lap":
         gc.enable()
-    return {"m3": m3, "perm": perm, "costs": costs, "first_loss": first, "last_loss": last, "layers": len(fit.plans)}
+    return {"m3": m3, "perm": perm, "costs": costs, "first_loss": first, "last_loss": last, "layers": len(fit.plans),
+            "hip_perm": hip_perm, "hip_costs": hip_costs}
 
 
 def check_result(spec, res, full=True):
@@ -368,48 +379,102 @@ def time_bn_reset(m3, pool, n_batches=101):
     return out
 
 
-def cpu_baseline(spec, arch, batch_full, sample_batch, n_match, n_pleas, ratio):
-    """Oracle (CPU restatement of the reference path) on this box's host cores, bounded sample:
-    3 matching batches + 3 PLeaS updates at a reduced batch size (~10-15 s of CPU work), all LAPs, the merge; extrapolated linearly
-    in samples to the job that the GPU ran."""
+def cpu_baseline_and_parity(cfg, spec, m1, m2, pool, n_match, n_pleas, n_sched, sample_match, sample_updates):
+    """The CPU oracle (restatement of the reference path) on this box's host cores, on the job's OWN first batches at the
+    job's batch size -- ``sample_match`` matching batches and ``sample_updates`` PLeaS updates, i.e. the count is
+    subsampled, not the batch -- and, on exactly those batches, the HIP job with the timed knobs (same batches per twin
+    forward, same updates per source forward, prefetch during the LAP) compared with it:
+      * worst group-cost rel-fro, assignments equal k / groups (a differing group must be a near tie: the HIP assignment
+        is what the oracle's LAP returns on the HIP costs and its value under the ORACLE's costs is within 1e-6);
+      * merged state dict bit-equal; trained tensors after the sample's updates (both sides continue from the ORACLE's
+        assignment) against the oracle, with the oracle's own oneDNN-on / off disagreement as the yardstick
+        (tests/test_hip_timed_config.py is the same comparison as a test).
+    Returns (cpu_baseline, parity)."""
+    import copy
+
     from oracle import pleas_oracle as orc
-    from pleas_merging_amd import resnet as zoo
 
     cores = usable_cores()
     torch.set_num_threads(cores)
-    log("cpu baseline on %d cores" % cores)
-    models = []
-    for seed in (0, 1):
-        torch.manual_seed(seed)
-        m = zoo.MODELS[arch](num_classes=1000)
-        g = torch.Generator().manual_seed(900)
-        zoo.calibrate_bn(m, [torch.randn(sample_batch, 3, 224, 224, generator=g)])
-        models.append(m)
-    m1, m2 = models
-    g = torch.Generator().manual_seed(1000)
-    data = [(torch.randn(sample_batch, 3, 224, 224, generator=g), None) for _ in range(6)]
+    nM, nU = min(n_match, sample_match), min(n_pleas, sample_updates)
+    log("cpu baseline + parity on %d cores: %d matching batches + %d updates of the job's own batches" % (cores, nM, nU))
+    c1, c2 = copy.deepcopy(m1).cpu(), copy.deepcopy(m2).cpu()
+    data = [(x.cpu(), None) for x, _ in pool.loader(0, max(nM, nU))]
+    ratio = cfg["ratio"]
+    seen = {}
+
+    def after_matching(perm, costs):
+        t0 = time.time()
+        want_costs = orc.matching_costs(spec, c1, c2, data[:nM], nM, accumulate=True)
+        seen["t_match"] = (time.time() - t0) / nM
+        t0 = time.time()
+        want_perm = {k: orc.solve_lsa(v) for k, v in want_costs.items()}
+        seen["t_lap"] = time.time() - t0
+        log("cpu: matching batch %.1fs, all LAPs %.2fs" % (seen["t_match"], seen["t_lap"]))
+        seen["want_perm"], seen["want_costs"] = want_perm, want_costs
+        return want_perm, {k: v.to(costs[k].device) for k, v in want_costs.items()}
+
+    res = run_job(cfg, spec, m1, m2, pool.loader(0, nM), pool.loader(0, nU), n_sched, after_matching=after_matching)
+    torch.cuda.synchronize()
+    want_perm, want_costs = seen["want_perm"], seen["want_costs"]
+    rel = lambda a, b: float((a.double().cpu() - b.double().cpu()).norm() / (b.double().norm() + 1e-30))
+    value = lambda cost, perm: float(cost.double().cpu()[torch.arange(len(perm)), perm].sum())
+    worst_cost = max(rel(res["hip_costs"][k], want_costs[k]) for k in spec)
+    equal, near_ties, bad_groups = 0, {}, []
+    for k in spec:
+        if (res["hip_perm"][k] == want_perm[k]).all():
+            equal += 1
+            continue
+        same_lap = bool((orc.solve_lsa(res["hip_costs"][k].cpu()) == res["hip_perm"][k]).all())
+        best, mine = value(want_costs[k], want_perm[k]), value(want_costs[k], res["hip_perm"][k])
+        gap = (best - mine) / abs(best)
+        near_ties[str(k)] = [int((res["hip_perm"][k] != want_perm[k]).sum()), gap]
+        if not (same_lap and 0 <= gap < 1e-6):
+            bad_groups.append(str(k))
+    # ---- merge + updates on the CPU, from the same assignment
     t0 = time.time()
-    costs = orc.matching_costs(spec, m1, m2, data[:3], 3, accumulate=True)
-    t_match = (time.time() - t0) / 3
-    log("cpu: matching batch %.1fs" % t_match)
-    t0 = time.time()
-    perm = {k: orc.solve_lsa(v) for k, v in costs.items()}
-    t_lap = time.time() - t0
-    t0 = time.time()
-    m3 = orc.partial_merge(spec, m1, m2, perm, costs, ratio)
+    o3 = orc.partial_merge(spec, c1, c2, want_perm, want_costs, ratio)
     t_merge = time.time() - t0
+    merged = {k: v.clone() for k, v in o3.state_dict().items()}
     t0 = time.time()
-    orc.train(data[3:6], m1, m2, m3, spec, perm, costs, ratio, 2)
-    t_step = (time.time() - t0) / 3
+    o3, _ = orc.train(data[:nU], c1, c2, o3, spec, want_perm, want_costs, ratio, n_sched)
+    t_step = (time.time() - t0) / nU
     log("cpu: PLeaS update %.1fs" % t_step)
-    scale = batch_full / sample_batch
-    total = n_match * t_match * scale + t_lap + t_merge + n_pleas * t_step * scale
-    return {
-        "value": round(total, 1), "unit": "s", "cores": cores, "kind": "port",
-        "sample": "oracle on %s pair: 3 matching batches (%.1fs each) + 3 PLeaS updates (%.1fs each) at batch %d, all %d "
-                  "LAPs (%.2fs), merge (%.2fs); batches scaled x%.0f to batch %d, then x%d matching + x%d updates"
-                  % (arch, t_match, t_step, sample_batch, len(perm), t_lap, t_merge, scale, batch_full, n_match, n_pleas),
-    }
+    want = o3.state_dict()
+    with torch.backends.mkldnn.flags(enabled=False):      # the oracle against itself: the yardstick at this depth
+        v3 = orc.partial_merge(spec, c1, c2, want_perm, want_costs, ratio)
+        v3, _ = orc.train(data[:nU], c1, c2, v3, spec, want_perm, want_costs, ratio, n_sched)
+    variant = v3.state_dict()
+    got = {k: v.cpu() for k, v in res["m3"].state_dict().items()}
+    rows = {}
+    for k in want:
+        if k == "conv1.weight" or not want[k].dtype.is_floating_point or torch.equal(want[k], merged[k]):
+            continue      # the stem's residual is rounding noise in the reference itself (DESIGN.md section 1)
+        rows[k] = (rel(got[k], want[k]), rel(variant[k], want[k]))
+    worst = max(rows, key=lambda k: rows[k][0]) if rows else None
+    yard_max = max((v[1] for v in rows.values()), default=0.0)
+    over = {k: v for k, v in rows.items() if v[0] > max(1e-4, 3 * v[1])}
+    ok = (worst_cost < 1e-4 and not bad_groups and len(near_ties) <= 4 and len(over) <= max(1, len(rows) // 150)
+          and all(v[0] <= max(1e-4, 3 * yard_max) for v in over.values()))
+    parity = {
+        "ok": bool(ok), "matching_batches": nM, "updates": nU, "batch": int(data[0][0].shape[0]),
+        "worst_group_cost_rel_fro": worst_cost, "assignments_equal": "%d / %d" % (equal, len(spec)),
+        "near_tie_groups": near_ties, "groups_that_are_not_near_ties": bad_groups,
+        "trained_tensors": len(rows), "worst_trained_tensor": worst,
+        "worst_trained_rel_fro": rows[worst][0] if worst else None,
+        "oracle_self_spread_of_that_tensor": rows[worst][1] if worst else None, "oracle_self_spread_worst": yard_max,
+        "tensors_above_1e-4": sum(1 for v in rows.values() if v[0] > 1e-4),
+        "tensors_above_3x_own_yardstick": {k: list(v) for k, v in over.items()},
+        "note": "HIP job with the timed knobs on the job's own first batches vs the CPU oracle on the same batches; trained "
+                "tensors: both sides continue from the oracle's assignment, yardstick = the oracle with oneDNN "
+                "convolutions on vs off; gate as tests/test_hip_timed_config.py"}
+    total = n_match * seen["t_match"] + seen["t_lap"] + t_merge + n_pleas * t_step
+    cpu = {"value": round(total, 1), "unit": "s", "cores": cores, "kind": "port",
+           "sample": "oracle on the job's own batches at batch %d: %d matching batches (%.1fs each) + %d PLeaS updates (%.1fs "
+                     "each), all %d LAPs (%.2fs), merge (%.2fs); counts scaled to %d matching batches + %d updates"
+                     % (data[0][0].shape[0], nM, seen["t_match"], nU, t_step, len(want_perm), seen["t_lap"], t_merge, n_match,
+                        n_pleas)}
+    return cpu, parity
 
 
 def cpu_reference_legs(costs, hip_perm, alt):
@@ -689,9 +754,11 @@ def main():
                                   if args.emulate_allreduce_us > 0 else "skipped"))
             out["metric"] = "EMULATED " + out["metric"]
         if world == 1 and not args.no_cpu_baseline and args.emulate_world <= 1:
-            out["cpu_baseline"] = cpu_baseline(spec, args.arch, args.batch, args.cpu_sample_batch, n_match, n_pleas,
-                                               args.ratio)
+            out["cpu_baseline"], parity = cpu_baseline_and_parity(cfg, spec, m1, m2, pool, n_match, n_pleas, n_sched,
+                                                                  args.cpu_match_batches, args.cpu_updates)
             out["cpu_baseline"]["reference_legs"] = cpu_reference_legs(res["costs"], res["perm"], alt)
+            checks["parity_vs_oracle"] = parity
+            checks["ok"] = bool(checks["ok"] and parity["ok"])
         if phases is not None:
             phases = {"spec": round(spec_s, 4), **phases,
                       "note": "one extra job with a device synchronisation at every boundary (phases cannot overlap "

@@ -1055,6 +1055,18 @@ static int build_fwd_plan(FwdPlan& P, const pleas_fwd_layer* ly, int n) {
     return PLEAS_OK;
 }
 
+// the streamed form (conv_fwd_stream.hip): one persistent grid with producer / consumer waves
+namespace fwds {
+size_t stream_ws_bytes(const pleas_fwd_layer* layers, int n_layers);
+int stream_plan_info(const pleas_fwd_layer* layers, int n_layers, int n_wg, int* info);
+int stream_launch(const pleas_fwd_layer* layers, int n_layers, float* loss, void* ws, size_t ws_bytes, int ws_fresh,
+                  hipStream_t stream);
+}  // namespace fwds
+static bool fwd_streamed() {
+    static const bool on = !(std::getenv("PLEAS_FWD_STREAM") && std::atoi(std::getenv("PLEAS_FWD_STREAM")) == 0);
+    return on;
+}
+
 }  // namespace pleas
 
 using namespace pleas;
@@ -1106,7 +1118,9 @@ extern "C" size_t pleas_fwd_batch_ws_bytes(const pleas_fwd_layer* layers, int n_
     if (!layers || n_layers <= 0) return 0;
     FwdPlan tmp;
     if (build_fwd_plan(tmp, layers, n_layers) != PLEAS_OK) return 0;
-    return tmp.total;
+    const size_t streamed = fwds::stream_ws_bytes(layers, n_layers);
+    if (streamed == 0) return 0;
+    return std::max(tmp.total, streamed);
 }
 
 extern "C" int pleas_fwd_batch(const pleas_fwd_layer* layers, int n_layers, float* loss, void* ws, size_t ws_bytes,
@@ -1119,6 +1133,7 @@ extern "C" int pleas_fwd_batch(const pleas_fwd_layer* layers, int n_layers, floa
         if (((uintptr_t)l.ip & 15) != 0) return bad_arg("conv_fwd: the merged input must be 16-byte aligned");
     }
     hipStream_t stream = (hipStream_t)stream_;
+    if (fwd_streamed()) return fwds::stream_launch(layers, n_layers, loss, ws, ws_bytes, ws_fresh, stream);
     std::lock_guard<std::mutex> lk(g_fplan_mu);
     std::vector<int64_t> key;
     key.push_back(n_layers);

@@ -470,9 +470,11 @@ __global__ __launch_bounds__(256) void neq_finalize_kernel(float* __restrict__ A
 static bool lag_form(const pleas_neq_layer& l) {
     const char* env = std::getenv("PLEAS_NEQ_LAG");       // PLEAS_NEQ_LAG=0: every block contracted (A/B experiments)
     if (env && env[0] == '0') return false;
-    return l.KH == l.KW && l.KH > 1 && l.stride == 1 && 2 * l.pad == l.KH - 1 &&
-           (int64_t)l.N * l.Cin * l.Hin * l.Win < (1ll << 31);
+    // geometry only -- NOT the batch size: accumulate (any batch) and finalize (no batch at hand) must classify a layer alike
+    return l.KH == l.KW && l.KH > 1 && l.stride == 1 && 2 * l.pad == l.KH - 1;
 }
+// the lag tile addresses its input with 32-bit element offsets
+static bool lag_fits(const pleas_neq_layer& l) { return (int64_t)l.N * l.Cin * l.Hin * l.Win < (1ll << 31); }
 
 constexpr int nPtrBatch = 224;
 struct NeqPtrBatch {
@@ -537,6 +539,8 @@ static int build_neq_plan(NeqPlan& P, const pleas_neq_layer* ly, int n) {
         const int T = l.Cin > 64 ? 128 : 64;
         const bool direct = R == 1 && l.stride == 1 && l.pad == 0;
         const bool lag = !direct && lag_form(l);
+        if (lag && !lag_fits(l))      // an error, not another form: pleas_normal_eq_finalize classifies by geometry alone
+            return bad_arg("normal_eq: a stride-1 k x k layer's input must hold fewer than 2^31 elements per call");
         const bool vec = (direct || lag) && HWo % 4 == 0;
         d.variant = (T == 64 ? 1 : 0) | (vec ? 0 : 2) | (direct ? 0 : lag ? 8 : 4);
         d.total = lag ? (int)((int64_t)l.N * l.Cin * l.Hin * l.Win) : 0;

@@ -428,12 +428,19 @@ class BnTrainFold:
         self._ws = torch.empty(need // 8, dtype=torch.float64, device=x.device)
         self._out = torch.empty(2, batches, C, dtype=torch.float32, device=x.device)
         ptr = lambda t: t.data_ptr() if t is not None else None
-        self._tensors = (bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked)   # identity check below
+        self._tensors = self._addresses()      # compared per call: Module._apply swaps .data under the same objects
         self._args = (n, batches, C, inner, ptr(bn.weight), ptr(bn.bias), float(bn.eps),
                       ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
                       ptr(bn.num_batches_tracked) if (track and bn.num_batches_tracked is not None) else None,
                       self._out[0].data_ptr(), self._out[1].data_ptr(), self._ws.data_ptr(), need)
         self._shape = (tuple(x.shape), x.device, batches)
+
+    def _addresses(self) -> tuple:
+        """What the cached arguments depend on: the addresses of the module's parameters / buffers (``.to()`` / ``.float()``
+        swap ``.data`` under the SAME Parameter objects) and ``eps``."""
+        bn = self.bn
+        return tuple(t.data_ptr() if t is not None else 0 for t in
+                     (bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked)) + (float(bn.eps),)
 
     def __call__(self, x: torch.Tensor, batches: int = 1) -> Tuple[torch.Tensor, torch.Tensor]:
         """``batches`` > 1: ``x`` is that many batches back to back along dim 0; each is folded on its own samples, in
@@ -442,8 +449,7 @@ class BnTrainFold:
             raise PleasHipError("bn_train_fold needs an fp32 [N, C, ...] tensor on the GPU")
         x = x.contiguous()
         bn = self.bn
-        if self._shape != (tuple(x.shape), x.device, batches) or any(a is not b for a, b in zip(
-                self._tensors, (bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked))):
+        if self._shape != (tuple(x.shape), x.device, batches) or self._tensors != self._addresses():
             self._prepare(x, batches)
         n, nb, C, inner, w, b, eps, rm, rv, nbt, o0, o1, ws, need = self._args
         rc = _lib.lib().pleas_bn_train_fold_batches(x.data_ptr(), n, nb, C, inner, w, b, eps,
@@ -806,10 +812,16 @@ class NormalEqBatch:
             a.N, a.Cin, a.Hin, a.Win, a.KH, a.KW, a.stride, a.pad = geo
         return arr
 
-    def finalize(self) -> None:
+    def seen(self) -> dict:
+        """``{address of A: (A, geometry)}`` of every matrix this object has accumulated into."""
+        return dict(self._seen)
+
+    def finalize(self, pairs=None) -> None:
         """Fill the blocks ``flush`` leaves to the end (``pleas_normal_eq_finalize``: stride-1 k x k layers contract one
-        block per lag class only).  Once, after the last batch -- and after the all-reduce of a multi-GPU run."""
-        pairs = list(self._seen.values())
+        block per lag class only).  Once, after the last batch -- and after the all-reduce of a multi-GPU run.
+        ``pairs``: the ``(A, geometry)`` list to finalize when it is not this object's own -- a data-parallel rank that
+        accumulated no batch still receives the all-reduced matrices and must complete ALL of them."""
+        pairs = list(self._seen.values()) if pairs is None else list(pairs)
         if pairs:
             check(_lib.lib().pleas_normal_eq_finalize(self._layer_array(pairs), len(pairs), _stream()),
                   "pleas_normal_eq_finalize")

@@ -434,15 +434,13 @@ def _force_collectives() -> bool:
 
 
 def _unfolded_batch_statistics(gm: nn.Module) -> bool:
-    """Does the twin graph still CALL a normalisation module that uses batch statistics?  The fused chains fold a
-    train-mode BatchNorm2d per batch (``pleas_bn_train_fold_batches``: exact on a concatenated forward); a module that is
-    called as it is would normalise the concatenated batch as one."""
-    for node in gm.graph.nodes:
-        if node.op == "call_module":
-            m = gm.get_submodule(node.target)
-            if isinstance(m, nn.modules.batchnorm._BatchNorm) and (m.training or m.running_mean is None):
-                return True
-    return False
+    """Does the twin graph still CALL something that uses batch statistics?  The fused chains fold a train-mode BatchNorm2d
+    per batch (``pleas_bn_train_fold_batches``: exact on a concatenated forward); a module -- or a functional
+    ``F.batch_norm(training=True)`` / ``F.instance_norm`` -- that is called as it is would normalise the concatenated batch
+    as one, so batches then go one per forward."""
+    from .source_forward import uses_batch_statistics
+
+    return uses_batch_statistics(gm)
 
 
 def _model_device(model: nn.Module) -> torch.device:

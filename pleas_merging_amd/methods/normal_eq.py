@@ -136,7 +136,21 @@ class NormalEqFitter(PleasFitter):
         for s in self.bias_stats.values():
             for t in s:
                 dp_sum_(t, self.world)
-        self.neq.finalize()      # blocks of stride-1 k x k layers that are copies of contracted ones (lag classes)
+        # blocks of stride-1 k x k layers that are copies of contracted ones (lag classes): EVERY matrix of the all-reduced
+        # arena, whichever rank contracted into it -- a rank whose share of the batches was empty has seen no geometry of its
+        # own and takes the others' (the layers' image sizes; the batch size plays no part)
+        mine = self.neq.seen()
+        geos = {i: mine[A.data_ptr()][1] for i, A in enumerate(self.A) if A.data_ptr() in mine}
+        if self.world > 1:
+            import torch.distributed as dist
+
+            if dist.is_initialized():
+                every = [None] * dist.get_world_size()
+                dist.all_gather_object(every, geos)
+                for other in every:
+                    for i, g in other.items():
+                        geos.setdefault(i, g)
+        self.neq.finalize([(self.A[i], g) for i, g in sorted(geos.items())])
         info: Dict[str, float] = {}
         jobs, finals = [], []   # (W, rows, free, A_FF, rhs, A_FF backup) per solve; (plan, W, layout) per layer
         for idx, plan in enumerate(self.plans):

@@ -523,6 +523,13 @@ class PleasFitter:
         self.fast_updates = 0    # updates applied by patching the tables (the rest took the layer-by-layer path)
 
         layers = {n: m for n, m in model3.named_modules() if isinstance(m, (nn.Conv2d, nn.Linear))}
+        # The grouped HIP kernels take dense, undilated Conv2d layers with a square kernel / stride / padding (and Linear
+        # layers on 2-D inputs); there is no vendor fallback for other geometries.  Said HERE, with the whole list, instead
+        # of at the first update ("Layer geometries").
+        odd = [n for n, m in layers.items() if isinstance(m, nn.Conv2d) and not _square_conv(m)]
+        if odd:
+            raise NotImplementedError("pleas_merging.train: the grouped HIP kernels take dense, undilated Conv2d layers with a "
+                                      "square kernel / stride / padding; not supported: %s" % ", ".join(odd))
         self.layer_modules = layers
         pad4 = lambda n: (n + 3) // 4 * 4   # every tensor starts 16-byte aligned inside the arenas (vector loads)
         total = sum(pad4(p.numel()) for m in layers.values() for p in m.parameters())

@@ -216,7 +216,30 @@ def fuse_bn_act(model: nn.Module, op: Callable = _bn_act, train_stats: bool = Fa
     gm.train(model.training)
     gm.batches_per_forward = state      # reset_bn_stats: `gm.batches_per_forward.parts = k` around a k-batch forward
     # does every normalisation layer with batch statistics go through a per-batch fold?  (only then may batches share a forward)
-    gm.all_batch_statistics_folded = not any(
-        n.op == "call_module" and isinstance(mods.get(n.target), nn.modules.batchnorm._BatchNorm)
-        and (mods[n.target].training or mods[n.target].running_mean is None) for n in graph.nodes)
+    gm.all_batch_statistics_folded = not uses_batch_statistics(gm)
     return gm
+
+
+def uses_batch_statistics(gm) -> bool:
+    """Does ``gm``'s graph still CALL something that normalises with the statistics of the batch it is given -- a BatchNorm /
+    InstanceNorm module in train mode (or without running statistics), a functional ``batch_norm`` / ``instance_norm`` with
+    ``training`` / ``use_input_stats`` not provably off, or a module outside ``torch.nn`` that has such a submodule?
+    Several batches may share a forward only when the answer is no (the fused chains fold train-mode BatchNorm per batch)."""
+    import torch.nn.functional as F
+
+    norm = (nn.modules.batchnorm._BatchNorm, nn.modules.instancenorm._InstanceNorm)
+    stat = lambda m: isinstance(m, norm) and (m.training or getattr(m, "running_mean", None) is None)
+    for n in gm.graph.nodes:
+        if n.op == "call_module":
+            m = gm.get_submodule(n.target)
+            if stat(m) or any(stat(c) for c in m.modules()):
+                return True
+        elif n.op == "call_function" and n.target in (F.batch_norm, torch.batch_norm):
+            training = n.kwargs.get("training", n.args[5] if len(n.args) > 5 else False)
+            if training is not False:
+                return True
+        elif n.op == "call_function" and n.target in (F.instance_norm, torch.instance_norm):
+            use_input = n.kwargs.get("use_input_stats", n.args[5] if len(n.args) > 5 else True)
+            if use_input is not False:
+                return True
+    return False
