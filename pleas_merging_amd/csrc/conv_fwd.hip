@@ -859,18 +859,49 @@ static void fwd_slice_by_work(const FwdPlan& P, const FwdPlan::Unit& u, const st
     size_t final_slice = 0;          // the last slice with a share takes what rounding left over
     for (size_t k = 0; k < share.size(); ++k)
         if (share[k] > 0) final_slice = k;
+    if (!(want > 0) || !(work > 0)) {      // nothing to divide by: the unit stays whole (on the first lane that wanted a share)
+        out.push_back(FwdPlan::Unit{u.form, u.begin, u.count, (int)final_slice, u.ms});
+        return;
+    }
     for (size_t k = 0; k < share.size(); ++k) {
         upto += work * share[k] / want;
         int end = begin;
         while (end < u.begin + u.count && share[k] > 0 && (k == final_slice || acc + P.item_work[end] <= upto)) acc += P.item_work[end++];
         if (end == begin && share[k] > 0 && end < u.begin + u.count) acc += P.item_work[end++];
-        out.push_back(FwdPlan::Unit{u.form, begin, end - begin, (int)k, u.ms * share[k] / want});   // lane field: slice index
+        if (end > begin)                   // never a slice without items (a 0-block grid is an invalid launch)
+            out.push_back(FwdPlan::Unit{u.form, begin, end - begin, (int)k, u.ms * share[k] / want});   // lane field: slice index
         begin = end;
     }
 }
-static void fwd_schedule_measured(FwdPlan& P) {
+// every form's slices must tile [form_begin, form_begin + form_count) exactly, each with at least one item
+static bool fwd_units_cover(const FwdPlan& P) {
+    for (int f = 0; f < fForms; ++f) {
+        std::vector<std::pair<int, int>> sl;
+        for (const auto& u : P.units)
+            if (u.form == f) {
+                if (u.count <= 0 || u.lane < 0 || u.lane > fLanes) return false;
+                sl.emplace_back(u.begin, u.count);
+            }
+        std::sort(sl.begin(), sl.end());
+        int at = P.form_begin[f];
+        for (const auto& s2 : sl) {
+            if (s2.first != at) return false;
+            at += s2.second;
+        }
+        if (at != P.form_begin[f] + P.form_count[f]) return false;
+    }
+    return true;
+}
+// Returns false -- and leaves the plan's units as they were -- when the measurements are unusable (an event that failed to
+// time: ms <= 0) or the result would not launch every item exactly once; the caller then keeps the static lanes.
+static bool fwd_schedule_measured(FwdPlan& P) {
     double total = 0;
-    for (const auto& u : P.units) total += u.ms;
+    for (const auto& u : P.units) {
+        if (!(u.ms > 0)) return false;
+        total += u.ms;
+    }
+    if (!(total > 0)) return false;
+    const std::vector<FwdPlan::Unit> before = P.units;
     const double fair = total / (fLanes + 1);
     int filler = -1;
     for (size_t i = 0; i < P.units.size(); ++i)
@@ -912,6 +943,11 @@ static void fwd_schedule_measured(FwdPlan& P) {
             if (sl.count > 0) rest.push_back(sl);      // .lane = slice index = the lane it levels
     }
     P.units.swap(rest);
+    if (!fwd_units_cover(P)) {
+        P.units = before;
+        return false;
+    }
+    return true;
 }
 
 static std::mutex g_fplan_mu;
@@ -1062,9 +1098,14 @@ int stream_plan_info(const pleas_fwd_layer* layers, int n_layers, int n_wg, int*
 int stream_launch(const pleas_fwd_layer* layers, int n_layers, float* loss, void* ws, size_t ws_bytes, int ws_fresh,
                   hipStream_t stream);
 }  // namespace fwds
+// STUDY switch (round 4): the streamed form is correct on every test of the grouped forward but
+// SLOWER than the one-item-per-workgroup forms (5.0 vs 2.8 ms per ResNet-101 update): its producer waves share their SIMD's
+// vector issue with the MFMA waves, and back-to-back fp32 MFMAs leave another wave ~1/8 of the VALU rate
+// (tools/hipbench/mfma_valu_share.hip).  Off unless PLEAS_FWD_STREAM=1 or pleas_fwd_stream(1).
+static int g_fwd_stream = -1;
 static bool fwd_streamed() {
-    static const bool on = !(std::getenv("PLEAS_FWD_STREAM") && std::atoi(std::getenv("PLEAS_FWD_STREAM")) == 0);
-    return on;
+    if (g_fwd_stream < 0) g_fwd_stream = (std::getenv("PLEAS_FWD_STREAM") && std::atoi(std::getenv("PLEAS_FWD_STREAM")) != 0) ? 1 : 0;
+    return g_fwd_stream == 1;
 }
 
 }  // namespace pleas
@@ -1102,7 +1143,7 @@ extern "C" int pleas_fwd_plan_units(const pleas_fwd_layer* layers, int n_layers,
     if (rc != PLEAS_OK) return rc;
     if (form_ms) {       // as if the calibration launch had measured these per-form durations
         for (auto& u : tmp.units) u.ms = form_ms[u.form];
-        fwd_schedule_measured(tmp);
+        (void)fwd_schedule_measured(tmp);      // unusable measurements: the static units stay
     }
     const int n = (int)std::min<size_t>(tmp.units.size(), (size_t)max_units);
     for (int i = 0; i < n; ++i) {
@@ -1112,6 +1153,13 @@ extern "C" int pleas_fwd_plan_units(const pleas_fwd_layer* layers, int n_layers,
         units[4 * i + 3] = tmp.units[i].lane;
     }
     return (int)tmp.units.size();
+}
+
+extern "C" void pleas_fwd_stream(int on) { g_fwd_stream = on ? 1 : 0; }
+
+extern "C" int pleas_fwd_stream_plan_info(const pleas_fwd_layer* layers, int n_layers, int n_workgroups, int* info) {
+    if (!layers || n_layers <= 0 || !info) return bad_arg("fwd_stream_plan_info: empty layer list / null output");
+    return fwds::stream_plan_info(layers, n_layers, n_workgroups, info);
 }
 
 extern "C" size_t pleas_fwd_batch_ws_bytes(const pleas_fwd_layer* layers, int n_layers) {
@@ -1219,10 +1267,11 @@ extern "C" int pleas_fwd_batch(const pleas_fwd_layer* layers, int n_layers, floa
                     float ms = 0.f;
                     P.units[u].ms = hipEventElapsedTime(&ms, P.t0[u], P.t1[u]) == hipSuccess ? ms : 0.0;
                 }
-                fwd_schedule_measured(P);
                 P.calib = 2;
-                if (g_fcalib.size() >= 16) g_fcalib.erase(g_fcalib.begin());
-                g_fcalib.emplace_back(fwd_geometry_key(P.key), P.units);
+                if (fwd_schedule_measured(P)) {      // else: static lanes kept, nothing published to other fitters
+                    if (g_fcalib.size() >= 16) g_fcalib.erase(g_fcalib.begin());
+                    g_fcalib.emplace_back(fwd_geometry_key(P.key), P.units);
+                }
             }
             (void)hipGetLastError();   // hipEventQuery's "not ready" is not an error of this call
         }

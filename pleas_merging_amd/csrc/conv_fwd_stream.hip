@@ -37,7 +37,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kBK = 32, kTN = 128;
-constexpr int kCW = 8, kPW = 4, kThreads = 64 * (kCW + kPW), kPT = 64 * kPW;
+constexpr int kCW = 8, kPW = 8, kThreads = 64 * (kCW + kPW);      // 8 consumer waves, 2 producer groups of 4 waves
+constexpr int kAhead = 3;      // an element is requested three ticks before it is multiplied
 constexpr int kLdsA = 36;      // W tile rows [TM][36] (k contiguous; 16-byte aligned, conflict-free ds_read_b128)
 constexpr int kCt = 132;       // accumulator tile rows [TM][132]
 constexpr int kLr1 = 132;      // image rows of the VEC / GEN forms: 128 pixels
@@ -53,10 +54,22 @@ static_assert(kLdsFloats * 4 <= 163840, "one workgroup takes the CU's LDS");
 // record of one work item (64 dwords; lane l of a loading wave holds dword l)
 enum { rIP = 0, rW = 2, rBIAS = 4, rO1 = 6, rO2 = 8, rROW1 = 10, rROW2 = 12, rRESID = 14,      // pointers: patched per launch
        rLAYER = 16, rI0, rP0, rPSLOT, rNB, rNCH, rFLAGS, rLR, rCOUT, rCIN, rHIN, rWIN, rWOUT, rKH, rKW, rSTRIDE, rPAD, rCSRC,
-       rHWO, rPTOT, rKD, rDSCALE, rHALO, rR, rCB, rHWI, rS, rNMERGED, rUsed };
+       rHWO, rPTOT, rKD, rDSCALE, rHALO, rR, rCB, rHWI, rS, rNMERGED, rIMG0, rUsed };
 static_assert(rUsed <= 64, "record is 64 dwords");
 constexpr int fEND = 1, fTM64 = 2, fFormShift = 2, fSCALARA = 16, fKPOS = 32, fVECEPI = 64;
 constexpr int FORM_VEC = 0, FORM_FLAT = 1, FORM_GEN = 2;
+constexpr int kSliceCh = 2;    // output channels per thread and epilogue slice (x 4 pixels): kSliceCh * 8 channels of the tile per slice
+constexpr int kParts = 8;      // loss partials per item: one per producer wave
+
+#ifndef PLEAS_FWDS_STAMPS
+#define PLEAS_FWDS_STAMPS 0      // experiments only (tools/hipbench): per-workgroup cycle accounting of the three roles
+#endif
+#if PLEAS_FWDS_STAMPS
+__device__ long long g_fwds_stamps[1024][16];  // + 8..11: group 0's cycles in its phases (1) write, (2) consume, (3) request, (4) gather   // per workgroup: total, consumer busy, chunks, group 0 busy, its active ticks, group 1 busy, its active ticks, ticks
+#define FWDS_T(var) const long long var = clock64()
+#else
+#define FWDS_T(var)
+#endif
 
 struct Meta {       // what the write step of a tick needs to know about the loads the previous tick issued
     int code;       // bits 0-1: weights (0 none, 1 16-byte rows, 2 scalar rows); 2-4: input (0 none, 1 VEC image, 2 GEN image,
@@ -65,6 +78,12 @@ struct Meta {       // what the write step of a tick needs to know about the loa
     unsigned oka, okb;   // per thread: which of its weight rows / input values are real (the rest is written as zero)
 };
 
+// An item's record in ONE register per wave (lane l holds dword l): fields come out by v_readlane, no memory access.
+__device__ __forceinline__ int rl(const int rec, const int k) { return __builtin_amdgcn_readlane(rec, k); }
+__device__ __forceinline__ const char* rlp(const int rec, const int k) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane(rec, k), hi = (unsigned)__builtin_amdgcn_readlane(rec, k + 1);
+    return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ const float* rec_ptr(const int* ring, int slot, int k) {
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane(ring[slot * 64 + k]);
     const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane(ring[slot * 64 + k + 1]);
@@ -98,6 +117,8 @@ __global__ __launch_bounds__(kThreads, 1) void fwd_stream_kernel(const int* __re
     const int first = wg[blockIdx.x].x, count = wg[blockIdx.x].y;      // records of this workgroup, the END record included
     if (wave == kCW) ring[lane] = recs[(size_t)first * 64 + lane];
     __syncthreads();
+    // Element x of the workgroup's stream (a K chunk of an item, or a bubble) is LOADED at tick x - 3, WRITTEN to LDS at tick
+    // x - 1 and MULTIPLIED at tick x.  Ticks start at -3.
 
     if (wave < kCW) {
         // ============================================================ consumers: LDS reads + MFMAs only
@@ -108,36 +129,40 @@ __global__ __launch_bounds__(kThreads, 1) void fwd_stream_kernel(const int* __re
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
         int jC = 0, tC = 0, ntC = 0, nbC = 0, nchC = 0, flagsC = 0;
-        int Lr = kLr1, halo = 0, Wimg = 1, KW = 1, pad = 0, R = 1, form = 0, TM = 128;
-        int imgC = 0, bsel = 0, jb = 0;
+        int Lr = kLr1, Wimg = 1, KW = 1, pad = 0, R = 1, form = 0, TM = 128, img0 = 0, jb = 0;
         unsigned tapok = ~0u;
         bool enter = true, finished = false;
-        for (int g = -2;; ++g) {
+#if PLEAS_FWDS_STAMPS
+        long long c_busy = 0, c_chunks = 0, c_ticks = 0;
+        const long long c_t0 = clock64();
+#endif
+        for (int g = -kAhead;; ++g) {
+            FWDS_T(cs0);
             if (g >= 0) {
                 if (enter) {
-                    const int slot = jC & 3;
-                    flagsC = rec_int(ring, slot, rFLAGS);
-                    nbC = rec_int(ring, slot, rNB);
-                    nchC = rec_int(ring, slot, rNCH);
+                    const int rc = ring[(jC & 3) * 64 + lane];      // the item's record: one LDS read per wave
+                    flagsC = rl(rc, rFLAGS);
+                    nbC = rl(rc, rNB);
+                    nchC = rl(rc, rNCH);
                     ntC = nbC + nchC;
                     tC = 0;
                     enter = false;
                     if (!(flagsC & fEND)) {
                         form = (flagsC >> fFormShift) & 3;
                         TM = (flagsC & fTM64) ? 64 : 128;
-                        Lr = rec_int(ring, slot, rLR);
-                        halo = rec_int(ring, slot, rHALO);
-                        R = rec_int(ring, slot, rR);
+                        Lr = rl(rc, rLR);
+                        R = rl(rc, rR);
+                        img0 = rl(rc, rIMG0);
                         const int q = wn * 32 + (lane & 31);
-                        jb = halo + q;
+                        jb = rl(rc, rHALO) + q;
                         tapok = ~0u;
                         if (form == FORM_FLAT) {
-                            Wimg = rec_int(ring, slot, rWIN);
-                            KW = rec_int(ring, slot, rKW);
-                            pad = rec_int(ring, slot, rPAD);
-                            const int Hin = rec_int(ring, slot, rHIN);
-                            const unsigned HW = (unsigned)rec_int(ring, slot, rHWO), Ptot = (unsigned)rec_int(ring, slot, rPTOT);
-                            const unsigned P = (unsigned)rec_int(ring, slot, rP0) + (unsigned)q;
+                            Wimg = rl(rc, rWIN);
+                            KW = rl(rc, rKW);
+                            pad = rl(rc, rPAD);
+                            const int Hin = rl(rc, rHIN);
+                            const unsigned HW = (unsigned)rl(rc, rHWO), Ptot = (unsigned)rl(rc, rPTOT);
+                            const unsigned P = (unsigned)rl(rc, rP0) + (unsigned)q;
                             unsigned mask = 0;
                             if (P < Ptot) {
                                 const unsigned n = P / HW, pp = P - n * HW;
@@ -154,17 +179,17 @@ __global__ __launch_bounds__(kThreads, 1) void fwd_stream_kernel(const int* __re
                 }
                 if (tC >= nbC && tC < ntC) {
                     const int c = tC - nbC;
-                    int r = 0, delta = 0;
+                    int r = 0, delta = 0, img = img0 + c;
                     if (form == FORM_FLAT) {
                         const int cb = c / R;
                         r = c - cb * R;
                         const int kh = r / KW, kw = r - kh * KW;
                         delta = (kh - pad) * Wimg + (kw - pad);
+                        img = img0 + cb;
                     }
-                    if (form != FORM_FLAT || r == 0) bsel = (imgC++) & 1;
                     const bool ok = (tapok >> r) & 1u;
                     const float* a = smem + oAs + (g & 1) * (128 * kLdsA) + (wm * (TM / 2) + (lane & 31)) * kLdsA + 4 * (lane >> 5);
-                    const float* b = smem + oB + bsel * (32 * kLrMax) + 4 * (lane >> 5) * Lr + jb + delta;
+                    const float* b = smem + oB + (img & 1) * (32 * kLrMax) + 4 * (lane >> 5) * Lr + jb + delta;
                     if (TM == 128) mfma_chunk<2>(a, b, Lr, ok, acc);
                     else mfma_chunk<1>(a, b, Lr, ok, acc);
                     if (c == nchC - 1) {      // the item is complete: accumulators -> LDS tile [co][pixel], start over
@@ -182,6 +207,9 @@ __global__ __launch_bounds__(kThreads, 1) void fwd_stream_kernel(const int* __re
                             }
                     }
                 }
+#if PLEAS_FWDS_STAMPS
+                if (tC >= nbC && tC < ntC) ++c_chunks;
+#endif
                 if (++tC >= ntC) {
                     if (flagsC & fEND) finished = true;
                     else {
@@ -190,62 +218,82 @@ __global__ __launch_bounds__(kThreads, 1) void fwd_stream_kernel(const int* __re
                     }
                 }
             }
+#if PLEAS_FWDS_STAMPS
+            c_busy += clock64() - cs0;
+            ++c_ticks;
+#endif
             __syncthreads();
             if (finished) break;
         }
+#if PLEAS_FWDS_STAMPS
+        if (tid == 0 && blockIdx.x < 1024) {
+            g_fwds_stamps[blockIdx.x][0] = clock64() - c_t0;
+            g_fwds_stamps[blockIdx.x][1] = c_busy;
+            g_fwds_stamps[blockIdx.x][2] = c_chunks;
+            g_fwds_stamps[blockIdx.x][7] = c_ticks;
+        }
+#endif
         return;
     }
 
     // ================================================================ producers: every global access of the launch
-    // Uniform per-item values are re-read from the record ring where they are used (a broadcast LDS read each) instead of
-    // being carried across ticks: the live state of a producer wave is the two register sets in flight, the gathered
-    // targets of one epilogue slice and a handful of cursors.
-    const int pt = tid - 64 * kCW, pw = pt >> 6;
-    // ---- the load cursor L (element g + 2 at tick g)
-    int jL = 0, tL = 0, ntL = 0, nbL = 0, flagsL = 0, imgL = 0;
-    bool doneL = false;
+    // TWO groups of four waves.  Group q handles the elements of parity q: at its active ticks (every other tick) it
+    //   (1) waits for everything it requested two ticks ago and writes that element's tiles to LDS (+ the next record / the
+    //       block maps it fetched), (2) finishes the epilogue slice whose targets it gathered two ticks ago,
+    //   (3) requests the tiles of its next element, (4) gathers the targets of its next epilogue slice.
+    // Waiting happens BEFORE anything new is requested, so "wait for all outstanding loads" (what the compiler emits when
+    // paths request different numbers of loads) costs nothing, and every request has two ticks to complete.
+    // Uniform per-item values are re-read from the record ring where they are used (a broadcast LDS read each).
+    const int pt = tid - 64 * kCW, grp = pt >> 8, pq = pt & 255, pw = pq >> 6;
+    // ---- the load cursor: element eL (parity grp) = tick tL of item jL
+    int eL = grp, jL = 0, tL = grp, ntL = 0, nbL = 0, flagsL = 0;
+    int recL = 0, recE = ring[lane];      // the records of the cursor's item and of the item in the epilogue: one register each
+    bool need_enter = true, at_end = false;
     int g_stop = 0x7fffffff;
     uint32_t voff[4] = {0, 0, 0, 0};      // this thread's image columns [bytes] (GEN: [0] pixel offset, [1] [2] tap mask)
     unsigned vokL = 0;
-    // ---- register sets of the two elements in flight, the next record, the maps of the item L entered last
-    f32x4 ra0[4], ra1[4], rb0[4], rb1[4];
-    Meta me0 = {0, 0, 0, 0}, me1 = me0;
-    int fdn = 0;
-    bool fd_pending = false;
+    f32x4 ra[4], rb[4];
+    Meta me = {0, 0, 0, 0};
+    int fdn = 0, fd_slot = -1, mp_item = -1;      // mp_item: the item whose maps (mp1, mp2, mpb) are on their way
     int mp1 = -1, mp2 = -1;
-    float mpb = 0.f, mpc = 0.f;
-    bool mp_pending = false;
-    // ---- epilogue of the item the consumers finished last
-    bool ep_pending = false, ep_active = false;
-    int ep_start = 0, ep_next = 0, ep_j = 0, ep_k = 0;      // ep_next: the item whose epilogue starts at tick ep_start
+    float mpb = 0.f;
+    // ---- epilogue: item ep_cur's accumulators are in the LDS tile from tick ep_elast on
+    int ep_cur = 0, ep_elast = rl(recE, rNB) + rl(recE, rNCH) - 1;
+    int ep_s = -1;            // slice whose targets are in (ta, tb), -1: none
+    bool ep_setup = false;
     float sq = 0.f;
     bool gin = false;
     uint32_t gbase = 0, rbase = 0;        // [bytes]
-    f32x4 ta[4], tb[4];
+    f32x4 ta[kSliceCh], tb[kSliceCh];
 
     auto enter_item = [&]() __attribute__((always_inline)) {
-        const int slot = jL & 3;
-        flagsL = rec_int(ring, slot, rFLAGS);
-        nbL = rec_int(ring, slot, rNB);
-        ntL = nbL + rec_int(ring, slot, rNCH);
-        if (jL + 1 < count) {        // the next record: requested now, put into the ring by the next tick's write step
+        recL = ring[(jL & 3) * 64 + lane];
+        flagsL = rl(recL, rFLAGS);
+        nbL = rl(recL, rNB);
+        ntL = nbL + rl(recL, rNCH);
+        need_enter = false;
+        const bool owner = tL == 0;      // the group that handles the item's first element also fetches the next record / the maps
+        if (owner && jL + 1 < count) {
             if (pw == 0) fdn = recs[(size_t)(first + jL + 1) * 64 + lane];
-            fd_pending = true;
+            fd_slot = (jL + 1) & 3;
         }
-        if (flagsL & fEND) return;
+        if (flagsL & fEND) {
+            at_end = true;
+            g_stop = eL - tL + ntL - 1;      // the END record's last element
+            return;
+        }
         const int form = (flagsL >> fFormShift) & 3;
-        const int Cin = rec_int(ring, slot, rCIN);
-        const unsigned p0 = (unsigned)rec_int(ring, slot, rP0), Ptot = (unsigned)rec_int(ring, slot, rPTOT);
-        const unsigned HWo = (unsigned)rec_int(ring, slot, rHWO);
-        // input image: this thread's columns
+        const int Cin = rl(recL, rCIN);
+        const unsigned p0 = (unsigned)rl(recL, rP0), Ptot = (unsigned)rl(recL, rPTOT);
+        const unsigned HWo = (unsigned)rl(recL, rHWO);
         if (form == FORM_VEC) {
-            const unsigned P4 = p0 + 4u * (pt & 31);
+            const unsigned P4 = p0 + 4u * (pq & 31);
             const bool ok = P4 < Ptot;
             const unsigned n = ok ? P4 / HWo : 0u, p = ok ? P4 - n * HWo : 0u;
-            voff[0] = ok ? 4u * (n * (unsigned)Cin * HWo + p + (unsigned)(pt >> 5) * HWo) : 0u;
+            voff[0] = ok ? 4u * (n * (unsigned)Cin * HWo + p + (unsigned)(pq >> 5) * HWo) : 0u;
             vokL = ok ? 1u : 0u;
         } else if (form == FORM_FLAT) {
-            const int halo = rec_int(ring, slot, rHALO);
+            const int halo = rl(recL, rHALO);
             const int span = kTN + 2 * halo;
             vokL = 0;
 #pragma unroll
@@ -258,11 +306,11 @@ __global__ __launch_bounds__(kThreads, 1) void fwd_stream_kernel(const int* __re
                 vokL |= (ok ? 1u : 0u) << m;
             }
         } else {
-            const int stride = rec_int(ring, slot, rSTRIDE), Wout = rec_int(ring, slot, rWOUT), Hin = rec_int(ring, slot, rHIN);
-            const int Win = rec_int(ring, slot, rWIN), pad = rec_int(ring, slot, rPAD), KW = rec_int(ring, slot, rKW);
-            const int R = rec_int(ring, slot, rR);
-            const unsigned HWi = (unsigned)rec_int(ring, slot, rHWI);
-            const unsigned P = p0 + (unsigned)(pt & 127);
+            const int stride = rl(recL, rSTRIDE), Wout = rl(recL, rWOUT), Hin = rl(recL, rHIN);
+            const int Win = rl(recL, rWIN), pad = rl(recL, rPAD), KW = rl(recL, rKW);
+            const int R = rl(recL, rR);
+            const unsigned HWi = (unsigned)rl(recL, rHWI);
+            const unsigned P = p0 + (unsigned)(pq & 127);
             const bool pin = P < Ptot;
             const unsigned pn = pin ? P / HWo : 0u, pp = pin ? P - pn * HWo : 0u;
             const int oh = (int)(pp / (unsigned)Wout), ow = (int)(pp - (unsigned)oh * Wout);
@@ -277,34 +325,33 @@ __global__ __launch_bounds__(kThreads, 1) void fwd_stream_kernel(const int* __re
             voff[1] = (uint32_t)tapmask;
             voff[2] = (uint32_t)(tapmask >> 32);
         }
-        // block maps / bias of the tile's output channels: into LDS by the next tick's write step
-        mp_pending = true;
-        const int TM = (flagsL & fTM64) ? 64 : 128;
-        if (pt < TM) {
-            const unsigned Cout = (unsigned)rec_int(ring, slot, rCOUT);
-            const unsigned co = (unsigned)rec_int(ring, slot, rI0) + (unsigned)pt;
-            const unsigned cc = min(co, Cout - 1u);
-            const int* row1 = reinterpret_cast<const int*>(rec_ptr(ring, slot, rROW1));
-            const int* row2 = reinterpret_cast<const int*>(rec_ptr(ring, slot, rROW2));
-            const float* bias = rec_ptr(ring, slot, rBIAS);
-            mp1 = PLEAS_GLOBAL_I(row1)[cc];
-            mp2 = PLEAS_GLOBAL_I(row2)[cc];
-            mpb = bias ? PLEAS_GLOBAL(bias)[cc] : 0.f;
-            mpc = co < Cout ? (co < (unsigned)rec_int(ring, slot, rNMERGED) ? 0.5f : 1.0f) : 0.f;
+        if (owner) {      // block maps / bias of the tile's output channels: into LDS at this group's next active tick
+            mp_item = jL;
+            if (pq < ((flagsL & fTM64) ? 64 : 128)) {
+                const unsigned Cout = (unsigned)rl(recL, rCOUT);
+                const unsigned co = (unsigned)rl(recL, rI0) + (unsigned)pq;
+                const unsigned cc = min(co, Cout - 1u);
+                const int* row1 = reinterpret_cast<const int*>(rlp(recL, rROW1));
+                const int* row2 = reinterpret_cast<const int*>(rlp(recL, rROW2));
+                const float* bias = reinterpret_cast<const float*>(rlp(recL, rBIAS));
+                mp1 = PLEAS_GLOBAL_I(row1)[cc];
+                mp2 = PLEAS_GLOBAL_I(row2)[cc];
+                mpb = bias ? PLEAS_GLOBAL(bias)[cc] : 0.f;
+            }
         }
     };
 
-    // loads of chunk c of L's item into (ra, rb); me describes them for the write step
-    auto issue_chunk = [&](const int c, f32x4 (&ra)[4], f32x4 (&rb)[4], Meta& me) __attribute__((always_inline)) {
-        const int slot = jL & 3;
+    // loads of chunk c of the cursor's item into (ra, rb); me describes them for the write step
+    auto issue_chunk = [&](const int c) __attribute__((always_inline)) {
         const int form = (flagsL >> fFormShift) & 3;
         const bool kpos = (flagsL & fKPOS) != 0;
         const int TM = (flagsL & fTM64) ? 64 : 128;
-        const int R = rec_int(ring, slot, rR), Cin = rec_int(ring, slot, rCIN);
-        const unsigned Kd = (unsigned)rec_int(ring, slot, rKD), Cout = (unsigned)rec_int(ring, slot, rCOUT);
-        const unsigned i0 = (unsigned)rec_int(ring, slot, rI0), HWi = (unsigned)rec_int(ring, slot, rHWI);
-        const char* wB = reinterpret_cast<const char*>(rec_ptr(ring, slot, rW));
-        const char* ipB = reinterpret_cast<const char*>(rec_ptr(ring, slot, rIP));
+        const int R = rl(recL, rR), Cin = rl(recL, rCIN);
+        const unsigned Kd = (unsigned)rl(recL, rKD), Cout = (unsigned)rl(recL, rCOUT);
+        const unsigned i0 = (unsigned)rl(recL, rI0), HWi = (unsigned)rl(recL, rHWI);
+        const int img0 = rl(recL, rIMG0);
+        const char* wB = rlp(recL, rW);
+        const char* ipB = rlp(recL, rIP);
         int cb = c, r = 0;
         if (kpos || form == FORM_FLAT) {
             cb = c / R;
@@ -313,28 +360,28 @@ __global__ __launch_bounds__(kThreads, 1) void fwd_stream_kernel(const int* __re
         int code = 0;
         // ---- weights
         if (!(flagsL & fSCALARA)) {
-            const unsigned k = (kpos || form == FORM_FLAT ? (unsigned)r * Cin + (unsigned)cb * kBK : (unsigned)c * kBK) + 4u * (pt & 7);
+            const unsigned k = (kpos || form == FORM_FLAT ? (unsigned)r * Cin + (unsigned)cb * kBK : (unsigned)c * kBK) + 4u * (pq & 7);
             const bool kina = k < Kd;
             const unsigned kc = kina ? k : 0u;
             unsigned oka = 0;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (q < TM / 32) {
-                    const unsigned gi = i0 + (unsigned)(pt >> 3) + 32u * q;
+                    const unsigned gi = i0 + (unsigned)(pq >> 3) + 32u * q;
                     if (gi < Cout && kina) oka |= 1u << q;
                     ra[q] = *(const __attribute__((address_space(1))) f32x4*)(wB + 4u * (min(gi, Cout - 1u) * Kd + kc));
                 }
             code = 1 | ((TM / 32) << 8);
             me.oka = oka;
         } else {
-            const unsigned k = (unsigned)c * kBK + (unsigned)(pt & 31);
+            const unsigned k = (unsigned)c * kBK + (unsigned)(pq & 31);
             const bool kina = k < Kd;
             const unsigned kc = kina ? k : 0u;
             unsigned oka = 0;
 #pragma unroll
             for (int q = 0; q < 16; ++q)
                 if (q < TM / 8) {
-                    const unsigned gi = i0 + (unsigned)(pt >> 5) + 8u * q;
+                    const unsigned gi = i0 + (unsigned)(pq >> 5) + 8u * q;
                     if (gi < Cout && kina) oka |= 1u << q;
                     ra[q >> 2][q & 3] = *(const __attribute__((address_space(1))) float*)(wB + 4u * (min(gi, Cout - 1u) * Kd + kc));
                 }
@@ -342,16 +389,16 @@ __global__ __launch_bounds__(kThreads, 1) void fwd_stream_kernel(const int* __re
             me.oka = oka;
         }
         // ---- input
-        me.lrspan = rec_int(ring, slot, rLR);
+        me.lrspan = rl(recL, rLR);
         if (form == FORM_VEC) {
             const char* base = ipB + (size_t)c * kBK * HWi * 4u;
 #pragma unroll
             for (int i = 0; i < 4; ++i) rb[i] = *(const __attribute__((address_space(1))) f32x4*)(base + (voff[0] + 4u * (unsigned)(8 * i) * HWi));
-            code |= (1 << 2) | (((imgL++) & 1) << 5);
+            code |= (1 << 2) | (((img0 + c) & 1) << 5);
             me.okb = vokL;
         } else if (form == FORM_GEN) {
-            const int khalf = __builtin_amdgcn_readfirstlane(pt >> 7);
-            const int Win = rec_int(ring, slot, rWIN), KW = rec_int(ring, slot, rKW);
+            const int khalf = __builtin_amdgcn_readfirstlane(pq >> 7);
+            const int Win = rl(recL, rWIN), KW = rl(recL, rKW);
             const unsigned long long tapmask = ((unsigned long long)voff[2] << 32) | voff[1];
             unsigned okb = 0;
             if (R == 1 || kpos) {
@@ -389,15 +436,15 @@ __global__ __launch_bounds__(kThreads, 1) void fwd_stream_kernel(const int* __re
                     ci += cr;
                 }
             }
-            code |= (2 << 2) | (((imgL++) & 1) << 5);
+            code |= (2 << 2) | (((img0 + c) & 1) << 5);
             me.okb = okb;
         } else {
             // FLAT: tap 0 carries the second half of its block's image, the last tap the first half of the next block's
-            const int CB = rec_int(ring, slot, rCB);
+            const int CB = rl(recL, rCB);
             const int half = r == 0 ? 1 : ((r == R - 1 && cb + 1 < CB) ? 0 : -1);
             if (half >= 0) {
                 const int blk = half ? cb : cb + 1;
-                const int span = kTN + 2 * rec_int(ring, slot, rHALO);
+                const int span = kTN + 2 * rl(recL, rHALO);
                 const int M = (span + 63) / 64;
                 const char* base = ipB + (size_t)(blk * kBK + 8 * pw + 4 * half) * HWi * 4u;
 #pragma unroll
@@ -405,32 +452,30 @@ __global__ __launch_bounds__(kThreads, 1) void fwd_stream_kernel(const int* __re
 #pragma unroll
                     for (int m = 0; m < 4; ++m)
                         if (m < M) rb[kr][m] = *(const __attribute__((address_space(1))) float*)(base + (voff[m] + 4u * (unsigned)kr * HWi));
-                code |= ((3 + half) << 2) | ((imgL & 1) << 5);
+                code |= ((3 + half) << 2) | (((img0 + blk) & 1) << 5);
                 me.lrspan |= span << 16;
                 me.okb = vokL;
-                if (half) ++imgL;
             }
         }
         me.code = code;
     };
     // the bubble right before a FLAT item's first chunk carries the first half of its first image
-    auto issue_first_half = [&](f32x4 (&rb)[4], Meta& me) __attribute__((always_inline)) {
-        const int slot = jL & 3;
-        const unsigned HWi = (unsigned)rec_int(ring, slot, rHWI);
-        const int span = kTN + 2 * rec_int(ring, slot, rHALO);
+    auto issue_first_half = [&]() __attribute__((always_inline)) {
+        const unsigned HWi = (unsigned)rl(recL, rHWI);
+        const int span = kTN + 2 * rl(recL, rHALO);
         const int M = (span + 63) / 64;
-        const char* base = reinterpret_cast<const char*>(rec_ptr(ring, slot, rIP)) + (size_t)(8 * pw) * HWi * 4u;
+        const char* base = rlp(recL, rIP) + (size_t)(8 * pw) * HWi * 4u;
 #pragma unroll
         for (int kr = 0; kr < 4; ++kr)
 #pragma unroll
             for (int m = 0; m < 4; ++m)
                 if (m < M) rb[kr][m] = *(const __attribute__((address_space(1))) float*)(base + (voff[m] + 4u * (unsigned)kr * HWi));
-        me.code = (3 << 2) | ((imgL & 1) << 5);
-        me.lrspan = rec_int(ring, slot, rLR) | (span << 16);
+        me.code = (3 << 2) | ((rl(recL, rIMG0) & 1) << 5);
+        me.lrspan = rl(recL, rLR) | (span << 16);
         me.okb = vokL;
     };
 
-    auto write_set = [&](const int stage, const f32x4 (&ra)[4], const f32x4 (&rb)[4], const Meta& me) __attribute__((always_inline)) {
+    auto write_set = [&](const int stage) __attribute__((always_inline)) {
         float* a = smem + oAs + stage * (128 * kLdsA);
         const int am = me.code & 3, bm = (me.code >> 2) & 7, buf = (me.code >> 5) & 1, rowsA = me.code >> 8;
         if (am == 1) {
@@ -439,12 +484,12 @@ __global__ __launch_bounds__(kThreads, 1) void fwd_stream_kernel(const int* __re
                 if (q < rowsA) {
                     const bool ok = (me.oka >> q) & 1u;
                     const f32x4 v = {ok ? ra[q][0] : 0.f, ok ? ra[q][1] : 0.f, ok ? ra[q][2] : 0.f, ok ? ra[q][3] : 0.f};
-                    *reinterpret_cast<f32x4*>(a + ((pt >> 3) + 32 * q) * kLdsA + 4 * (pt & 7)) = v;
+                    *reinterpret_cast<f32x4*>(a + ((pq >> 3) + 32 * q) * kLdsA + 4 * (pq & 7)) = v;
                 }
         } else if (am == 2) {
 #pragma unroll
             for (int q = 0; q < 16; ++q)
-                if (q < rowsA) a[((pt >> 5) + 8 * q) * kLdsA + (pt & 31)] = ((me.oka >> q) & 1u) ? ra[q >> 2][q & 3] : 0.f;
+                if (q < rowsA) a[((pq >> 5) + 8 * q) * kLdsA + (pq & 31)] = ((me.oka >> q) & 1u) ? ra[q >> 2][q & 3] : 0.f;
         }
         float* b = smem + oB + buf * (32 * kLrMax);
         if (bm == 1) {
@@ -452,12 +497,12 @@ __global__ __launch_bounds__(kThreads, 1) void fwd_stream_kernel(const int* __re
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const f32x4 v = {ok ? rb[i][0] : 0.f, ok ? rb[i][1] : 0.f, ok ? rb[i][2] : 0.f, ok ? rb[i][3] : 0.f};
-                *reinterpret_cast<f32x4*>(b + ((pt >> 5) + 8 * i) * kLr1 + 4 * (pt & 31)) = v;
+                *reinterpret_cast<f32x4*>(b + ((pq >> 5) + 8 * i) * kLr1 + 4 * (pq & 31)) = v;
             }
         } else if (bm == 2) {
-            const int khalf = pt >> 7;
+            const int khalf = pq >> 7;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) b[(khalf * 16 + q) * kLr1 + (pt & 127)] = ((me.okb >> q) & 1u) ? rb[q >> 2][q & 3] : 0.f;
+            for (int q = 0; q < 16; ++q) b[(khalf * 16 + q) * kLr1 + (pq & 127)] = ((me.okb >> q) & 1u) ? rb[q >> 2][q & 3] : 0.f;
         } else if (bm >= 3) {
             const int half = bm - 3, Lr = me.lrspan & 0xffff, span = me.lrspan >> 16;
 #pragma unroll
@@ -468,17 +513,16 @@ __global__ __launch_bounds__(kThreads, 1) void fwd_stream_kernel(const int* __re
         }
     };
 
-    // ---- epilogue slices: this thread owns channels (pt / 32) + 8 j of the tile and 4 consecutive pixels
+    // ---- epilogue slices: this thread owns channels (pq / 32) + 8 j of the tile and 4 consecutive pixels
     auto ep_gather = [&](const int s) __attribute__((always_inline)) {
-        const int slot = ep_j & 3;
-        if (!(rec_int(ring, slot, rFLAGS) & fVECEPI)) return;
-        const char* o1 = reinterpret_cast<const char*>(rec_ptr(ring, slot, rO1));
-        const char* o2 = reinterpret_cast<const char*>(rec_ptr(ring, slot, rO2));
-        const unsigned hw4 = 4u * (unsigned)rec_int(ring, slot, rHWO);
-        const int* mp = maps + (ep_j & 1) * (128 * 4);
+        if (!(rl(recE, rFLAGS) & fVECEPI)) return;
+        const char* o1 = rlp(recE, rO1);
+        const char* o2 = rlp(recE, rO2);
+        const unsigned hw4 = 4u * (unsigned)rl(recE, rHWO);
+        const int* mp = maps + (ep_cur & 1) * (128 * 4);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int lco = (pt >> 5) + 8 * (4 * s + u);
+        for (int u = 0; u < kSliceCh; ++u) {
+            const int lco = (pq >> 5) + 8 * (kSliceCh * s + u);
             const i32x4 mm = *reinterpret_cast<const i32x4*>(mp + lco * 4);
             const uint32_t oa = (gin && mm[0] >= 0) ? gbase + (unsigned)mm[0] * hw4 : 0u;
             const uint32_t ob = (gin && mm[1] >= 0) ? gbase + (unsigned)mm[1] * hw4 : 0u;
@@ -487,18 +531,17 @@ __global__ __launch_bounds__(kThreads, 1) void fwd_stream_kernel(const int* __re
         }
     };
     auto ep_consume = [&](const int s) __attribute__((always_inline)) {
-        const int slot = ep_j & 3;
-        const int flags = rec_int(ring, slot, rFLAGS);
-        const float dscale = __int_as_float(rec_int(ring, slot, rDSCALE));
-        const unsigned HWo = (unsigned)rec_int(ring, slot, rHWO);
-        char* resid = const_cast<char*>(reinterpret_cast<const char*>(rec_ptr(ring, slot, rRESID)));
-        const int* mp = maps + (ep_j & 1) * (128 * 4);
+        const int flags = rl(recE, rFLAGS);
+        const float dscale = __int_as_float(rl(recE, rDSCALE));
+        const unsigned HWo = (unsigned)rl(recE, rHWO);
+        char* resid = const_cast<char*>(rlp(recE, rRESID));
+        const int* mp = maps + (ep_cur & 1) * (128 * 4);
         const float* Ct = smem + oCt;
-        const int pg = (pt & 31) * 4;
+        const int pg = (pq & 31) * 4;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = 4 * s + u;
-            const int lco = (pt >> 5) + 8 * j;
+        for (int u = 0; u < kSliceCh; ++u) {
+            const int j = kSliceCh * s + u;
+            const int lco = (pq >> 5) + 8 * j;
             const i32x4 mm = *reinterpret_cast<const i32x4*>(mp + lco * 4);
             const float bias = __int_as_float(mm[2]), coef = __int_as_float(mm[3]);
             const bool live = gin && coef != 0.f;
@@ -517,12 +560,12 @@ __global__ __launch_bounds__(kThreads, 1) void fwd_stream_kernel(const int* __re
                 sq += live ? s4 : 0.f;
                 if (live) *(__attribute__((address_space(1))) f32x4*)(resid + (rbase + (unsigned)(8 * j) * (4u * HWo))) = d;
             } else if (live) {
-                const char* o1 = reinterpret_cast<const char*>(rec_ptr(ring, slot, rO1));
-                const char* o2 = reinterpret_cast<const char*>(rec_ptr(ring, slot, rO2));
-                const unsigned Ptot = (unsigned)rec_int(ring, slot, rPTOT), Csrc = (unsigned)rec_int(ring, slot, rCSRC);
-                const unsigned Cout = (unsigned)rec_int(ring, slot, rCOUT);
-                const unsigned co = (unsigned)rec_int(ring, slot, rI0) + (unsigned)lco;
-                const unsigned Pg = (unsigned)rec_int(ring, slot, rP0) + 4u * (pt & 31);
+                const char* o1 = rlp(recE, rO1);
+                const char* o2 = rlp(recE, rO2);
+                const unsigned Ptot = (unsigned)rl(recE, rPTOT), Csrc = (unsigned)rl(recE, rCSRC);
+                const unsigned Cout = (unsigned)rl(recE, rCOUT);
+                const unsigned co = (unsigned)rl(recE, rI0) + (unsigned)lco;
+                const unsigned Pg = (unsigned)rl(recE, rP0) + 4u * (pq & 31);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const unsigned Pe = Pg + e;
@@ -540,82 +583,104 @@ __global__ __launch_bounds__(kThreads, 1) void fwd_stream_kernel(const int* __re
         }
     };
 
-    auto ptick = [&](const int g, f32x4 (&raW)[4], f32x4 (&rbW)[4], Meta& meW, f32x4 (&raL)[4], f32x4 (&rbL)[4], Meta& meL)
-                     __attribute__((always_inline)) {
-        // (1) LDS writes of element g + 1 (loads issued by the previous tick), the next record, the block maps
-        if (fd_pending) {      // requested when L entered item jL: the record of item jL + 1
-            if (pw == 0) ring[((jL + 1) & 3) * 64 + lane] = fdn;
-            fd_pending = false;
-        }
-        if (mp_pending) {
-            const int TM = (flagsL & fTM64) ? 64 : 128;
-            if (pt < TM) {
-                const i32x4 v = {mpc != 0.f ? mp1 : -1, mpc != 0.f ? mp2 : -1, __float_as_int(mpb), __float_as_int(mpc)};
-                *reinterpret_cast<i32x4*>(maps + (jL & 1) * (128 * 4) + pt * 4) = v;
+#if PLEAS_FWDS_STAMPS
+    long long p_busy = 0, p_active = 0, p_ph[5] = {0, 0, 0, 0, 0};
+#endif
+    for (int g = -kAhead;; ++g) {
+        if (((g + kAhead) & 1) == grp) {
+            FWDS_T(ps0);
+#if PLEAS_FWDS_STAMPS
+            __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): how long do the requests of two ticks ago still take?
+            const long long psw = clock64();
+#endif
+            // ---- (1) LDS writes: the element requested two ticks ago (element g + 1), the next record, the block maps
+            if (fd_slot >= 0) {
+                if (pw == 0) ring[fd_slot * 64 + lane] = fdn;
+                fd_slot = -1;
             }
-            mp_pending = false;
-        }
-        write_set((g + 1) & 1, raW, rbW, meW);
-        // (2) epilogue: consume the slice whose gathers the previous tick issued
-        if (ep_active && ep_k >= 1) {
-            ep_consume(ep_k - 1);
-            if (ep_k == rec_int(ring, ep_j & 3, rS)) {
+            if (mp_item >= 0) {
+                const int rm = ring[(mp_item & 3) * 64 + lane];
+                if (pq < ((rl(rm, rFLAGS) & fTM64) ? 64 : 128)) {
+                    const unsigned co = (unsigned)rl(rm, rI0) + (unsigned)pq;
+                    // coef: 0.5 merged unit, 1 separate unit, 0 = row past Cout (never live)
+                    const float coef = co < (unsigned)rl(rm, rCOUT) ? (co < (unsigned)rl(rm, rNMERGED) ? 0.5f : 1.0f) : 0.f;
+                    const i32x4 v = {coef != 0.f ? mp1 : -1, coef != 0.f ? mp2 : -1, __float_as_int(mpb), __float_as_int(coef)};
+                    *reinterpret_cast<i32x4*>(maps + (mp_item & 1) * (128 * 4) + pq * 4) = v;
+                }
+                mp_item = -1;
+            }
+            write_set((g + 1) & 1);
+            FWDS_T(ps1);
+            // ---- (2) epilogue: finish the slice gathered two ticks ago
+            if (ep_s >= 0) {
+                ep_consume(ep_s);
+                if (ep_s + 2 >= rl(recE, rS)) {      // this group's last slice of the item
 #pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off);
-                if (lane == 0) partials[rec_int(ring, ep_j & 3, rPSLOT) + pw] = sq;
-                ep_active = false;
+                    for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off);
+                    if (lane == 0) partials[rl(recE, rPSLOT) + 4 * grp + pw] = sq;
+                    ++ep_cur;      // its record is in the ring: the consumers are multiplying it (or it is the END record)
+                    recE = ring[(ep_cur & 3) * 64 + lane];
+                    ep_elast += rl(recE, rNB) + rl(recE, rNCH);
+                    ep_setup = false;
+                }
+                ep_s = -1;
             }
-        }
-        // (3) loads of element g + 2
-        meL.code = 0;
-        if (!doneL) {
-            if (tL == 0) enter_item();
-            if (!(flagsL & fEND)) {
-                if (tL >= nbL) issue_chunk(tL - nbL, raL, rbL, meL);
-                else if (((flagsL >> fFormShift) & 3) == FORM_FLAT && tL == nbL - 1) issue_first_half(rbL, meL);
-            }
-            if (++tL >= ntL) {
-                if (flagsL & fEND) {
-                    doneL = true;
-                    g_stop = g + 2;
-                } else {
-                    ep_pending = true;      // the consumers drop this item's accumulators at tick g + 2
-                    ep_start = g + 2;
-                    ep_next = jL;           // (the epilogue of the item before it may still be running: ep_j is its)
-                    ++jL;
-                    tL = 0;
+            FWDS_T(ps2);
+            // ---- (3) requests for element g + 3
+            me.code = 0;
+            if (!at_end) {
+                if (need_enter) enter_item();
+                if (!at_end) {
+                    if (tL >= nbL) issue_chunk(tL - nbL);
+                    else if (((flagsL >> fFormShift) & 3) == FORM_FLAT && tL == nbL - 1) issue_first_half();
+                    tL += 2;
+                    eL += 2;
+                    if (tL >= ntL) {      // ticks of an item >= 3: at most one boundary per step
+                        tL -= ntL;
+                        ++jL;
+                        need_enter = true;
+                    }
                 }
             }
+            FWDS_T(ps3);
+            // ---- (4) epilogue: gather the targets of this group's next slice
+            {
+                const int s = g - ep_elast;
+                if (s >= 0 && !(rl(recE, rFLAGS) & fEND) && s < rl(recE, rS)) {
+                    if (!ep_setup) {
+                        ep_setup = true;
+                        sq = 0.f;
+                        const unsigned HWo = (unsigned)rl(recE, rHWO), Ptot = (unsigned)rl(recE, rPTOT);
+                        const unsigned Pg = (unsigned)rl(recE, rP0) + 4u * (pq & 31);
+                        gin = Pg < Ptot;
+                        const unsigned gn = gin ? Pg / HWo : 0u, gp = gin ? Pg - gn * HWo : 0u;
+                        gbase = 4u * (gn * (unsigned)rl(recE, rCSRC) * HWo + gp);
+                        rbase = 4u * ((gn * (unsigned)rl(recE, rCOUT) + (unsigned)rl(recE, rI0) + (unsigned)(pq >> 5)) * HWo + gp);
+                    }
+                    ep_gather(s);
+                    ep_s = s;
+                }
+            }
+#if PLEAS_FWDS_STAMPS
+            {
+                const long long pe = clock64();
+                p_busy += pe - ps0;
+                p_ph[4] += psw - ps0; p_ph[0] += ps1 - ps0; p_ph[1] += ps2 - ps1; p_ph[2] += ps3 - ps2; p_ph[3] += pe - ps3;
+                ++p_active;
+            }
+#endif
         }
-        // (4) epilogue: request the next slice's targets
-        if (ep_pending && g == ep_start) {
-            ep_j = ep_next;
-            const int slot = ep_j & 3;
-            ep_pending = false;
-            ep_active = true;
-            ep_k = 0;
-            sq = 0.f;
-            const unsigned HWo = (unsigned)rec_int(ring, slot, rHWO), Ptot = (unsigned)rec_int(ring, slot, rPTOT);
-            const unsigned Pg = (unsigned)rec_int(ring, slot, rP0) + 4u * (pt & 31);
-            gin = Pg < Ptot;
-            const unsigned gn = gin ? Pg / HWo : 0u, gp = gin ? Pg - gn * HWo : 0u;
-            gbase = 4u * (gn * (unsigned)rec_int(ring, slot, rCSRC) * HWo + gp);
-            rbase = 4u * ((gn * (unsigned)rec_int(ring, slot, rCOUT) + (unsigned)rec_int(ring, slot, rI0) + (unsigned)(pt >> 5)) * HWo + gp);
-        }
-        if (ep_active) {
-            if (ep_k < rec_int(ring, ep_j & 3, rS)) ep_gather(ep_k);
-            ++ep_k;
-        }
-    };
-
-    for (int g = -2;; g += 2) {
-        ptick(g, ra1, rb1, me1, ra0, rb0, me0);
         __syncthreads();
         if (g >= g_stop) break;
-        ptick(g + 1, ra0, rb0, me0, ra1, rb1, me1);
-        __syncthreads();
-        if (g + 1 >= g_stop) break;
     }
+#if PLEAS_FWDS_STAMPS
+    if (pq == 0 && blockIdx.x < 1024) {
+        g_fwds_stamps[blockIdx.x][3 + 2 * grp] = p_busy;
+        g_fwds_stamps[blockIdx.x][4 + 2 * grp] = p_active;
+        if (grp == 0)
+            for (int k = 0; k < 5; ++k) g_fwds_stamps[blockIdx.x][8 + k] = p_ph[k];
+    }
+#endif
 }
 
 // every record's eight pointers from its layer's row of the pointer table (which the host rewrites per launch)
@@ -729,23 +794,23 @@ static int build_plan(Plan& P, const pleas_fwd_layer* ly, int n, int n_wg) {
         c[rLAYER] = i; c[rFLAGS] = flags; c[rLR] = Lr; c[rCOUT] = l.Cout; c[rCIN] = l.Cin; c[rHIN] = l.Hin; c[rWIN] = l.Win;
         c[rWOUT] = Wout; c[rKH] = l.KH; c[rKW] = l.KW; c[rSTRIDE] = l.stride; c[rPAD] = l.pad; c[rCSRC] = l.Csrc;
         c[rHWO] = (int)HWo; c[rPTOT] = (int)Ptot; c[rKD] = (int)Kd; std::memcpy(&c[rDSCALE], &l.dscale, 4);
-        c[rHALO] = form == FORM_FLAT ? halo : 0; c[rR] = R; c[rCB] = l.Cin / kBK; c[rHWI] = l.Hin * l.Win; c[rS] = TM / 32;
+        c[rHALO] = form == FORM_FLAT ? halo : 0; c[rR] = R; c[rCB] = l.Cin / kBK; c[rHWI] = l.Hin * l.Win; c[rS] = TM / (8 * kSliceCh);
         c[rNMERGED] = l.n_merged; c[rNCH] = nch;
         const int tms = (int)ceil_div(l.Cout, TM), tps = (int)ceil_div(Ptot, kTN);
         int slot = 0;
         for (int tp = 0; tp < tps; ++tp)
             for (int tm = 0; tm < tms; ++tm) {
                 HostItem it;
-                it.layer = i; it.i0 = tm * TM; it.p0 = tp * kTN; it.slot = parts + 4 * slot; it.nch = nch; it.flags = flags;
-                it.S = TM / 32;
+                it.layer = i; it.i0 = tm * TM; it.p0 = tp * kTN; it.slot = parts + kParts * slot; it.nch = nch; it.flags = flags;
+                it.S = TM / (8 * kSliceCh);
                 // relative duration: the chunks' MFMA time, or -- short K -- the epilogue's memory time (3 x tile bytes)
                 const double mfma = (double)nch * (TM / 64) * 0.5, mem = (TM / 64) * 1.6 + 0.5;
                 it.cost = std::max(mfma, mem) + 0.3;
                 items.push_back(it);
                 ++slot;
             }
-        P.loss[i] = LossDev{parts, 4 * slot, l.loss_scale, 0};
-        parts += 4 * slot;
+        P.loss[i] = LossDev{parts, kParts * slot, l.loss_scale, 0};
+        parts += kParts * slot;
         P.forms[form] += slot;
         P.flops += 2.0 * l.Cout * (double)Kd * (double)Ptot;
         P.bytes += ((double)l.Cin * l.N * l.Hin * l.Win + 3.0 * l.Cout * (double)Ptot) * sizeof(float);
@@ -775,14 +840,17 @@ static int build_plan(Plan& P, const pleas_fwd_layer* ly, int n, int n_wg) {
     P.ticks_min = 1 << 30;
     for (int w = 0; w < n_wg; ++w) {
         P.wg[w].x = (int)(P.recs.size() / 64);
-        int prevS = 0, ticks = 0;
+        int prevS = 0, ticks = 0, img = 0;
         for (int idx : lists[w]) {
             const HostItem& it = items[idx];
             std::vector<int> rec = lay[it.layer];
             const int form = (it.flags >> fFormShift) & 3;
-            // ticks of an item >= 3 (record pipeline) and > the epilogue slices of its predecessor (one accumulator tile)
-            const int nb = std::max(std::max(form == FORM_FLAT ? 1 : 0, 3 - it.nch), prevS + 1 - it.nch);
-            rec[rI0] = it.i0; rec[rP0] = it.p0; rec[rPSLOT] = it.slot; rec[rNB] = nb;
+            // ticks of an item >= 3 (record pipeline) and >= the epilogue slices of its predecessor + 2: slice s of an item
+            // whose accumulators reach the LDS tile at tick T is gathered at tick T + s and finished at T + s + 2, and the
+            // next item's accumulators must not arrive before that
+            const int nb = std::max(std::max(form == FORM_FLAT ? 1 : 0, 3 - it.nch), prevS + 2 - it.nch);
+            rec[rI0] = it.i0; rec[rP0] = it.p0; rec[rPSLOT] = it.slot; rec[rNB] = nb; rec[rIMG0] = img;
+            img += form == FORM_FLAT ? rec[rCB] : it.nch;      // LDS images the item reads (one per chunk / per channel block)
             P.recs.insert(P.recs.end(), rec.begin(), rec.end());
             P.bubbles += nb;
             ticks += nb + it.nch;
@@ -790,7 +858,7 @@ static int build_plan(Plan& P, const pleas_fwd_layer* ly, int n, int n_wg) {
         }
         std::vector<int> end(64, 0);
         end[rFLAGS] = fEND;
-        end[rNB] = std::max(3, prevS + 1);
+        end[rNB] = std::max(3, prevS + 2);
         P.recs.insert(P.recs.end(), end.begin(), end.end());
         ticks += end[rNB];
         P.wg[w].y = (int)lists[w].size() + 1;
@@ -812,6 +880,12 @@ static int build_plan(Plan& P, const pleas_fwd_layer* ly, int n, int n_wg) {
     P.uploaded = false;
     return PLEAS_OK;
 }
+
+#if PLEAS_FWDS_STAMPS
+extern "C" int pleas_fwds_stamps_read(long long* out, int n_wg) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fwds_stamps), sizeof(long long) * 16 * (size_t)std::min(n_wg, 1024)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 size_t stream_ws_bytes(const pleas_fwd_layer* layers, int n_layers) {
     Plan tmp;

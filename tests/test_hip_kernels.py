@@ -885,6 +885,23 @@ def test_fwd_batch_flat_forms_random_geometries(ops):
         assert abs(float(loss[i]) - want_loss) < 1e-5 * max(1.0, want_loss), geo
 
 
+def test_fwd_batch_streamed_form(ops):
+    """The STUDY form of pleas_fwd_batch (one persistent workgroup per CU, producer / consumer waves, csrc/conv_fwd_stream.hip;
+    off by default) on the same cases as the default forms: every geometry class of FWD_CASES and the random
+    multi-layer launch, whose workgroups walk several items (record ring, epilogue of an item under the next item's MFMAs)."""
+    from pleas_merging_amd import _lib
+
+    lib = _lib.lib()
+    lib.pleas_fwd_stream(1)
+    try:
+        for case in FWD_CASES:
+            test_fwd_batch_matches_conv_and_target.__wrapped__(ops, *case) if hasattr(
+                test_fwd_batch_matches_conv_and_target, "__wrapped__") else test_fwd_batch_matches_conv_and_target(ops, *case)
+        test_fwd_batch_flat_forms_random_geometries(ops)
+    finally:
+        lib.pleas_fwd_stream(0)
+
+
 # ------------------------------------------------------------------------------------------ exchange step through the C-ABI
 _ALLREDUCE_CHILD = r"""
 import ctypes, sys, time
