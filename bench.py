@@ -55,6 +55,14 @@ def parse(argv=None):
     ap.add_argument("--ratio", type=float, default=0.0)
     ap.add_argument("--match-batches", type=int, default=FULL_MATCH, help="debug: matching batches per job (default 100)")
     ap.add_argument("--updates", type=int, default=FULL_PLEAS, help="debug: PLeaS updates per job (default 401)")
+    ap.add_argument("--inputs", default="resident", choices=("resident", "host"),
+                    help="where the timed jobs take their batches from: HBM-resident tensors, or pinned host tensors copied "
+                         "host -> device inside the loops on a copy stream; the other mode is timed on two extra jobs and "
+                         "reported beside it (`inputs`)")
+    ap.add_argument("--match-mode", default="eval", choices=("eval", "train"),
+                    help="train: both models are put in train mode before every job's activation matching, as the reference "
+                         "drivers run it (no .eval() before activation_matching, run_domainnet.py:172-186): BatchNorm uses "
+                         "batch statistics and moves its running statistics; `train` puts the sources in eval mode as ever")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-solver", action="store_true", help="skip the closed-form (normal equations) leg")
     ap.add_argument("--no-phases", action="store_true", help="skip the extra synchronised job that fills phases_s")
@@ -148,17 +156,27 @@ def log(msg):
 
 
 class Pool:
-    """Synthetic batches resident in HBM: batch b = N(0,1) from a generator seeded 1000 + b."""
+    """Synthetic batches: batch b = N(0,1) from a generator seeded 1000 + b, generated on the device.  ``where`` =
+    "resident": the loops are handed the HBM-resident tensors; "host": PINNED host copies -- every batch then crosses PCIe
+    inside the timed region, as in the reference's loops (activation_matching.py:121, pleas_merging.py:266), on a copy
+    stream beside the previous batch's compute (hip_ops.to_device_async)."""
 
-    def __init__(self, n, batch, device):
+    def __init__(self, n, batch, device, host=False):
         gen = torch.Generator(device=device)
-        self.items = []
+        self.items, self.host_items = [], []
         for b in range(n):
             gen.manual_seed(1000 + b)
-            self.items.append(torch.randn(batch, 3, 224, 224, generator=gen, device=device))
+            x = torch.randn(batch, 3, 224, 224, generator=gen, device=device)
+            self.items.append(x)
+            if host:
+                h = torch.empty(x.shape, dtype=x.dtype, pin_memory=True)
+                h.copy_(x)
+                self.host_items.append(h)
+        self.where = "resident"
 
     def loader(self, start, count):
-        return [(self.items[(start + i) % len(self.items)], None) for i in range(count)]
+        src = self.host_items if self.where == "host" else self.items
+        return [(src[(start + i) % len(src)], None) for i in range(count)]
 
 
 def build_models(arch, device, batch):
@@ -212,6 +230,9 @@ def run_job(cfg, spec, m1, m2, match_loader, pleas_loader, n_pleas_sched, phases
     dp = cfg["dp"]
     if cfg.get("gc") == "lap":
         gc.disable()
+    if cfg.get("match_mode") == "train":      # the drivers' mode (the PLeaS phase puts the sources back into eval mode)
+        m1.train()
+        m2.train()
     # The frozen sources of the PLeaS phase do not depend on the permutation: while the batched LAP kernel runs (one
     # workgroup per problem), the host builds their fused forwards and enqueues the first groups of source forwards on
     # the side streams, where they also fill the GPU's idle time during partial merge and fitter set-up.
@@ -300,7 +321,7 @@ def time_normal_eq(spec, m1, m2, perm, costs, loader, ratio, sources_per_forward
         pass
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    fit.solve()
+    solve_info = fit.solve()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     hip_ops.profile_enable(False)
@@ -323,6 +344,11 @@ def time_normal_eq(spec, m1, m2, perm, costs, loader, ratio, sources_per_forward
             samples.append({"name": pl.name, "K": k, "cout": pl.w_shape[0], "ridge": fit.ridge,
                             "A": (torch.tril(A) + torch.tril(A, -1).t()).cpu(), "Bt": fit.Bt[idx].cpu(), "W_hip": w.cpu()})
     return {"solver": "normal_eq", "batches": len(loader), "accumulate_s": round(t1 - t0, 3), "solve_s": round(t2 - t1, 3),
+            "fp64_fallbacks": int(solve_info.get("fp64_fallbacks", 0)),
+            "fp64_fallbacks_note": "systems the fp32 HIP Cholesky flagged (non-positive pivot) and torch.linalg redid in fp64",
+            "kernels_ms": {k: {"launches": v[0], "total_ms": round(v[1], 2)} for k, v in sorted(p.items()) if v[0]},
+            "kernels_note": "own kernels of this leg by HIP events (on several streams: they overlap); what is left of accumulate_s is "
+                            "the vendor source forwards (see `vendor`), the bias statistics and host dispatch",
             "neq_batch_kernel": {"bound": "mfma", "launches": rec[0], "avg_launch_us": round(rec[1] * 1e3 / max(rec[0], 1), 1),
                                  "achieved": round(ach, 1), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                                  "frac": round(ach / FP32_MATRIX_PEAK_TFLOPS, 3),
@@ -588,7 +614,8 @@ def main():
     spec = get_permutation_spec(m1, ((1, 3, 224, 224),))
     spec_s = time.perf_counter() - t0
     ranks = max(world, args.emulate_world)
-    pool = Pool(max(n_match, n_pleas), args.batch, device)
+    pool = Pool(max(n_match, n_pleas), args.batch, device, host=(world == 1 and args.emulate_world <= 1) or args.inputs == "host")
+    pool.where = args.inputs
     dp = world > 1
     if args.emulate_world > 1:
         assert world == 1, "--emulate-world is a single-process aid"
@@ -596,7 +623,7 @@ def main():
         os.environ["PLEAS_EMULATE_ALLREDUCE_US"] = str(args.emulate_allreduce_us)
         dp = True
     cfg = {"dp": dp, "ratio": args.ratio, "prefetch_groups": args.prefetch_groups, "prefetch_memory": args.prefetch_memory,
-           "shard_optimizer": args.shard_optimizer, "gc": args.gc, "match_per_forward": args.match_per_forward or None, "sources_per_forward": (args.sources_per_forward * ranks) or None, "lookahead": None if args.lookahead < 0 else bool(args.lookahead)}
+           "shard_optimizer": args.shard_optimizer, "gc": args.gc, "match_mode": args.match_mode, "match_per_forward": args.match_per_forward or None, "sources_per_forward": (args.sources_per_forward * ranks) or None, "lookahead": None if args.lookahead < 0 else bool(args.lookahead)}
     log("spec (%d groups, %.2f s on the host, outside `value`) + %d synthetic batches resident" % (len(spec), spec_s, len(pool.items)))
 
     def job(phases=None):
@@ -654,7 +681,38 @@ def main():
         ph = Phases(on=True, verbose=args.phase_log)
         job(ph)
         phases = dict(ph.out)
-    alt = vendor = bn_reset = None
+    alt = vendor = bn_reset = inputs_cmp = None
+    if world == 1 and args.emulate_world <= 1 and pool.host_items:
+        # the other input mode on extra jobs (one untimed first: its allocator pools / pinned staging are new)
+        other = "host" if args.inputs == "resident" else "resident"
+        pool.where = other
+        job()
+        torch.cuda.synchronize()
+        t_other = []
+        for _ in range(2):
+            tj = time.perf_counter()
+            job()
+            torch.cuda.synchronize()
+            t_other.append(time.perf_counter() - tj)
+        pool.where = args.inputs
+        mb = pool.items[0].numel() * 4 * (n_match + n_pleas) / 1e6
+        inputs_cmp = {"timed_jobs_take_batches_from": args.inputs, other + "_s_per_job": round(min(t_other), 4),
+                      other + "_jobs": [round(t, 4) for t in t_other],
+                      "host_to_device_MB_per_job": round(mb, 1),
+                      "note": "host = pinned host tensors, copied inside the loops on a copy stream beside the previous "
+                              "batch's compute (hip_ops.to_device_async; reference: blocking x.cuda() per batch, "
+                              "activation_matching.py:121, pleas_merging.py:266)"}
+        log("inputs from %s: %s s per job (timed jobs, from %s: %.3f)" % (other, inputs_cmp[other + "_s_per_job"], args.inputs, value))
+    alt_emulated = None
+    if world == 1 and args.emulate_world > 1 and not args.no_alt_solver:
+        # rank 0's share of the CLOSED FORM under data parallelism: whole batches b % W == 0 are accumulated, ONE exchange of
+        # the A / B arenas at the end (skipped here), every rank solves every layer
+        mine = pool.loader(0, n_pleas)[::args.emulate_world]
+        a = time_normal_eq(spec, m1, m2, res["perm"], res["costs"], mine, args.ratio, args.sources_per_forward or None)
+        alt_emulated = {k: v for k, v in a.items() if not k.startswith("_")}
+        alt_emulated["note"] = ("rank 0's share (%d of %d batches) of solver='normal_eq' in a %d-rank job; the all-reduce of the "
+                                "A / B arenas before the solve is NOT included" % (len(mine), n_pleas, args.emulate_world))
+        log("closed form, emulated rank of %d: accumulate %.2fs, solve %.2fs" % (args.emulate_world, a["accumulate_s"], a["solve_s"]))
     if world == 1 and args.emulate_world <= 1:
         if not args.no_alt_solver:
             alt = time_normal_eq(spec, m1, m2, res["perm"], res["costs"], pool.loader(0, n_pleas), args.ratio,
@@ -736,6 +794,8 @@ def main():
                 "sources_per_forward": cfg["sources_per_forward"] or 2 * ranks,
                 "matching_batches_per_forward": cfg["match_per_forward"] or 2,
                 "host_gc": "collected once per job while the LAP kernel runs" if args.gc == "lap" else "interpreter default",
+                "inputs": "HBM-resident batches" if args.inputs == "resident" else "pinned host batches, copied host -> device inside the loops",
+                "matching_mode": args.match_mode,
                 "not_in_value": "get_permutation_spec %.2f s (host, once per model)" % spec_s,
             },
             "job_s": {"mean": round(value, 4), "median": round(srt[len(srt) // 2], 4), "min": round(srt[0], 4),
@@ -779,6 +839,10 @@ def main():
                 alt["job_s_if_closed_form"] = round(phases["matching"] + phases["lap"] + phases["merge_and_setup"]
                                                     + alt["accumulate_s"] + alt["solve_s"], 3)
             out["alt_solver"] = alt
+        if alt_emulated is not None:
+            out["alt_solver_emulated_rank"] = alt_emulated
+        if inputs_cmp is not None:
+            out["inputs"] = inputs_cmp
         if vendor is not None:
             out["vendor"] = vendor
         if bn_reset is not None:

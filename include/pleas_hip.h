@@ -242,6 +242,10 @@ size_t pleas_sqerr_ws_bytes(int64_t n);
 int pleas_sqerr(const float* a, const float* b, int64_t n, float scale, int accumulate, float* out, float dscale,
                 float* diff, void* ws, size_t ws_bytes, void* stream);
 
+/* Bias gradient of a merged layer: out[c] = sum_{n, p} x[n][c][p] for x = the layer's residual [N][C][HW] (Linear: HW = 1).
+ * Replaces the bias node of autograd's backward (pleas_merging.py:287).  Deterministic (fixed order, no atomics). */
+int pleas_channel_sum(const float* x, int N, int C, int64_t HW, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * PLeaS layer fitting: fused target/residual/loss pass and grouped weight-gradient launch.
  *

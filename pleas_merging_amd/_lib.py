@@ -46,6 +46,7 @@ SIGNATURES = {
     "pleas_sqerr_ws_bytes": (c_size_t, [c_int64]),
     "pleas_sqerr": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_int, c_void_p, c_float, c_void_p, c_void_p, c_size_t,
                             c_void_p]),
+    "pleas_channel_sum": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p]),
     "pleas_prof_enable": (None, [c_int]),
     "pleas_prof_select": (None, [ctypes.c_uint]),
     "pleas_prof_reset": (None, []),

@@ -46,6 +46,11 @@ struct WgradLayerDev {
                          // bit4: Y shifted through aligned 16-byte loads (stride-1 "same" layers; X carries the border mask)
     int flags;           // PLEAS_WGRAD_ACCUMULATE | PLEAS_WGRAD_KPOS_MAJOR
     int total;           // floats in ip (bit4 form: clamps the shifted operand's loads)
+    // bit5 of variant, "virtual channels" (layers with fewer than 16 input channels, e.g. the 3-channel 7x7 stem): the
+    // N axis of the contraction is j = (ci, kh, kw) flattened -- Cin / KH / KW above then describe that 1x1 VIEW
+    // (Cin = real Cin * R, KH = KW = 1: epilogue and slab reduce see an ordinary 1x1 layer whose standard layout
+    // [Cout][Cin*R] IS the real layer's [Cout][Cin][KH][KW]) and these three the real layer for the loader
+    int rCin, rKW, rR;
 };
 struct WgradItemDev {
     int layer, tm, tn, r, split, c_begin, c_end, pad;
@@ -60,7 +65,8 @@ template <int TM, int TN, int VECX, int YMODE>
 __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradItemDev& it, float* smem) {
     constexpr int MTM = TM / 64, MTN = TN / 64;
     constexpr bool YSHIFT = YMODE == 1;
-    constexpr int VECY = YMODE == 1 ? 1 : (YMODE == 2 ? 4 : VECX);
+    constexpr bool YROWS = YMODE == 3;     // every row of the Y tile has its own (channel, tap): virtual channels
+    constexpr int VECY = (YMODE == 1 || YMODE == 3) ? 1 : (YMODE == 2 ? 4 : VECX);
     static_assert(YMODE != 2 || VECX == 4, "the 16-byte shifted form needs HW % 4 == 0, hence vector loads of X too");
     constexpr int LPR_X = cBK / VECX, RPP_X = cThreads / LPR_X, PASS_X = TM / RPP_X;
     constexpr int LPR_Y = cBK / VECY, RPP_Y = cThreads / LPR_Y, PASS_Y = TN / RPP_Y;
@@ -87,11 +93,20 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradIt
         if (gi < L.Cout) okx |= 1u << q;
         offx[q] = (uint32_t)min(gi, L.Cout - 1) * L.HWo;
     }
+    int tapq[YROWS ? PASS_Y : 1];         // YROWS: (kh - pad) | (kw - pad) << 16 of this thread's rows
+    unsigned okyc = 0;                    // YROWS: rows whose tap is inside the image at this thread's pixel of the chunk
 #pragma unroll
     for (int q = 0; q < PASS_Y; ++q) {
         const int gj = j0 + yrow + q * RPP_Y;
         if (gj < L.Cin) oky |= 1u << q;
-        offy[q] = (uint32_t)min(gj, L.Cin - 1) * HWi;
+        if constexpr (YROWS) {
+            const int jj = min(gj, L.Cin - 1), cj = jj / L.rR, rr = jj - cj * L.rR;
+            const int khq = rr / L.rKW, kwq = rr - khq * L.rKW;
+            tapq[q] = ((khq - L.pad) & 0xffff) | ((kwq - L.pad) << 16);
+            offy[q] = (uint32_t)cj * HWi;
+        } else {
+            offy[q] = (uint32_t)min(gj, L.Cin - 1) * HWi;
+        }
     }
     f32x16 acc[MTM][MTN];
 #pragma unroll
@@ -135,7 +150,19 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradIt
             const uint32_t n = in ? P / L.HWo : 0u;
             const uint32_t p = in ? P - n * L.HWo : 0u;
             size_t base;
-            if constexpr (YSHIFT) {
+            if constexpr (YROWS) {
+                const int oh = (int)(p / (uint32_t)L.Wout), ow = (int)(p - (uint32_t)oh * L.Wout);
+                const int ihb = oh * L.stride, iwb = ow * L.stride;
+                base = (size_t)n * L.rCin * HWi;
+                okyc = 0;
+#pragma unroll
+                for (int q = 0; q < PASS_Y; ++q) {
+                    const int ih = ihb + (int)(short)(tapq[q] & 0xffff), iw = iwb + (tapq[q] >> 16);
+                    const bool inq = in && ih >= 0 && ih < L.Hin && iw >= 0 && iw < L.Win;
+                    okyc |= (inq ? 1u : 0u) << q;
+                    ry[q][0] = PLEAS_GLOBAL(L.ip)[base + offy[q] + (inq ? (size_t)ih * L.Win + iw : 0)];
+                }
+            } else if constexpr (YSHIFT) {
                 const int oh = (int)(p / (uint32_t)L.Wout), ow = (int)(p - (uint32_t)oh * L.Wout);
                 const int ih = oh * L.stride + dh, iw = ow * L.stride + dw;
                 in = in && ih >= 0 && ih < L.Hin && iw >= 0 && iw < L.Win;
@@ -144,7 +171,9 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradIt
                 base = (size_t)n * L.Cin * HWi + p;
             }
             kiny = in;
-            if constexpr (YMODE == 2) {
+            if constexpr (YROWS) {
+                // loaded above, row by row
+            } else if constexpr (YMODE == 2) {
                 // whatever lies outside the tensor lies outside its image, i.e. at an output pixel whose residual is zeroed:
                 // only the run that straddles the tensor's first / last float goes element by element, clamped
                 const int b0 = (int)base + delta;
@@ -190,7 +219,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradIt
         }
 #pragma unroll
         for (int q = 0; q < PASS_Y; ++q) {
-            const bool ok = kiny && ((oky >> q) & 1u);
+            const bool ok = (YROWS ? ((okyc >> q) & 1u) != 0 : kiny) && ((oky >> q) & 1u);
             const int row = yrow + q * RPP_Y;
             if constexpr (YMODE == 2) {
                 const bool rowok = (oky >> q) & 1u;
@@ -308,7 +337,10 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradIt
 template <int TM, int TN>
 __device__ __forceinline__ void wgrad_dispatch(const WgradLayerDev& L, const WgradItemDev& it, float* smem) {
     const bool xs = L.variant & 4, ys = L.variant & 8;
-    if (L.variant & 16) wgrad_tile<TM, TN, 4, 2>(L, it, smem);
+    if (L.variant & 32) {
+        if (xs) wgrad_tile<TM, TN, 1, 3>(L, it, smem);
+        else wgrad_tile<TM, TN, 4, 3>(L, it, smem);
+    } else if (L.variant & 16) wgrad_tile<TM, TN, 4, 2>(L, it, smem);
     else if (!xs && !ys) wgrad_tile<TM, TN, 4, 0>(L, it, smem);
     else if (!xs && ys) wgrad_tile<TM, TN, 4, 1>(L, it, smem);
     else if (xs && !ys) wgrad_tile<TM, TN, 1, 0>(L, it, smem);
@@ -493,18 +525,28 @@ static int build_wgrad_plan(WgradPlan& P, const pleas_wgrad_layer* ly, int n) {
         d.HWo = (uint32_t)HWo;
         d.Ktot = (uint32_t)K;
         d.flags = l.flags;
-        const int R = l.KH * l.KW;
-        const int TM = l.Cout > 64 ? 128 : 64, TN = l.Cin > 64 ? 128 : 64;
-        const bool ydirect = R == 1 && l.stride == 1 && l.pad == 0;
+        int R = l.KH * l.KW;
+        // fewer than 16 input channels (the 3-channel stem): one tile row per (channel, tap) instead of one tap per item with
+        // 3 of 64 rows alive -- the layer is planned as the 1x1 view [Cout][Cin * R] of its own gradient
+        const bool virt = l.Cin < 16 && R > 1 && !(l.flags & PLEAS_WGRAD_KPOS_MAJOR) && (int64_t)l.Cin * R < (1 << 20);
+        int Cin = l.Cin;
+        d.rCin = l.Cin; d.rKW = l.KW; d.rR = R;
+        if (virt) {
+            Cin = l.Cin * R;
+            R = 1;
+            d.Cin = Cin; d.KH = d.KW = 1;
+        }
+        const int TM = l.Cout > 64 ? 128 : 64, TN = Cin > 64 ? 128 : 64;
+        const bool ydirect = !virt && R == 1 && l.stride == 1 && l.pad == 0;
         const bool xvec = HWo % 4 == 0;
         // direct Y shares X's vector width, so it also needs HWi == HWo (true for 1x1 stride 1)
-        d.variant = (TM == 64 ? 1 : 0) | (TN == 64 ? 2 : 0) | (xvec ? 0 : 4) | (ydirect ? 0 : 8);
+        d.variant = (TM == 64 ? 1 : 0) | (TN == 64 ? 2 : 0) | (xvec ? 0 : 4) | (ydirect ? 0 : 8) | (virt ? 32 : 0);
         // stride-1 "same" k x k layers on images with HW % 4 == 0: the shifted operand comes through aligned 16-byte loads
         // (PLEAS_WGRAD_VECSHIFT=0 keeps the one-pixel-per-load form for A/B)
         static const bool vecshift = !(std::getenv("PLEAS_WGRAD_VECSHIFT") && std::atoi(std::getenv("PLEAS_WGRAD_VECSHIFT")) == 0);
         const int64_t total = (int64_t)l.N * l.Cin * HWi;
         d.total = 0;
-        if (vecshift && !ydirect && xvec && l.stride == 1 && l.KH == l.KW && 2 * l.pad == l.KH - 1 && HWi == HWo &&
+        if (vecshift && !virt && !ydirect && xvec && l.stride == 1 && l.KH == l.KW && 2 * l.pad == l.KH - 1 && HWi == HWo &&
             total < (1ll << 31)) {
             d.variant |= 16;
             d.total = (int)total;
@@ -515,8 +557,8 @@ static int build_wgrad_plan(WgradPlan& P, const pleas_wgrad_layer* ly, int n) {
         d.S = S;
         if (S > 1) {
             slab_off[i] = slabs;
-            slabs += (size_t)S * l.Cout * l.Cin * R;
-            const int nb = (int)ceil_div((int64_t)l.Cout * l.Cin * R, 256);
+            slabs += (size_t)S * l.Cout * Cin * R;
+            const int nb = (int)ceil_div((int64_t)l.Cout * Cin * R, 256);
             for (int b = 0; b < nb; ++b) {
                 P.blk_layer.push_back(i);
                 P.blk_begin.push_back(blk);
@@ -524,9 +566,9 @@ static int build_wgrad_plan(WgradPlan& P, const pleas_wgrad_layer* ly, int n) {
             blk += nb;
         }
         P.lds = std::max(P.lds, (size_t)2 * (TM + TN) * cLds * sizeof(float));
-        P.flops += 2.0 * l.Cout * (double)l.Cin * R * (double)K;
+        P.flops += 2.0 * l.Cout * (double)Cin * R * (double)K;
         P.bytes += ((double)l.Cout * K + (double)l.Cin * l.N * HWi) * sizeof(float);
-        const int tms = (int)ceil_div(l.Cout, TM), tns = (int)ceil_div(l.Cin, TN);
+        const int tms = (int)ceil_div(l.Cout, TM), tns = (int)ceil_div(Cin, TN);
         for (int s = 0; s < S; ++s)
             for (int r = 0; r < R; ++r)
                 for (int tm = 0; tm < tms; ++tm)

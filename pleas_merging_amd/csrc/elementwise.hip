@@ -478,3 +478,34 @@ extern "C" int pleas_sqerr(const float* a, const float* b, int64_t n, float scal
     PLEAS_LAUNCH_CHECK("sqerr_final_kernel");
     return PLEAS_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Bias gradient of a merged layer: gb[c] = sum over samples and pixels of resid[n][c][p] (pleas_merging.py:287, the bias
+// node of autograd's backward).  One workgroup per channel, fixed summation order (thread t takes elements t, t + 256, ...
+// of the channel's (n, p) range, then a tree over the threads): deterministic, no atomics.
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, int N, int C, long long HW,
+                                                          float* __restrict__ out) {
+    __shared__ float red[256];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const long long total = (long long)N * HW;
+    float s = 0.f;
+    for (long long i = tid; i < total; i += 256) {
+        const long long n = i / HW, p = i - n * HW;
+        s += x[((size_t)n * C + c) * HW + p];
+    }
+    red[tid] = s;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (tid < off) red[tid] += red[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) out[c] = red[0];
+}
+
+extern "C" int pleas_channel_sum(const float* x, int N, int C, int64_t HW, float* out, void* stream_) {
+    if (!x || !out) return bad_arg("channel_sum: null pointer");
+    if (N <= 0 || C <= 0 || HW <= 0) return bad_arg("channel_sum: empty tensor");
+    hipLaunchKernelGGL(channel_sum_kernel, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream_, x, N, C, (long long)HW, out);
+    PLEAS_LAUNCH_CHECK("channel_sum_kernel");
+    return PLEAS_OK;
+}

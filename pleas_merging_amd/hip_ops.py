@@ -76,6 +76,27 @@ def role_stream(device: torch.device, role: str, priority: int = 0) -> torch.cud
     return st
 
 
+def to_device_async(x: torch.Tensor, device: torch.device) -> torch.Tensor:
+    """``x`` on ``device``, usable on the CURRENT stream.  The reference moves every batch inside its loops with a blocking
+    ``x.cuda()`` (activation_matching.py:121, pleas_merging.py:266).  A PINNED host tensor is copied on a dedicated copy
+    stream ("h2d") instead: the host enqueues a loop's kernels far ahead of the GPU, so the copy of batch b + 1 runs while
+    batch b computes, and the current stream only waits for the copy's event.  Pageable host tensors and device tensors
+    take the ordinary path."""
+    device = torch.device(device)
+    if x.device == device:
+        return x
+    if x.is_cuda or not x.is_pinned():
+        return x.to(device, non_blocking=True)
+    copy, cur = role_stream(device, "h2d"), torch.cuda.current_stream(device)
+    with torch.cuda.stream(copy):
+        d = x.to(device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(copy)
+    cur.wait_event(ev)
+    d.record_stream(cur)      # allocated in the copy stream's pool, consumed on `cur`
+    return d
+
+
 class Workspace:
     """Grow-only device scratch buffer, one per (device, stream): two streams that run ``gram_accum`` / ``sqerr`` side
     by side must not share scratch.  Callers never see hidden allocations inside the C library."""
@@ -508,6 +529,17 @@ def masked_adam(p: torch.Tensor, g: torch.Tensor, mask: Optional[torch.Tensor], 
     rc = _lib.lib().pleas_masked_adam(p.data_ptr(), g.data_ptr(), mask.data_ptr() if mask is not None else None,
                                       m.data_ptr(), v.data_ptr(), n, lr, b1, b2, eps, step, _stream())
     check(rc, "pleas_masked_adam")
+
+
+def channel_sum(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """``out[c] = sum over n, p of x[n][c][p]`` (``x`` [N, C, ...] contiguous fp32): the bias gradient of a merged layer from
+    its residual (reference: the bias node of ``total.backward()``, pleas_merging.py:287)."""
+    _need_gpu(x, out)
+    if not x.is_contiguous() or x.dim() < 2 or out.numel() != x.shape[1] or not out.is_contiguous():
+        raise PleasHipError("channel_sum: x must be contiguous [N, C, ...] and out hold C floats")
+    check(_lib.lib().pleas_channel_sum(x.data_ptr(), x.shape[0], x.shape[1], math.prod(x.shape[2:]), out.data_ptr(), _stream()),
+          "pleas_channel_sum")
+    return out
 
 
 def sqerr(a: torch.Tensor, b: torch.Tensor, scale: float, out: torch.Tensor, accumulate: bool = False,

@@ -580,7 +580,7 @@ def accumulate_costs_fused(spec: PermutationSpec, model1: nn.Module, model2: nn.
     with torch.inference_mode(), torch.cuda.stream(work):
         run: List[torch.Tensor] = []
         for x, _ in shard_batches(dataloader, num_batches, *take):
-            x = x.to(device, non_blocking=True)
+            x = hip_ops.to_device_async(x, device)      # pinned host batches: copied on a copy stream, beside the previous forward
             if single:
                 per_forward = 1
             elif per_forward is None:

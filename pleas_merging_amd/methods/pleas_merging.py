@@ -384,7 +384,7 @@ class FrozenSources:
     def launch(self, x: torch.Tensor, parts: int = 1, after_current: bool = True):
         """Enqueue both source forwards for ``x``; returns the generation (device batch, taps, events) the update will
         consume.  ``parts`` > 1: ``x`` is that many batches back to back, each of which is sample-sliced on its own."""
-        x = x.to(self.device, non_blocking=True)
+        x = self.ops.to_device_async(x, self.device)
         if self._slice_batch:
             if parts > 1 and self.world > 1:
                 h = x.shape[0] // parts
@@ -401,7 +401,8 @@ class FrozenSources:
         """One source forward for several batches; their generations (views of its taps) join the queue."""
         first = self._side_streams[0] if (self._side_streams is not None and not after_current) else None
         with (torch.cuda.stream(first) if first is not None else contextlib.nullcontext()):
-            both = torch.cat([b.to(self.device, non_blocking=True) for b in run], 0)
+            # pinned host batches travel on a copy stream while the previous group's updates run (hip_ops.to_device_async)
+            both = torch.cat([self.ops.to_device_async(b, self.device) for b in run], 0)
             xdev, (in1, out1), (in2, out2), events = self.launch(both, parts=len(run), after_current=after_current)
         n = xdev.shape[0] // len(run)
         for i, b in enumerate(run):
@@ -519,7 +520,7 @@ class PleasFitter:
         # two updates of that shape in the tap addresses alone -- see _step.
         self._buffers: Dict[tuple, Dict[tuple, Tuple[torch.Tensor, torch.Tensor]]] = {}
         self._bufs: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}      # (layer, half-batch) -> (merged input, residual)
-        self._replay = None      # (shape key, names, merge table, forward table, vendor / bias work) of the latest full update
+        self._replay = None      # (shape key, names, merge table, forward table, bias work) of the latest full update
         self.fast_updates = 0    # updates applied by patching the tables (the rest took the layer-by-layer path)
 
         layers = {n: m for n, m in model3.named_modules() if isinstance(m, (nn.Conv2d, nn.Linear))}
@@ -664,24 +665,14 @@ class PleasFitter:
                          flags=ops.FwdBatch.KPOS_MAJOR if plan.kpos else 0)
             self._fwd_rows.append(idx)
             gw, gb = (plan.gw, plan.gb) if h == 0 else (plan.gw2, plan.gb2)   # second half: its own arena, added in _step
-            if ip.shape[1] >= 16 or linear:
-                self.wgrad.add(resid, ip, gw, *geo, flags=ops.WgradBatch.KPOS_MAJOR if plan.kpos else 0)
-            else:   # the stem (3 input channels): narrower than the tile's 16-channel chunks -> vendor weight gradient
-                self._vendor_wgrad.append((resid, ip, plan, gw))
+            # every layer, the 3-channel stem included (its rows are (channel, tap) pairs: "virtual channels", csrc/conv.hip)
+            self.wgrad.add(resid, ip, gw, *geo, flags=ops.WgradBatch.KPOS_MAJOR if plan.kpos else 0)
             if gb is not None:
                 self._bias_grads.append((resid, plan, gb))
 
-    def _finish_vendor_parts(self) -> None:
-        for resid, ip, plan, gw in self._vendor_wgrad:
-            mod = plan.mod
-            if plan.is_conv:
-                g = torch.ops.aten.convolution_backward(resid, ip, plan.w, None, mod.stride, mod.padding, mod.dilation,
-                                                        False, [0, 0], mod.groups, [False, True, False])[1]
-                gw.copy_(g)
-            else:
-                torch.mm(resid.reshape(-1, resid.shape[-1]).t(), ip.reshape(-1, ip.shape[-1]), out=gw)
-        for resid, plan, gb in self._bias_grads:
-            gb.copy_(resid.sum((0, 2, 3)) if plan.is_conv else resid.reshape(-1, resid.shape[-1]).sum(0))
+    def _bias_gradients(self) -> None:
+        for resid, plan, gb in self._bias_grads:      # HIP: one deterministic row-sum launch per biased layer
+            self.ops.channel_sum(resid if resid.dim() > 1 else resid.reshape(1, -1), gb)
 
     def _begin_update(self, x: torch.Tensor, next_x: Optional[torch.Tensor]) -> None:
         """Taps of ``x`` become current (running its sources now unless they were prefetched); the sources of
@@ -821,7 +812,7 @@ class PleasFitter:
             if any(p is None for p in ptrs):
                 replay = None
         if replay is not None:
-            _, names, merge_tab, fwd_tab, self._vendor_wgrad, self._bias_grads = replay
+            _, names, merge_tab, fwd_tab, self._bias_grads = replay
             merge_tab["w1"][:], merge_tab["w2"][:], fwd_tab["o1"][:], fwd_tab["o2"][:] = ptrs
             with self.ops.pin_stream():
                 self.merge.relaunch()
@@ -830,7 +821,7 @@ class PleasFitter:
         else:
             self._replay = None
             self._bufs = self._buffers.setdefault(key, {}) if key else {}
-            self._fwd_rows, self._vendor_wgrad, self._bias_grads = [], [], []
+            self._fwd_rows, self._bias_grads = [], []
             complete = bool(key)
             with self.ops.pin_stream():
                 for idx, plan in enumerate(self.plans):
@@ -851,7 +842,7 @@ class PleasFitter:
                 self.loss_now.index_add_(0, self._fwd_index, self._fwd_loss)
             else:
                 self.loss_now.index_copy_(0, self._fwd_index, self._fwd_loss)
-        self._finish_vendor_parts()
+        self._bias_gradients()
         if replay is not None:
             with self.ops.pin_stream():
                 self.wgrad.relaunch()
@@ -862,7 +853,7 @@ class PleasFitter:
                 names = tuple(self.plans[i].name for i in self._fwd_rows)
                 merge_tab, fwd_tab = self.merge.table(), self.fwd.table()
                 if merge_tab is not None and fwd_tab is not None and len(merge_tab) == len(fwd_tab) == len(names):
-                    self._replay = (key, names, merge_tab, fwd_tab, self._vendor_wgrad, self._bias_grads)
+                    self._replay = (key, names, merge_tab, fwd_tab, self._bias_grads)
         if self.stacked:
             self.g.add_(self.g2)     # second half-batch's gradients (same launch, own arena)
         lr = self.lrs[min(self.step_count, len(self.lrs) - 1)]

@@ -593,6 +593,11 @@ WGRAD_CASES = [
     (4, 256, 128, 28, 28, 1, 2, 0),    # 1x1 stride 2 (downsample)
     (2, 64, 64, 56, 56, 3, 1, 1),      # long pixel axis -> split into slabs + reduce
     (16, 64, 32, 1, 1, 1, 1, 0),       # linear-like (HW = 1)
+    # fewer than 16 input channels: rows of the tile are (channel, tap) pairs ("virtual channels")
+    (4, 64, 3, 224, 224, 7, 2, 3),     # the ResNet stem (K = 147, slabs + reduce)
+    (2, 8, 3, 9, 11, 3, 1, 1),         # tiny, ragged, one tile
+    (2, 20, 5, 12, 12, 5, 2, 2),       # 5x5 stride 2: 125 virtual channels, HWo = 36
+    (3, 70, 15, 7, 7, 3, 1, 1),        # 135 virtual channels: TN = 128, HW = 49 (scalar residual loads)
 ]
 
 
@@ -883,6 +888,19 @@ def test_fwd_batch_flat_forms_random_geometries(ops):
     for i, (keep, want, want_loss, geo) in enumerate(cases):
         assert _rel(keep[7].cpu(), want) < 5e-6, (geo, _rel(keep[7].cpu(), want))
         assert abs(float(loss[i]) - want_loss) < 1e-5 * max(1.0, want_loss), geo
+
+
+def test_channel_sum_is_the_bias_gradient(ops):
+    g = torch.Generator().manual_seed(3)
+    for shape in [(16, 1000), (4, 70, 14, 14), (3, 9, 5, 7), (1, 1, 1, 1), (300, 5)]:
+        x = torch.randn(shape, generator=g)
+        out = torch.full((shape[1],), float("nan"), device="cuda")
+        ops.channel_sum(x.cuda(), out)
+        want = x.double().sum(dim=[d for d in range(x.dim()) if d != 1])
+        assert _rel(out.cpu(), want) < 2e-6, shape
+        again = torch.empty_like(out)
+        ops.channel_sum(x.cuda(), again)
+        assert torch.equal(out, again)      # deterministic
 
 
 def test_fwd_batch_streamed_form(ops):
