@@ -128,41 +128,61 @@ __device__ __forceinline__ void gram_tile(const GramGeom& g, float* smem, const 
     // and masked when written to LDS, so all loads of a chunk stay in flight behind the MFMAs
     // (a predicated load makes hipcc branch and wait vmcnt(0) per load).
     unsigned rows_ok_a = 0, rows_ok_b = 0;
-    size_t row_off_a[PASSES], row_off_b[PASSES];
+    // BYTE offsets in 32 bits (the plan builders refuse nodes of 2^30 elements or more): a load is then the uniform base
+    // pointer + one 32-bit vector offset, i.e. ONE vector add per load instead of a 64-bit add chain
+    uint32_t row_off_a[PASSES], row_off_b[PASSES];
 #pragma unroll
     for (int q = 0; q < PASSES; ++q) {
         const int row = srow + q * ROWS_PER_PASS;
         const int gi = i0 + row, gj = j0 + row;
         if (gi < g.C) rows_ok_a |= 1u << q;
         if (gj < g.C) rows_ok_b |= 1u << q;
-        row_off_a[q] = (size_t)min(gi, g.C - 1) * g.HW;
-        row_off_b[q] = (size_t)min(gj, g.C - 1) * g.HW;
+        row_off_a[q] = 4u * ((uint32_t)min(gi, g.C - 1) * g.HW);
+        row_off_b[q] = 4u * ((uint32_t)min(gj, g.C - 1) * g.HW);
     }
     bool staged_kin = false;
-    bool staged_full = false;                                         // SPLIT: the staged chunk lies inside K (block-uniform)
-    const bool interior = i0 + TILE <= g.C && j0 + TILE <= g.C;       // SPLIT: every row of both operand tiles exists
+    bool staged_full = false;                                         // the staged chunk lies inside K (block-uniform)
+    const bool interior = i0 + TILE <= g.C && j0 + TILE <= g.C;       // every row of both operand tiles exists
+    // (sample, pixel) of this thread's k in the chunk being loaded: ONE division per work item, then steps of kBK
+    // (chunks are loaded in order); images smaller than a chunk keep the division
+    uint32_t lk = (uint32_t)c_begin * kBK + scol;
+    uint32_t ln = lk / g.HW, lp = lk - ln * g.HW;
+    const char* xb = reinterpret_cast<const char*>(g.x);
+    const char* yb = reinterpret_cast<const char*>(g.y);
     auto load_chunk = [&](int c) {
-        const uint32_t k = (uint32_t)c * kBK + scol;
+        const uint32_t k = lk;
         const bool kin = k < g.Ktot;
-        if constexpr (SPLIT) staged_full = (uint32_t)(c + 1) * kBK <= g.Ktot;
-        const uint32_t n = kin ? k / g.HW : 0u;
-        const uint32_t p = kin ? k - n * g.HW : 0u;
-        const size_t base = (size_t)n * g.C * g.HW + p;
+        staged_full = (uint32_t)(c + 1) * kBK <= g.Ktot;
+        const uint32_t n = kin ? ln : 0u;
+        const uint32_t p = kin ? lp : 0u;
+        const uint32_t base = 4u * (n * (uint32_t)g.C * g.HW + p);
         staged_kin = kin;
 #pragma unroll
         for (int q = 0; q < PASSES; ++q) {
             if constexpr (VEC == 4) {
-                const f32x4 va = *(const __attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL(g.x) + base + row_off_a[q]);
-                const f32x4 vb = *(const __attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL(g.y) + base + row_off_b[q]);
+                const f32x4 va = *(const __attribute__((address_space(1))) f32x4*)(xb + (base + row_off_a[q]));
+                const f32x4 vb = *(const __attribute__((address_space(1))) f32x4*)(yb + (base + row_off_b[q]));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     ra.v[q][e] = va[e];
                     rb.v[q][e] = vb[e];
                 }
             } else {
-                ra.v[q][0] = PLEAS_GLOBAL(g.x)[base + row_off_a[q]];
-                rb.v[q][0] = PLEAS_GLOBAL(g.y)[base + row_off_b[q]];
+                ra.v[q][0] = *(const __attribute__((address_space(1))) float*)(xb + (base + row_off_a[q]));
+                rb.v[q][0] = *(const __attribute__((address_space(1))) float*)(yb + (base + row_off_b[q]));
             }
+        }
+        // next chunk
+        lk += kBK;
+        if (g.HW >= (uint32_t)kBK) {
+            lp += kBK;
+            if (lp >= g.HW) {
+                lp -= g.HW;
+                ++ln;
+            }
+        } else {
+            ln = lk / g.HW;
+            lp = lk - ln * g.HW;
         }
     };
     auto store_chunk = [&](int buf) {
@@ -173,8 +193,8 @@ __device__ __forceinline__ void gram_tile(const GramGeom& g, float* smem, const 
             const int row = srow + q * ROWS_PER_PASS;
             const bool oka = staged_kin && ((rows_ok_a >> q) & 1u);
             const bool okb = staged_kin && ((rows_ok_b >> q) & 1u);
-            // SPLIT: a tile inside the matrix on a chunk inside K needs no masking (block-uniform test, no selects)
-            if (!(SPLIT && interior && staged_full)) {
+            // a tile inside the matrix on a chunk inside K needs no masking (block-uniform test, no selects)
+            if (!(interior && staged_full)) {
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
                     ra.v[q][e] = oka ? ra.v[q][e] : 0.f;
@@ -604,6 +624,7 @@ extern "C" int pleas_gram_accum(const float* x, const float* y, int B, int C, in
     if (!x || !y || !acc) return bad_arg("null tensor pointer");
     if (B <= 0 || C <= 0 || HW <= 0) return bad_arg("B, C, HW must be positive");
     if ((int64_t)B * HW >= (1ll << 31) || HW >= (1ll << 31)) return bad_arg("B*HW must be < 2^31");
+    if ((int64_t)B * C * HW >= (1ll << 30)) return bad_arg("B*C*HW must be < 2^30 (the tile addresses an operand with 32-bit byte offsets)");
     if (epilogue != PLEAS_EPI_INNER && epilogue != PLEAS_EPI_NEG_CDIST) return bad_arg("epilogue");
     const bool aligned = (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
     const GramPlan p = make_plan(B, C, HW, aligned);
@@ -708,6 +729,7 @@ static int build_batch_plan(BatchPlan& P, const pleas_gram_node* nd, int n, floa
         const int B = nd[i].B, C = nd[i].C;
         const int64_t HW = nd[i].HW;
         if (B <= 0 || C <= 0 || HW <= 0 || (int64_t)B * HW >= (1ll << 31)) return bad_arg("gram_batch: node shape");
+        if ((int64_t)B * C * HW >= (1ll << 30)) return bad_arg("gram_batch: a node must hold fewer than 2^30 elements per batch");
         if (nd[i].group < 0 || nd[i].group >= n_groups || group_C[nd[i].group] != C) return bad_arg("gram_batch: node group");
         const int tile = C > 64 ? 128 : 64;
         const int vec = (HW % 4 == 0) ? 4 : 1;  // operand alignment is checked per call
