@@ -41,11 +41,12 @@ def read(path, kernels):
 def main():
     tag = sys.argv[1]
     commit = sys.argv[sys.argv.index("--commit") + 1] if "--commit" in sys.argv else None
+    rnd = sys.argv[sys.argv.index("--round") + 1] if "--round" in sys.argv else "r03"      # file prefix of the GPU call's outputs
     out_dir = os.path.join(ROOT, "gpurun_out")
-    shas = json.load(open(os.path.join(out_dir, "r03_%s_source_sha.json" % tag)))
+    shas = json.load(open(os.path.join(out_dir, "%s_%s_source_sha.json" % (rnd, tag))))
     for key, (fname, kernels, sources, algo, what) in KERNELS.items():
-        fetch_p = os.path.join(out_dir, "r03_%s_pmc_%s_FETCH_SIZE.txt" % (tag, key))
-        write_p = os.path.join(out_dir, "r03_%s_pmc_%s_WRITE_SIZE.txt" % (tag, key))
+        fetch_p = os.path.join(out_dir, "%s_%s_pmc_%s_FETCH_SIZE.txt" % (rnd, tag, key))
+        write_p = os.path.join(out_dir, "%s_%s_pmc_%s_WRITE_SIZE.txt" % (rnd, tag, key))
         if not (os.path.exists(fetch_p) and os.path.exists(write_p)):
             print("skip", key, "(no PMC summary for tag %s)" % tag)
             continue
@@ -54,8 +55,8 @@ def main():
         if fetch <= 0:
             print("skip", key, "(kernel not found in the summary)")
             continue
-        blob = {"kernel": " + ".join("pleas::" + k for k in kernels), "round": 3, "tag": tag, "commit": commit, "what": what,
-                "command": "tools/run_final_profile_r03.sh %s (standalone replay; rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in "
+        blob = {"kernel": " + ".join("pleas::" + k for k in kernels), "round": int(rnd[1:]), "tag": tag, "commit": commit, "what": what,
+                "command": "tools/" + ("run_final_profile_r03.sh" if rnd == "r03" else rnd + "/final_profile.sh") + " %s (standalone replay; rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in "
                            "separate passes, mean per dispatch, summed over the launch's kernels)" % tag,
                 "fetch_size_kb_raw": fetch, "write_size_kb_raw": write, "fetch_size_kb_raw_per_kernel": per_f,
                 "write_size_kb_raw_per_kernel": per_w,
