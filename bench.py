@@ -82,8 +82,9 @@ def parse(argv=None):
     ap.add_argument("--miopen-find", type=int, default=0, help="1: torch.backends.cudnn.benchmark = True, i.e. the vendor "
                     "library times its candidate convolution kernels per configuration (Find mode) instead of taking the "
                     "immediate-mode pick; costs seconds per new configuration in the first warm-up job")
-    ap.add_argument("--shard-optimizer", action="store_true", help="data parallel: reduce-scatter the gradient arena, Adam on "
-                    "this rank's 1/world slice, all-gather the parameters (instead of all-reduce + full Adam on every rank)")
+    ap.add_argument("--no-shard-optimizer", action="store_true", help="data parallel: all-reduce + full Adam on every rank "
+                    "instead of the default (reduce-scatter the gradient arena, Adam on this rank's 1/world slice, all-gather "
+                    "the parameters)")
     ap.add_argument("--prefetch-memory", type=float, default=0.7, help="share of the free HBM the prefetched taps may take")
     ap.add_argument("--emulate-allreduce-us", type=float, default=0.0,
                     help="with --emulate-world: hold the update stream this long where the gradient all-reduce would run")
@@ -623,7 +624,7 @@ def main():
         os.environ["PLEAS_EMULATE_ALLREDUCE_US"] = str(args.emulate_allreduce_us)
         dp = True
     cfg = {"dp": dp, "ratio": args.ratio, "prefetch_groups": args.prefetch_groups, "prefetch_memory": args.prefetch_memory,
-           "shard_optimizer": args.shard_optimizer, "gc": args.gc, "match_mode": args.match_mode, "match_per_forward": args.match_per_forward or None, "sources_per_forward": (args.sources_per_forward * ranks) or None, "lookahead": None if args.lookahead < 0 else bool(args.lookahead)}
+           "shard_optimizer": not args.no_shard_optimizer, "gc": args.gc, "match_mode": args.match_mode, "match_per_forward": args.match_per_forward or None, "sources_per_forward": (args.sources_per_forward * ranks) or None, "lookahead": None if args.lookahead < 0 else bool(args.lookahead)}
     log("spec (%d groups, %.2f s on the host, outside `value`) + %d synthetic batches resident" % (len(spec), spec_s, len(pool.items)))
 
     def job(phases=None):

@@ -495,7 +495,8 @@ class PleasFitter:
     def __init__(self, model1, model2, model3, spec, perm, costs, budget_ratios, max_steps: int, lr: float = 5e-4,
                  separate_classifier=False, num_classes=1000, model_type="rn50", data_parallel: bool = False,
                  fuse_sources: bool = True, overlap_sources: bool = True, fused_sources=None,
-                 sources: Optional[FrozenSources] = None, merging: str = "perm_gradmask", shard_optimizer: bool = False):
+                 sources: Optional[FrozenSources] = None, merging: str = "perm_gradmask",
+                 shard_optimizer: Optional[bool] = None):
         from .. import hip_ops
 
         self.ops = hip_ops
@@ -534,11 +535,15 @@ class PleasFitter:
         self.layer_modules = layers
         pad4 = lambda n: (n + 3) // 4 * 4   # every tensor starts 16-byte aligned inside the arenas (vector loads)
         total = sum(pad4(p.numel()) for m in layers.values() for p in m.parameters())
-        # shard_optimizer (option, data parallel): rank r keeps the Adam moments of -- and applies the update to -- the r-th
+        # shard_optimizer (data parallel; default ON there since round 4, DESIGN.md section 5: the per-update exchange is as
+        # long as a rank's per-update compute, so nothing that does not shrink with the ranks may stay on the update's
+        # path): rank r keeps the Adam moments of -- and applies the update to -- the r-th
         # 1/world slice of the flat arena only: reduce-scatter of the gradients, Adam on the slice, all-gather of the
         # parameters.  Same bytes on the links as the all-reduce, 1/world of the optimiser's work and state per rank.
         from .activation_matching import _force_collectives
 
+        if shard_optimizer is None:
+            shard_optimizer = True
         self.shard_optimizer = bool(shard_optimizer) and (self.world > 1 or _force_collectives())
         if self.shard_optimizer:
             total = (total + 4 * self.world - 1) // (4 * self.world) * (4 * self.world)    # equal, 16-byte aligned slices
