@@ -115,7 +115,15 @@ __device__ __forceinline__ void gram_tile(const GramGeom& g, float* smem, const 
 #pragma unroll
     for (int q = 0; q < PASSES; ++q) sqa[q] = sqb[q] = sma[q] = smb[q] = 0.f;
     const bool want_sums = g.sums != 0;   // block-uniform
-    const bool norm_a = tn == 0, norm_b = tm == 0;
+    // EVERY tile does the row-norm / row-sum arithmetic, although only the first block column / row stores it: the tiles of
+    // one (node, K range) stream the same operand rows through one XCD's L2 and stay in step only if they do the same work
+    // per chunk.  Round 3 let the other tiles skip it (commit 4ffa37f): they ran ahead, and the launch fetched 15.2 GB
+    // instead of 9.9 GB per ResNet-101 batch for no gain in time (profiles/r04_gram_traffic_bisect.txt; build with
+    // -DPLEAS_GRAM_NORMS_ALWAYS=0 to reproduce).
+#ifndef PLEAS_GRAM_NORMS_ALWAYS
+#define PLEAS_GRAM_NORMS_ALWAYS 1
+#endif
+    const bool norm_a = tn == 0 || PLEAS_GRAM_NORMS_ALWAYS, norm_b = tm == 0 || PLEAS_GRAM_NORMS_ALWAYS;
     f32x16 acc[MT][MT];
 #pragma unroll
     for (int a = 0; a < MT; ++a)
