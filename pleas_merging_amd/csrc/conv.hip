@@ -117,15 +117,54 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradIt
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     bool kinx = false, kiny = false;
+    // (sample, pixel, row, column) of this thread's first pixel of the chunk being loaded, for the X and the Y operand:
+    // ONE set of divisions per work item, then steps of cBK pixels (chunks are loaded in order).  The divisions per chunk --
+    // two to four, ~25 vector instructions each -- were a third of the loop's vector work, and vector instructions are what
+    // the fp32 MFMAs wait for.  Images smaller than a chunk keep the divisions.
+    struct Cursor { uint32_t P, n, p; int oh, ow; };
+    constexpr bool XHW = YMODE == 2, YHW = YSHIFT || YROWS;      // who needs (row, column)
+    const bool step_ok = L.HWo >= (uint32_t)cBK;
+    const int q32 = cBK / L.Wout, r32 = cBK - q32 * L.Wout;
+    auto cur_at = [&](Cursor& k, uint32_t P, bool hw) {
+        k.P = P;
+        k.n = P / L.HWo;
+        k.p = P - k.n * L.HWo;
+        k.oh = k.ow = 0;
+        if (hw) {
+            k.oh = (int)(k.p / (uint32_t)L.Wout);
+            k.ow = (int)(k.p - (uint32_t)k.oh * L.Wout);
+        }
+    };
+    auto cur_step = [&](Cursor& k, bool hw) {
+        if (!step_ok) {
+            cur_at(k, k.P + cBK, hw);
+            return;
+        }
+        k.P += cBK;
+        k.p += cBK;
+        if (hw) {
+            k.oh += q32;
+            k.ow += r32;
+            if (k.ow >= L.Wout) { k.ow -= L.Wout; ++k.oh; }
+        }
+        if (k.p >= L.HWo) {
+            k.p -= L.HWo;
+            ++k.n;
+            if (hw) k.oh -= L.Hout;
+        }
+    };
+    Cursor cx, cy;
+    cur_at(cx, (uint32_t)it.c_begin * cBK + xcol, XHW);
+    cur_at(cy, (uint32_t)it.c_begin * cBK + ycol, YHW);
     auto load_chunk = [&](int c) {
         {   // X: residual rows, direct
-            const uint32_t P = (uint32_t)c * cBK + xcol;
-            kinx = P < L.Ktot;
-            const uint32_t n = kinx ? P / L.HWo : 0u;
-            const uint32_t p = kinx ? P - n * L.HWo : 0u;
+            (void)c;
+            kinx = cx.P < L.Ktot;
+            const uint32_t n = kinx ? cx.n : 0u;
+            const uint32_t p = kinx ? cx.p : 0u;
             const size_t base = (size_t)n * L.Cout * L.HWo + p;
             if constexpr (YMODE == 2) {
-                int oh = (int)(p / (uint32_t)L.Wout), ow = (int)(p - (uint32_t)oh * L.Wout);
+                int oh = kinx ? cx.oh : 0, ow = kinx ? cx.ow : 0;
                 win = 0;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -145,13 +184,12 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradIt
             }
         }
         {   // Y: input rows, shifted by the kernel position (or direct for 1x1 stride 1)
-            const uint32_t P = (uint32_t)c * cBK + ycol;
-            bool in = P < L.Ktot;
-            const uint32_t n = in ? P / L.HWo : 0u;
-            const uint32_t p = in ? P - n * L.HWo : 0u;
+            bool in = cy.P < L.Ktot;
+            const uint32_t n = in ? cy.n : 0u;
+            const uint32_t p = in ? cy.p : 0u;
             size_t base;
             if constexpr (YROWS) {
-                const int oh = (int)(p / (uint32_t)L.Wout), ow = (int)(p - (uint32_t)oh * L.Wout);
+                const int oh = in ? cy.oh : 0, ow = in ? cy.ow : 0;
                 const int ihb = oh * L.stride, iwb = ow * L.stride;
                 base = (size_t)n * L.rCin * HWi;
                 okyc = 0;
@@ -163,7 +201,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradIt
                     ry[q][0] = PLEAS_GLOBAL(L.ip)[base + offy[q] + (inq ? (size_t)ih * L.Win + iw : 0)];
                 }
             } else if constexpr (YSHIFT) {
-                const int oh = (int)(p / (uint32_t)L.Wout), ow = (int)(p - (uint32_t)oh * L.Wout);
+                const int oh = in ? cy.oh : 0, ow = in ? cy.ow : 0;
                 const int ih = oh * L.stride + dh, iw = ow * L.stride + dw;
                 in = in && ih >= 0 && ih < L.Hin && iw >= 0 && iw < L.Win;
                 base = (size_t)n * L.Cin * HWi + (in ? (size_t)ih * L.Win + iw : 0);
@@ -201,6 +239,8 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradIt
                 }
             }
         }
+        cur_step(cx, XHW);
+        cur_step(cy, YHW);
     };
     auto store_chunk = [&](int buf) {
         float* a = As + buf * TM * cLds;

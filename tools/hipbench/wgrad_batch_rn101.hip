@@ -1,6 +1,6 @@
 // Standalone replay of the grouped weight-gradient launch on the exact ResNet-101 layer list
 // (tools/hipbench/rn101_layers.txt), batch 16: same kernels, same grid as one bench.py PLeaS update
-// (the stem's 3-channel layer goes to the vendor path in the product and is skipped here).
+// (argv[4] = 1 skips the 3-channel stem, as the launches before round 4 did: it went to the vendor's kernel then).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -15,7 +15,7 @@ int main(int argc, char** argv) {
     int n; fscanf(f, "%d", &n);
     std::vector<pleas_wgrad_layer> L; double flops = 0, bytes = 0;
     for (int i = 0; i < n; ++i) { int co, ci, h, w, k, s, p; fscanf(f, "%d %d %d %d %d %d %d", &co, &ci, &h, &w, &k, &s, &p);
-        if (ci < 16) continue;
+        if (ci < 16 && argc > 4 && atoi(argv[4]) == 1) continue;
         int ho = (h + 2 * p - k) / s + 1, wo = (w + 2 * p - k) / s + 1; size_t P = (size_t)N * ho * wo;
         pleas_wgrad_layer l{}; l.N = N; l.Cout = co; l.Cin = ci; l.Hin = h; l.Win = w; l.KH = l.KW = k; l.stride = s; l.pad = p;
         l.flags = (k > 1 && ci % 32 == 0) ? PLEAS_WGRAD_KPOS_MAJOR : 0;
