@@ -133,23 +133,27 @@ __device__ __forceinline__ void fwd_epilogue(const FwdLayerDev& L, const FwdItem
     // flight meanwhile) -> second batch issued -> first consumed -> second consumed.
     if (vec_ok) {
         f32x4 ta[NB][GB], tb[NB][GB];
-        // per-thread bases: the (sample, pixel group) part of every address is the same for all of the thread's channels, so
-        // a gather / store address is one 32 x 32 -> 64-bit multiply-add on top of it
-        const unsigned long long hw = L.HWo;
-        const unsigned long long gbase = (unsigned long long)gn * L.Csrc * hw + gp;
-        const unsigned long long rbase = ((unsigned long long)gn * L.Cout + i0 + (tid >> 5)) * hw + gp;
+        // per-thread bases: the (sample, pixel group) part of every address is the same for all of the thread's channels, so a
+        // gather / store address is the tensor's uniform base pointer + ONE 32-bit multiply-add in bytes (the plan builder
+        // refuses tensors of 4 GB and more)
+        const uint32_t hw4 = 4u * L.HWo;
+        const uint32_t gbase = 4u * (gn * (uint32_t)L.Csrc * L.HWo + gp);
+        const uint32_t rbase = 4u * ((gn * (uint32_t)L.Cout + (uint32_t)i0 + (uint32_t)(tid >> 5)) * L.HWo + gp);
+        const char* o1b = reinterpret_cast<const char*>(L.o1);
+        const char* o2b = reinterpret_cast<const char*>(L.o2);
+        char* rb_ = reinterpret_cast<char*>(L.resid);
         auto gather = [&](const int bt) {
 #pragma unroll
             for (int u = 0; u < GB; ++u) {
                 const int j = bt * GB + u;
-                const size_t oa = (gin && m1[j] >= 0) ? (size_t)(gbase + (unsigned)m1[j] * hw) : (size_t)0;
-                const size_t ob = (gin && m2[j] >= 0) ? (size_t)(gbase + (unsigned)m2[j] * hw) : (size_t)0;
+                const uint32_t oa = (gin && m1[j] >= 0) ? gbase + (uint32_t)m1[j] * hw4 : 0u;
+                const uint32_t ob = (gin && m2[j] >= 0) ? gbase + (uint32_t)m2[j] * hw4 : 0u;
                 if constexpr ((PLEAS_FWD_ABLATE & 1) != 0) {
                     ta[bt][u] = f32x4{(float)(oa & 3), 0.f, 0.f, 0.f};
                     tb[bt][u] = f32x4{(float)(ob & 3), 0.f, 0.f, 0.f};
                 } else {
-                    ta[bt][u] = *(const __attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL(L.o1) + oa);
-                    tb[bt][u] = *(const __attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL(L.o2) + ob);
+                    ta[bt][u] = *(const __attribute__((address_space(1))) f32x4*)(o1b + oa);
+                    tb[bt][u] = *(const __attribute__((address_space(1))) f32x4*)(o2b + ob);
                 }
             }
         };
@@ -173,7 +177,7 @@ __device__ __forceinline__ void fwd_epilogue(const FwdLayerDev& L, const FwdItem
                     d[e] = L.dscale * dd;
                 }
                 sq += live ? s4 : 0.f;
-                if (live) *(__attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL_W(L.resid) + (size_t)(rbase + (unsigned)(8 * j) * hw)) = d;
+                if (live) *(__attribute__((address_space(1))) f32x4*)(rb_ + (rbase + (uint32_t)(8 * j) * hw4)) = d;
             }
         };
         gather(0);
@@ -534,8 +538,17 @@ __device__ __forceinline__ void fwd_flat_tile(const FwdLayerDev& L, const FwdIte
             ra[q] = *(const __attribute__((address_space(1))) f32x4*)(PLEAS_GLOBAL(L.w) + offa[q] + k);
         }
     };
+    // Tiles whose rows / pixels all exist store their staged values as they are (block-uniform tests): every select that is
+    // not executed is vector-pipe time the fp32 MFMAs get back (a vector instruction costs ~4.5 cycles of it).
+    const bool full_a = i0 + TM <= L.Cout;
+    const bool full_b = p0 + fTN <= L.Ptot;
     auto store_a = [&](int buf, const f32x4 (&ra)[PASS]) {
         float* a = As + buf * TM * fLdsA;
+        if (full_a) {
+#pragma unroll
+            for (int q = 0; q < PASS; ++q) *reinterpret_cast<f32x4*>(a + (arow + q * RPP) * fLdsA + acol) = ra[q];
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < PASS; ++q) {
             const bool ok = (oka >> q) & 1u;
@@ -569,6 +582,14 @@ __device__ __forceinline__ void fwd_flat_tile(const FwdLayerDev& L, const FwdIte
     auto store_b = [&](int buf, const auto& rb) {
         float* b = Bs + buf * fBK * Lr;
         if constexpr (KIND == 0) {
+            if (full_b) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 v = {rb[4 * i], rb[4 * i + 1], rb[4 * i + 2], rb[4 * i + 3]};
+                    *reinterpret_cast<f32x4*>(b + ((tid >> 5) + 8 * i) * Lr + 4 * (tid & 31)) = v;
+                }
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const f32x4 v = {vok ? rb[4 * i] : 0.f, vok ? rb[4 * i + 1] : 0.f, vok ? rb[4 * i + 2] : 0.f, vok ? rb[4 * i + 3] : 0.f};
@@ -583,12 +604,17 @@ __device__ __forceinline__ void fwd_flat_tile(const FwdLayerDev& L, const FwdIte
                         b[(8 * wave + kr) * Lr + lane + 64 * m] = ((vok >> m) & 1u) ? rb[kr * MCOL + m] : 0.f;
         }
     };
+    // tap offsets of a k x k layer without a division per chunk: tap r -> r + 1 is one pixel to the right, or (at the end of a
+    // kernel row) W - KW + 1 pixels on; taps are visited in order 0 .. R - 1 per channel block (all scalar-unit arithmetic)
+    const int delta0 = -(L.pad * W + L.pad);
+    auto tap_delta = [&](int r) {
+        if constexpr (KIND != 2) return 0;
+        int kh = 0, rr = r;
+        while (rr >= L.KW) { rr -= L.KW; ++kh; }      // r < 32, KW >= 3: at most a few scalar steps
+        return delta0 + kh * W + rr;
+    };
     auto compute = [&](int abuf, int bbuf, int r) {
-        int delta = 0;
-        if constexpr (KIND == 2) {
-            const int kh = r / L.KW, kw = r - kh * L.KW;
-            delta = (kh - L.pad) * W + (kw - L.pad);
-        }
+        const int delta = tap_delta(r);
         const float* a = As + abuf * TM * fLdsA + (wm * (TM / 2) + (lane & 31)) * fLdsA + 4 * (lane >> 5);
         const float* bb = Bs + bbuf * fBK * Lr + 4 * (lane >> 5) * Lr;     // half-wave h takes k = 8 kk + e + 4 h
         // A lane whose tap falls outside the image takes 0: by a select on the value it read at its own (always valid:
@@ -973,6 +999,7 @@ static int build_fwd_plan(FwdPlan& P, const pleas_fwd_layer* ly, int n) {
         if (l.KH * l.KW > 64) return bad_arg("conv_fwd: kernels larger than 64 taps are not supported");
         const int64_t HWo = (int64_t)Hout * Wout, Ptot = (int64_t)l.N * HWo, Kd = (int64_t)l.Cin * l.KH * l.KW;
         if (Ptot >= (1ll << 31) || (int64_t)l.Cout * Kd >= (1ll << 32)) return bad_arg("conv_fwd: tensor too large");
+        if (Ptot * std::max(l.Cout, l.Csrc) >= (1ll << 30)) return bad_arg("conv_fwd: outputs of 4 GB and more per call are not supported");
         FwdLayerDev& d = P.layers[i];
         d.Cout = l.Cout; d.Cin = l.Cin; d.Hin = l.Hin; d.Win = l.Win; d.Hout = Hout; d.Wout = Wout;
         d.KH = l.KH; d.KW = l.KW; d.stride = l.stride; d.pad = l.pad; d.Csrc = l.Csrc; d.n_merged = l.n_merged;
