@@ -431,6 +431,9 @@ def cpu_baseline_and_parity(cfg, spec, m1, m2, pool, n_match, n_pleas, n_sched, 
     seen = {}
 
     def after_matching(perm, costs):
+        if cfg.get("match_mode") == "train":      # the oracle matches in the drivers' mode too (its `train` goes back to eval)
+            c1.train()
+            c2.train()
         t0 = time.time()
         want_costs = orc.matching_costs(spec, c1, c2, data[:nM], nM, accumulate=True)
         seen["t_match"] = (time.time() - t0) / nM
@@ -797,6 +800,10 @@ def main():
                 "host_gc": "collected once per job while the LAP kernel runs" if args.gc == "lap" else "interpreter default",
                 "inputs": "HBM-resident batches" if args.inputs == "resident" else "pinned host batches, copied host -> device inside the loops",
                 "matching_mode": args.match_mode,
+                "vendor_convolutions": "MIOpen, Winograd kernels %s (MIOPEN_DEBUG_CONV_WINOGRAD=%s; the library's default is "
+                                       "off: the direct kernels are as fast here and keep parity inside the oracle's own spread)"
+                                       % ("off" if os.environ.get("MIOPEN_DEBUG_CONV_WINOGRAD") == "0" else "on",
+                                          os.environ.get("MIOPEN_DEBUG_CONV_WINOGRAD")),
                 "not_in_value": "get_permutation_spec %.2f s (host, once per model)" % spec_s,
             },
             "job_s": {"mean": round(value, 4), "median": round(srt[len(srt) // 2], 4), "min": round(srt[0], 4),
