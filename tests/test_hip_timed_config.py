@@ -102,15 +102,15 @@ def test_rn101_timed_configuration_vs_oracle():
         torch.set_num_threads(threads)
 
     # ---- the gate.  A tensor's yardstick is ONE draw of "two correct implementations apart" (the oracle with oneDNN
-    # convolutions on / off), and so is the HIP path's distance -- whose 128-sample source forwards run the vendor's WINOGRAD
-    # 3 x 3 kernels.  Measured on the MI355X (profiles/r04_timed_config_parity*.json): with them, one tensor of 521
-    # (layer3.8.conv2.weight) sits at 5.7e-4 = 7 x its own yardstick and 0.34 % of its coordinates took the opposite first
-    # Adam step; with MIOPEN_DEBUG_CONV_WINOGRAD=0 (the vendor's direct kernels) no tensor is above 3 x its yardstick and the
-    # worst share is 0.14 % -- below the oracle's own 0.21 %.  The spread is the vendor's convolution arithmetic, not the
-    # update's kernels (those are held to fp64 on identical taps in test_hip_fullsize.py).  So, as for the long horizon
-    # (tests/test_hip_long_horizon.py): at most one tensor per 150 above 3 x its own yardstick, none above 3 x the model's
-    # LARGEST yardstick; the share of coordinates with a visibly different Adam step within 3 x the oracle's worst share;
-    # all other coordinates together within max(1e-4, 2 x the oracle's worst).
+    # convolutions on / off), and so is the HIP path's distance.  Measured on the MI355X (profiles/r04_timed_config_parity*.json):
+    # with the vendor's WINOGRAD 3 x 3 kernels in the 128-sample source forwards, one tensor of 105 (layer3.8.conv2.weight) sat
+    # at 5.7e-4 = 7 x its own yardstick with 0.34 % of its coordinates on the other side of Adam's first sign-like steps; with
+    # the vendor's direct kernels -- what the library asks MIOpen for since round 4 (pleas_merging_amd/__init__.py) -- no
+    # tensor is above 3 x its yardstick and the worst share is 0.14 %, below the oracle's own 0.21 %.  The spread is the
+    # vendor's convolution arithmetic, not the update's kernels (those are held to fp64 on identical taps in
+    # test_hip_fullsize.py).  So, as for the long horizon (tests/test_hip_long_horizon.py): at most one tensor per 150 above
+    # 3 x its own yardstick, none above 3 x the model's LARGEST yardstick; the share of coordinates with a visibly different
+    # Adam step within 3 x the oracle's worst share; all other coordinates together within max(1e-4, 2 x the oracle's worst).
     rows = {}
     for k in want:
         if k == fs.DEGENERATE or not want[k].dtype.is_floating_point:
