@@ -1126,9 +1126,9 @@ int stream_launch(const pleas_fwd_layer* layers, int n_layers, float* loss, void
                   hipStream_t stream);
 }  // namespace fwds
 // STUDY switch (round 4): the streamed form is correct on every test of the grouped forward but
-// SLOWER than the one-item-per-workgroup forms (5.0 vs 2.8 ms per ResNet-101 update): its producer waves share their SIMD's
-// vector issue with the MFMA waves, and back-to-back fp32 MFMAs leave another wave ~1/8 of the VALU rate
-// (tools/hipbench/mfma_valu_share.hip).  Off unless PLEAS_FWD_STREAM=1 or pleas_fwd_stream(1).
+// SLOWER than the one-item-per-workgroup forms (5.0 vs 2.8 ms per ResNet-101 update): while a wave issues fp32 MFMAs back
+// to back the other waves of its SIMD issue nothing at all, so producer and MFMA waves take turns instead of overlapping
+// (tools/hipbench/mfma_side_rates.hip).  Off unless PLEAS_FWD_STREAM=1 or pleas_fwd_stream(1).
 static int g_fwd_stream = -1;
 static bool fwd_streamed() {
     if (g_fwd_stream < 0) g_fwd_stream = (std::getenv("PLEAS_FWD_STREAM") && std::atoi(std::getenv("PLEAS_FWD_STREAM")) != 0) ? 1 : 0;

@@ -6,7 +6,7 @@
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-template <int CLS, bool MFMA_ON, bool SIDE_ON>
+template <int CLS, bool MFMA_ON, bool SIDE_ON, int PRIO>
 __global__ __launch_bounds__(512) void k(float* out, const float* __restrict__ src, int iters, long long* cyc) {
     __shared__ f32x4 lds[2048];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -27,6 +27,7 @@ __global__ __launch_bounds__(512) void k(float* out, const float* __restrict__ s
         return;
     }
     if (!SIDE_ON) return;
+    if (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO);      // the side wave outranks the (older) MFMA wave at the issue arbiter
     float v[8]; for (int j = 0; j < 8; ++j) v[j] = lane * 0.01f + j;
     f32x4 w = {v[0], v[1], v[2], v[3]}, racc = {0, 0, 0, 0};
     int sacc = 0;
@@ -59,13 +60,13 @@ __global__ __launch_bounds__(512) void k(float* out, const float* __restrict__ s
     out[blockIdx.x * 512 + threadIdx.x] = s;
     if (threadIdx.x == 256) cyc[blockIdx.x * 2 + 1] = clock64() - t0;
 }
-template <int CLS> static void run(const char* tag, float* out, const float* src, long long* cyc, int iters) {
+template <int CLS, int PRIO> static void run(const char* tag, float* out, const float* src, long long* cyc, int iters) {
     long long h[512]; double m[3], v[3];
     for (int mode = 0; mode < 3; ++mode) {
         hipMemset(cyc, 0, sizeof(h));
-        if (mode == 0) hipLaunchKernelGGL((k<CLS, true, false>), dim3(256), dim3(512), 0, 0, out, src, iters, cyc);
-        if (mode == 1) hipLaunchKernelGGL((k<CLS, false, true>), dim3(256), dim3(512), 0, 0, out, src, iters, cyc);
-        if (mode == 2) hipLaunchKernelGGL((k<CLS, true, true>), dim3(256), dim3(512), 0, 0, out, src, iters, cyc);
+        if (mode == 0) hipLaunchKernelGGL((k<CLS, true, false, PRIO>), dim3(256), dim3(512), 0, 0, out, src, iters, cyc);
+        if (mode == 1) hipLaunchKernelGGL((k<CLS, false, true, PRIO>), dim3(256), dim3(512), 0, 0, out, src, iters, cyc);
+        if (mode == 2) hipLaunchKernelGGL((k<CLS, true, true, PRIO>), dim3(256), dim3(512), 0, 0, out, src, iters, cyc);
         hipDeviceSynchronize(); hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
         m[mode] = v[mode] = 0; for (int i = 0; i < 256; ++i) { m[mode] += h[2 * i]; v[mode] += h[2 * i + 1]; } m[mode] /= 256; v[mode] /= 256;
     }
@@ -77,11 +78,19 @@ int main() {
     float* out; hipMalloc(&out, 256 * 512 * 4); long long* cyc; hipMalloc(&cyc, 256 * 2 * 8);
     float* src; hipMalloc(&src, 64 * 4096 * 16 + 65536); hipMemset(src, 0, 64 * 4096 * 16 + 65536);
     const int iters = 2000;
-    run<0>("v_fma_f32", out, src, cyc, iters);
-    run<1>("v_readlane_b32", out, src, cyc, iters);
-    run<2>("s_add_i32", out, src, cyc, iters);
-    run<3>("ds_write_b128", out, src, cyc, iters);
-    run<4>("ds_read_b128", out, src, cyc, iters);
-    run<5>("global_load_dwordx4 (L2)", out, src, cyc, iters);
+    printf("-- side waves at the default priority (they are the YOUNGER waves of the workgroup)\n");
+    run<0, 0>("v_fma_f32", out, src, cyc, iters);
+    run<1, 0>("v_readlane_b32", out, src, cyc, iters);
+    run<2, 0>("s_add_i32", out, src, cyc, iters);
+    run<3, 0>("ds_write_b128", out, src, cyc, iters);
+    run<4, 0>("ds_read_b128", out, src, cyc, iters);
+    run<5, 0>("global_load_dwordx4 (L2)", out, src, cyc, iters);
+    printf("-- side waves at s_setprio 3\n");
+    run<0, 3>("v_fma_f32", out, src, cyc, iters);
+    run<1, 3>("v_readlane_b32", out, src, cyc, iters);
+    run<2, 3>("s_add_i32", out, src, cyc, iters);
+    run<3, 3>("ds_write_b128", out, src, cyc, iters);
+    run<4, 3>("ds_read_b128", out, src, cyc, iters);
+    run<5, 3>("global_load_dwordx4 (L2)", out, src, cyc, iters);
     return 0;
 }
