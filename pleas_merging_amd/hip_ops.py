@@ -87,11 +87,25 @@ def to_device_async(x: torch.Tensor, device: torch.device) -> torch.Tensor:
         return x
     if x.is_cuda or not x.is_pinned():
         return x.to(device, non_blocking=True)
-    copy, cur = role_stream(device, "h2d"), torch.cuda.current_stream(device)
+    d, ev = h2d_start(x, device)
+    return h2d_finish(d, ev, device)
+
+
+def h2d_start(x: torch.Tensor, device: torch.device):
+    """Enqueue the copy of a PINNED host tensor on the copy stream NOW; returns ``(device tensor, event)`` for
+    :func:`h2d_finish`.  A caller that knows its next batches starts their copies a whole step early: a process's streams
+    share four hardware queues, so a copy enqueued right before it is needed sits behind the kernels already queued there."""
+    copy = role_stream(torch.device(device), "h2d")
     with torch.cuda.stream(copy):
         d = x.to(device, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(copy)
+    return d, ev
+
+
+def h2d_finish(d: torch.Tensor, ev, device: torch.device) -> torch.Tensor:
+    """Make the CURRENT stream wait for a copy started by :func:`h2d_start` and hand the tensor over to it."""
+    cur = torch.cuda.current_stream(torch.device(device))
     cur.wait_event(ev)
     d.record_stream(cur)      # allocated in the copy stream's pool, consumed on `cur`
     return d

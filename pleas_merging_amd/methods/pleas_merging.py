@@ -380,11 +380,26 @@ class FrozenSources:
         self._src_events = None
         self._slice_batch = True   # data parallel: every update splits its batch's samples over the ranks
         self.queue: collections.deque = collections.deque()
+        self._staged: dict = {}    # id(pinned host batch) -> (batch, device copy, event): copies started ahead of their forward
+
+    def stage(self, batches) -> None:
+        """Start the host -> device copies of PINNED host batches now (copy stream); the forward that takes a batch later
+        only waits for its event.  ``steps`` stages the group AFTER the one it launches: enqueued together with a group's
+        forwards, a copy would sit behind that group's kernels in a shared hardware queue and surface when it is needed."""
+        for b in batches:
+            if torch.is_tensor(b) and not b.is_cuda and b.is_pinned() and id(b) not in self._staged:
+                self._staged[id(b)] = (b,) + self.ops.h2d_start(b, self.device)
+
+    def _to_device(self, b: torch.Tensor) -> torch.Tensor:
+        hit = self._staged.pop(id(b), None) if torch.is_tensor(b) else None
+        if hit is not None and hit[0] is b:
+            return self.ops.h2d_finish(hit[1], hit[2], self.device)
+        return self.ops.to_device_async(b, self.device)
 
     def launch(self, x: torch.Tensor, parts: int = 1, after_current: bool = True):
         """Enqueue both source forwards for ``x``; returns the generation (device batch, taps, events) the update will
         consume.  ``parts`` > 1: ``x`` is that many batches back to back, each of which is sample-sliced on its own."""
-        x = self.ops.to_device_async(x, self.device)
+        x = self._to_device(x)
         if self._slice_batch:
             if parts > 1 and self.world > 1:
                 h = x.shape[0] // parts
@@ -402,7 +417,7 @@ class FrozenSources:
         first = self._side_streams[0] if (self._side_streams is not None and not after_current) else None
         with (torch.cuda.stream(first) if first is not None else contextlib.nullcontext()):
             # pinned host batches travel on a copy stream while the previous group's updates run (hip_ops.to_device_async)
-            both = torch.cat([self.ops.to_device_async(b, self.device) for b in run], 0)
+            both = torch.cat([self._to_device(b) for b in run], 0)
             xdev, (in1, out1), (in2, out2), events = self.launch(both, parts=len(run), after_current=after_current)
         n = xdev.shape[0] // len(run)
         for i, b in enumerate(run):
@@ -486,6 +501,7 @@ class FrozenSources:
         self.tap1.remove()
         self.tap2.remove()
         self.queue.clear()
+        self._staged.clear()
 
 
 class PleasFitter:
@@ -757,7 +773,7 @@ class PleasFitter:
             # the updates it has seen -- nothing is left to a generator's finalisation.
             with self._session():
                 while len(self._queue) <= keep:
-                    while len(ahead) < group and not exhausted:
+                    while len(ahead) < 2 * group and not exhausted:      # one group to launch, one whose copies start now
                         nxt = next(it, None)
                         if nxt is None:
                             exhausted = True
@@ -779,6 +795,7 @@ class PleasFitter:
                     else:
                         b = ahead.pop(0)
                         self._queue.append((b,) + self._launch_sources(b))
+                    self.sources.stage(ahead[:group])
                 if not self._queue:
                     break
                 self.step(self._queue[0][0])

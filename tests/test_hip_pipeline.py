@@ -560,18 +560,21 @@ def test_paired_source_forwards_equal_one_forward_per_batch(tiny_bottleneck):
     for kw in ({"sources_per_forward": 1}, {}, {"sources_per_forward": 4}, {"sources_per_forward": 3},   # default: pairs
                {"lookahead": True}, {"sources_per_forward": 3, "lookahead": True},    # next group enqueued beforehand
                {"prefetch": 2}, {"prefetch": 1, "sources_per_forward": 3, "lookahead": True},
-               {"prefetch": 3, "sources_per_forward": 1}):
+               {"prefetch": 3, "sources_per_forward": 1},
+               # PINNED host batches: copied on the copy stream, the next group's copies started a group ahead (stage)
+               {"pinned": True}, {"pinned": True, "sources_per_forward": 3, "prefetch": 1}, {"pinned": True, "sources_per_forward": 1}):
         m3 = partial_merge(t.spec, m1, m2, perm, costs, 0.5)
         kw = dict(kw)
         prefetch = kw.pop("prefetch", 0)
+        batches = [x.pin_memory() for x in xs] if kw.pop("pinned", False) else xs
         sources = None
         if prefetch:      # the first groups' forwards are enqueued before the fitter exists (as during the LAP kernel)
             sources = FrozenSources(m1, m2)
-            assert sources.prefetch(xs, group=kw.get("sources_per_forward"), max_groups=prefetch) == \
+            assert sources.prefetch(batches, group=kw.get("sources_per_forward"), max_groups=prefetch) == \
                 prefetch * kw.get("sources_per_forward", 2)
         fit = PleasFitter(m1, m2, m3, t.spec, perm, costs, 0.5, len(xs) - 1, num_classes=10, sources=sources)
-        assert list(fit.steps(xs, **kw)) == list(range(len(xs)))
-        assert fit.step_count == len(xs) and not fit._queue
+        assert list(fit.steps(batches, **kw)) == list(range(len(xs)))
+        assert fit.step_count == len(xs) and not fit._queue and not fit.sources._staged
         outs.append({k: v.clone() for k, v in fit.finish().state_dict().items()})
     for other in outs[1:]:
         for k in outs[0]:
