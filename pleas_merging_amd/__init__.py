@@ -8,7 +8,7 @@ import os as _os
 
 # The frozen source / twin forwards run on the vendor's convolutions.  At 128-160 samples per forward MIOpen's immediate mode
 # picks its Winograd F(2,3) kernels for the 3x3 layers; their rounding is what moves one trained tensor of the ResNet-101 job
-# past 3x the oracle's own spread (profiles/r04_timed_config_parity*.json), and the vendor's direct
+# past 3x the CPU reference's own run-to-run spread (profiles/r04_timed_config_parity*.json), and the vendor's direct
 # kernels are as fast on this job (6.20 s vs 6.19-6.21 s per job, profiles/r04_bench_nowinograd.json).  So the library asks
 # for the direct kernels unless the caller has decided otherwise: MIOpen reads this variable once, at its first convolution;
 # set MIOPEN_DEBUG_CONV_WINOGRAD=1 before importing this package to keep the vendor's own choice.
