@@ -433,7 +433,12 @@ __device__ __forceinline__ void fwd_tile(const FwdLayerDev& L, const FwdItemDev&
 // have tap r reads the row's ZERO COLUMN instead (one select on the address per tap and 32-pixel fragment).
 // Weights: kernel-position-major chunks (tap r, channel block) exactly as in fwd_tile; accumulators and epilogue shared.
 constexpr int fFlatRow1 = 132;     // Bs row stride of 1x1 layers: 128 pixels + zero column, 16-B aligned rows
-constexpr int fFlatRowK = 260;     // Bs row stride of k x k layers: 128 + 2 * halo <= 256 data columns + zero column
+constexpr int fFlatRowK = 260;     // (round 2-3 layout of the k x k image, [k][column]; kept for the 1x1 forms' sizing only)
+constexpr int fFlatPix = 36;       // k x k image since round 4: [column][36] -- a pixel's 32 channels contiguous (+ 4 pad: 16-byte
+                                   // aligned rows, conflict-free ds_read_b128 as for the weight tile), so that ONE 16-byte LDS read
+                                   // feeds four MFMA steps instead of four 4-byte reads (an LDS read costs the SIMD ~10 cycles
+                                   // whatever its width)
+constexpr int fFlatColsK = 248;    // columns of that image: 128 + 2 * halo data columns + one zero row
 // KIND 0: 1x1, 16-B loads along the pixel axis (HW % 4 == 0), two images (double buffer)
 // KIND 1: 1x1, scalar loads (HW % 4 != 0, e.g. 7 x 7), two images
 // KIND 2: k x k, scalar loads, ONE image per channel block shared by all taps
@@ -441,8 +446,8 @@ template <int TM, int KIND>
 __device__ __forceinline__ void fwd_flat_tile(const FwdLayerDev& L, const FwdItemDev& it, float* smem, float* __restrict__ partials) {
     constexpr int MTM = TM / 64;
     constexpr int LPR = fBK / 4, RPP = fThreads / LPR, PASS = TM / RPP;   // weight staging: 16-B loads
-    constexpr int Lr = KIND == 2 ? fFlatRowK : fFlatRow1;               // compile-time: LDS offsets are immediates
-    constexpr int jz = Lr - 1;                                           // the zero column
+    constexpr int Lr = KIND == 2 ? fFlatPix : fFlatRow1;                // compile-time: LDS offsets are immediates
+    constexpr int jz = KIND == 2 ? fFlatColsK - 1 : Lr - 1;              // the zero column (k x k: the zero ROW of the image)
     constexpr int NBUF = KIND == 2 ? 1 : 2;
     constexpr int MCOL = KIND == 2 ? 4 : 2;                              // scalar form: column passes of 64 lanes
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -457,7 +462,7 @@ __device__ __forceinline__ void fwd_flat_tile(const FwdLayerDev& L, const FwdIte
     const int CB = L.Cin / fBK;
     const int nchunks = CB * R;
     float* As = smem;                                // [2][TM][fLdsA]
-    float* Bs = smem + 2 * TM * fLdsA;               // [NBUF][32][Lr]
+    float* Bs = smem + 2 * TM * fLdsA;               // 1x1: [NBUF][32][Lr]; k x k: [fFlatColsK][fFlatPix]
 
     // ---- A (weights) staging, as in fwd_tile with VECA = 4
     const int arow = tid / LPR, acol = (tid % LPR) * 4;
@@ -595,6 +600,19 @@ __device__ __forceinline__ void fwd_flat_tile(const FwdLayerDev& L, const FwdIte
                 const f32x4 v = {vok ? rb[4 * i] : 0.f, vok ? rb[4 * i + 1] : 0.f, vok ? rb[4 * i + 2] : 0.f, vok ? rb[4 * i + 3] : 0.f};
                 *reinterpret_cast<f32x4*>(b + ((tid >> 5) + 8 * i) * Lr + 4 * (tid & 31)) = v;
             }
+        } else if constexpr (KIND == 2) {
+            // this thread holds channels 8 wave .. + 7 of columns lane + 64 m: two 16-byte runs of the column's row
+#pragma unroll
+            for (int m = 0; m < MCOL; ++m)
+                if (m < M && lane + 64 * m < span) {
+                    const bool ok = (vok >> m) & 1u;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x4 v = {ok ? rb[(4 * h + 0) * MCOL + m] : 0.f, ok ? rb[(4 * h + 1) * MCOL + m] : 0.f,
+                                         ok ? rb[(4 * h + 2) * MCOL + m] : 0.f, ok ? rb[(4 * h + 3) * MCOL + m] : 0.f};
+                        *reinterpret_cast<f32x4*>(b + (lane + 64 * m) * fFlatPix + 8 * wave + 4 * h) = v;
+                    }
+                }
         } else {
 #pragma unroll
             for (int kr = 0; kr < 8; ++kr)
@@ -625,6 +643,27 @@ __device__ __forceinline__ void fwd_flat_tile(const FwdLayerDev& L, const FwdIte
 #define PLEAS_FWD_ZEROCOL 0
 #endif
         const bool ok0 = (tapok[0] >> r) & 1u, ok1 = (tapok[1] >> r) & 1u;
+        if constexpr (KIND == 2) {
+            // [column][k] image: a lane's four k of an MFMA group are ONE 16-byte read; a lane whose tap is off the image
+            // reads the zero row (one select on the address per tap and fragment instead of one per value)
+            const float* c0 = Bs + (ok0 ? jb[0] + delta : jz) * fFlatPix + 4 * (lane >> 5);
+            const float* c1 = Bs + (ok1 ? jb[1] + delta : jz) * fFlatPix + 4 * (lane >> 5);
+#pragma unroll
+            for (int kk = 0; kk < fBK / 8; ++kk) {
+                f32x4 fa[MTM];
+#pragma unroll
+                for (int s = 0; s < MTM; ++s) fa[s] = *reinterpret_cast<const f32x4*>(a + s * 32 * fLdsA + kk * 8);
+                const f32x4 f0 = *reinterpret_cast<const f32x4*>(c0 + kk * 8), f1 = *reinterpret_cast<const f32x4*>(c1 + kk * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int sm = 0; sm < MTM; ++sm) {
+                        acc[sm][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sm][e], f0[e], acc[sm][0], 0, 0, 0);
+                        acc[sm][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sm][e], f1[e], acc[sm][1], 0, 0, 0);
+                    }
+            }
+            return;
+        }
         constexpr bool zero_col = PLEAS_FWD_ZEROCOL || KIND != 2;      // 1 x 1 forms: only pixels past the tensor's end
         const float* b0 = bb + ((zero_col && !ok0) ? jz : jb[0] + delta);
         const float* b1 = bb + ((zero_col && !ok1) ? jz : jb[1] + delta);
@@ -649,8 +688,10 @@ __device__ __forceinline__ void fwd_flat_tile(const FwdLayerDev& L, const FwdIte
         }
     };
 
-    // zero column of every row of every image (never overwritten: data columns end at span - 1 < jz)
-    if (tid < fBK * NBUF) Bs[tid * Lr + jz] = 0.f;
+    // zero column of every row of every image (never overwritten: data columns end at span - 1 < jz); k x k: the zero row
+    if constexpr (KIND == 2) {
+        if (tid < fFlatPix / 4) *reinterpret_cast<f32x4*>(Bs + jz * fFlatPix + 4 * tid) = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else if (tid < fBK * NBUF) Bs[tid * Lr + jz] = 0.f;
     load_a(0, 0, ra0);
     load_b(0, rb0);
     store_a(0, ra0);
@@ -1023,8 +1064,8 @@ static int build_fwd_plan(FwdPlan& P, const pleas_fwd_layer* ly, int n) {
             const bool same = l.stride == 1 && l.KH == l.KW && (l.KH & 1) && l.pad == (l.KH - 1) / 2;
             const int halo = l.pad * (l.Win + 1);
             const int kind = R > 1 ? 2 : (HWo % 4 == 0 ? 0 : 1);
-            const int Lr = kind == 2 ? fFlatRowK : fFlatRow1;
-            const size_t flat_lds = std::max((size_t)(2 * TM * fLdsA + (kind == 2 ? 1 : 2) * fBK * Lr) * sizeof(float),
+            const int Lr = kind == 2 ? fFlatColsK : fFlatRow1;      // k x k: columns of the [column][36] image, zero row included
+            const size_t flat_lds = std::max((size_t)(2 * TM * fLdsA + (kind == 2 ? fFlatColsK * fFlatPix : 2 * fBK * Lr)) * sizeof(float),
                                              (size_t)TM * 132 * sizeof(float));
             if (flat_on && same && l.Cin % fBK == 0 && R <= 32 && (R == 1 || (l.flags & PLEAS_FWD_KPOS_MAJOR)) &&
                 fTN + 2 * halo < Lr && flat_lds <= lds_bytes && (int64_t)l.N * l.Cin * HWo < (1ll << 32)) {

@@ -82,7 +82,8 @@ def _job(path, data_parallel, shard=False, time_collectives=False, calls=None):
     torch.cuda.synchronize()
     return {"perm": {str(k): v.cpu() for k, v in perm.items()}, "costs": {str(k): v.cpu() for k, v in costs.items()},
             "sd": sd, "loss": loss.cpu(), "info": info, "timings": timings, "merged_stem": merged_stem,
-            "calls": job_calls}
+            "calls": job_calls, "state_axes": {str(k): sorted({ax.key for ax in g.state}) for k, g in spec.items()},
+            "layers": [p.name for p in fit.plans]}
 
 
 def _time_collectives(costs, fit, reps=5):
@@ -193,9 +194,19 @@ def _compare(res, want, exact):
     spread = want["spread"]
     deterministic = spread["perm_equal"] and max(spread["costs"].values()) == 0.0 and max(spread["sd"].values()) == 0.0
     worst = {"cost": 0.0, "weight": 0.0}
+    # A group whose optimum is a near tie may be assigned differently by two partitionings of the job (the all-reduce sums
+    # the batches' costs in another order): accepted when the other assignment is within 1e-6 of the optimum under THIS job's
+    # costs (the rule of test_hip_fullsize._check_matching), for at most two groups; the tensors that carry such a group's
+    # axes are then merged differently and are left out of the weight comparison (layers are fitted independently).
+    flipped, skip = [], set()
+    value = lambda cost, perm: float(cost.double()[torch.arange(len(perm)), perm].sum())
     for k, v in want["perm"].items():
-        if spread["perm_equal"]:
-            assert torch.equal(res["perm"][k], v), k
+        if spread["perm_equal"] and not torch.equal(res["perm"][k], v):
+            best, mine = value(want["costs"][k], v), value(want["costs"][k], res["perm"][k])
+            gap = (best - mine) / abs(best)
+            assert not (exact and deterministic) and 0 <= gap < 1e-6, (k, gap)
+            flipped.append((k, int((res["perm"][k] != v).sum()), gap))
+            skip.update(want["state_axes"][k])
         r = _rel(res["costs"][k], want["costs"][k])
         worst["cost"] = max(worst["cost"], r)
         if exact and deterministic:
@@ -207,14 +218,18 @@ def _compare(res, want, exact):
             continue
         if exact and deterministic:
             assert torch.equal(res["sd"][k], v), k
-        elif k != "conv1.weight":      # degenerate stem: gated by the caller
+        elif k != "conv1.weight" and k not in skip:      # degenerate stem: gated by the caller
             r = _rel(res["sd"][k], v)
             worst["weight"] = max(worst["weight"], r)
             assert r <= max(WEIGHT_TOL, 3 * spread["sd"][k]), (k, r, spread["sd"][k])
+    assert len(flipped) <= 2, flipped
+    if flipped:
+        print("near-tie groups assigned differently (units, optimality gap):", flipped)
     if exact and deterministic:
         assert torch.equal(res["loss"], want["loss"])
     else:
-        assert torch.allclose(res["loss"], want["loss"], rtol=1e-4, atol=1e-7)
+        keep = torch.tensor([not any(a.rsplit(".", 1)[0] == n for a in skip) for n in want["layers"]])
+        assert torch.allclose(res["loss"][keep], want["loss"][keep], rtol=1e-4, atol=1e-7)
     return worst
 
 
