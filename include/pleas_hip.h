@@ -138,7 +138,11 @@ int pleas_merge_blocks(const float* w1, const float* w2, float* out, int64_t out
 /* Grouped form: the 1-axis block merge of MANY tensors (the merged layer inputs of one PLeaS update,
  * pleas_merging.py:125-147) in ONE launch.  items: HOST array; tensor pointers and maps are DEVICE pointers.
  * Tensors are viewed [outer][rows][inner]; semantics per tensor as pleas_merge_blocks without column maps.
- * Tensors with inner % 4 == 0 must be 16-byte aligned.  ws / ws_fresh as in pleas_gram_batch. */
+ * Tensors with inner % 4 == 0 must be 16-byte aligned.  ws / ws_fresh as in pleas_gram_batch.
+ * sub_stride > 1 (the input of a 1x1 convolution with that stride, which reads every sub_stride-th pixel of every
+ * sub_stride-th line): the sources are images of sub_h x sub_w pixels (inner_src = sub_h * sub_w) and `out` holds only the
+ * pixels the layer reads, inner = ceil(sub_h / sub_stride) * ceil(sub_w / sub_stride) -- the layer then is a dense 1x1
+ * stride-1 convolution for pleas_fwd_batch / pleas_wgrad_batch.  0 or 1: inner is the sources' inner size. */
 typedef struct pleas_merge_item {
     const float* w1;      /* [outer][rows_src][inner] */
     const float* w2;
@@ -147,6 +151,7 @@ typedef struct pleas_merge_item {
     const int32_t* row2;
     int64_t outer, inner;
     int rows_out, rows_src, n_merged;
+    int sub_stride, sub_h, sub_w;
 } pleas_merge_item;
 size_t pleas_merge_batch_ws_bytes(const pleas_merge_item* items, int n_items);
 int pleas_merge_batch(const pleas_merge_item* items, int n_items, void* ws, size_t ws_bytes, int ws_fresh, void* stream);

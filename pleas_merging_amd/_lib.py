@@ -84,7 +84,8 @@ SIGNATURES = {
 class MergeItem(ctypes.Structure):
     """struct pleas_merge_item"""
     _fields_ = [("w1", c_void_p), ("w2", c_void_p), ("out", c_void_p), ("row1", c_void_p), ("row2", c_void_p),
-                ("outer", c_int64), ("inner", c_int64), ("rows_out", c_int), ("rows_src", c_int), ("n_merged", c_int)]
+                ("outer", c_int64), ("inner", c_int64), ("rows_out", c_int), ("rows_src", c_int), ("n_merged", c_int),
+                ("sub_stride", c_int), ("sub_h", c_int), ("sub_w", c_int)]
 
 
 class FwdLayer(ctypes.Structure):

@@ -387,11 +387,29 @@ __device__ __forceinline__ void wgrad_dispatch(const WgradLayerDev& L, const Wgr
     else wgrad_tile<TM, TN, 1, 1>(L, it, smem);
 }
 
+#ifndef PLEAS_WGRAD_TIMELINE
+#define PLEAS_WGRAD_TIMELINE 0   // study builds (tools/r04/timeline.sh): per work item, when and where it ran
+#endif
+#if PLEAS_WGRAD_TIMELINE
+__device__ long long g_wgrad_timeline[16384][4];   // start, end (100 MHz wall clock), HW_ID | XCC_ID << 32, chunks * TM * TN
+#endif
+
 __global__ __launch_bounds__(cThreads, 2) void wgrad_batch_kernel(const WgradLayerDev* __restrict__ layers,
                                                                const WgradItemDev* __restrict__ items) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const WgradItemDev it = items[blockIdx.x];
+#if PLEAS_WGRAD_TIMELINE
+    const long long t_start = __builtin_amdgcn_s_memrealtime();
+    if (it.layer < 0) {
+        if (threadIdx.x == 0 && blockIdx.x < 16384) {
+            g_wgrad_timeline[blockIdx.x][0] = t_start; g_wgrad_timeline[blockIdx.x][1] = t_start;
+            g_wgrad_timeline[blockIdx.x][2] = -1; g_wgrad_timeline[blockIdx.x][3] = 0;
+        }
+        return;
+    }
+#else
     if (it.layer < 0) return;   // padding of the XCD-aware item order
+#endif
     const WgradLayerDev L = layers[it.layer];
     switch (L.variant & 3) {  // block-uniform
         case 0: wgrad_dispatch<128, 128>(L, it, smem); break;
@@ -399,6 +417,16 @@ __global__ __launch_bounds__(cThreads, 2) void wgrad_batch_kernel(const WgradLay
         case 2: wgrad_dispatch<128, 64>(L, it, smem); break;
         default: wgrad_dispatch<64, 64>(L, it, smem); break;
     }
+#if PLEAS_WGRAD_TIMELINE
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x < 16384) {
+        const long long hw = (long long)__builtin_amdgcn_s_getreg(63492) | ((long long)__builtin_amdgcn_s_getreg(63508) << 32);
+        g_wgrad_timeline[blockIdx.x][0] = t_start;
+        g_wgrad_timeline[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+        g_wgrad_timeline[blockIdx.x][2] = hw;
+        g_wgrad_timeline[blockIdx.x][3] = (long long)(it.c_end - it.c_begin) * ((L.variant & 1) ? 64 : 128) * ((L.variant & 2) ? 64 : 128);
+    }
+#endif
 }
 
 // per-update operand pointers -> device layer table (carried in kernel arguments)
@@ -652,6 +680,13 @@ static std::vector<int64_t> wgrad_key(const pleas_wgrad_layer* ly, int n, const 
 }  // namespace pleas
 
 using namespace pleas;
+
+#if PLEAS_WGRAD_TIMELINE
+extern "C" int pleas_wgrad_timeline_read(long long* out, int max_items) {      // study builds only
+    const int n = std::min(max_items, 16384);
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgrad_timeline), (size_t)n * 4 * sizeof(long long)) == hipSuccess ? n : -1;
+}
+#endif
 
 extern "C" void pleas_wgrad_tune(int item_chunks) {
     if (item_chunks > 0) g_wgrad_item_chunks = item_chunks;

@@ -439,6 +439,15 @@ constexpr int fFlatPix = 36;       // k x k image since round 4: [column][36] --
                                    // feeds four MFMA steps instead of four 4-byte reads (an LDS read costs the SIMD ~10 cycles
                                    // whatever its width)
 constexpr int fFlatColsK = 248;    // columns of that image: 128 + 2 * halo data columns + one zero row
+#ifndef PLEAS_FWD_TIMELINE
+#define PLEAS_FWD_TIMELINE 0   // study builds (tools/r04/timeline.sh): per work item, when and where it ran
+#endif
+#if PLEAS_FWD_TIMELINE
+__shared__ long long g_tl_phase[2];   // wall clock at the end of the prologue / of the K loop (flat forms)
+#define PLEAS_TL_PHASE(k) do { if (threadIdx.x == 0) g_tl_phase[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PLEAS_TL_PHASE(k)
+#endif
 // KIND 0: 1x1, 16-B loads along the pixel axis (HW % 4 == 0), two images (double buffer)
 // KIND 1: 1x1, scalar loads (HW % 4 != 0, e.g. 7 x 7), two images
 // KIND 2: k x k, scalar loads, ONE image per channel block shared by all taps
@@ -697,6 +706,7 @@ __device__ __forceinline__ void fwd_flat_tile(const FwdLayerDev& L, const FwdIte
     store_a(0, ra0);
     store_b(0, rb0);
     __syncthreads();
+    PLEAS_TL_PHASE(0);
     constexpr int ROWS = TM / 8;
     int m1[ROWS], m2[ROWS];
     float bias_v[ROWS];
@@ -755,6 +765,7 @@ __device__ __forceinline__ void fwd_flat_tile(const FwdLayerDev& L, const FwdIte
     fwd_load_maps<TM>(L, i0, m1, m2, bias_v);        // epilogue operands, requested under the last chunk's MFMAs
     compute((nchunks - 1) & 1, bsel, r);
     __syncthreads();
+    PLEAS_TL_PHASE(1);
     fwd_epilogue<TM>(L, it, acc, m1, m2, bias_v, smem, partials);
 }
 
@@ -762,6 +773,10 @@ __device__ __forceinline__ void fwd_flat_tile(const FwdLayerDev& L, const FwdIte
 // launches each form's slice of the item list.  Form ids: 0-3 = fwd_tile<128,4>, <64,4>, <128,1>, <64,1>;
 // 4-6 = fwd_flat_tile<128, KIND 0-2>;  7-9 = fwd_flat_tile<64, KIND 0-2>.
 constexpr int fForms = 10;
+#if PLEAS_FWD_TIMELINE
+__device__ long long g_fwd_timeline[32768][4];   // start, end (100 MHz wall clock), flat forms: prologue | K loop << 32 [ticks], form | chunks * TM << 8
+__device__ int g_fwd_timeline_n;
+#endif
 template <int FORM>
 __global__ __launch_bounds__(fThreads, 2) void fwd_batch_kernel(const FwdLayerDev* __restrict__ layers,
                                                              const FwdItemDev* __restrict__ items,
@@ -770,6 +785,24 @@ __global__ __launch_bounds__(fThreads, 2) void fwd_batch_kernel(const FwdLayerDe
     const FwdItemDev it = items[blockIdx.x];
     if (it.layer < 0) return;   // padding of the XCD-aware item order
     const FwdLayerDev L = layers[it.layer];
+#if PLEAS_FWD_TIMELINE
+    struct Stamp {
+        long long t0; int form; long long work;
+        __device__ ~Stamp() {
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int slot = atomicAdd(&g_fwd_timeline_n, 1);
+                if (slot < 32768) {
+                    g_fwd_timeline[slot][0] = t0;
+                    g_fwd_timeline[slot][1] = __builtin_amdgcn_s_memrealtime();
+                    g_fwd_timeline[slot][2] = form >= 4 ? ((g_tl_phase[0] - t0) | ((g_tl_phase[1] - t0) << 32)) : 0;
+                    g_fwd_timeline[slot][3] = form | (work << 8);
+                }
+            }
+        }
+    } stamp{(long long)__builtin_amdgcn_s_memrealtime(), FORM,
+            (long long)((L.Kd + fBK - 1) / fBK) * ((L.variant & 1) ? 64 : 128)};
+#endif
     if constexpr (FORM == 0) fwd_tile<128, 4>(L, it, smem, partials);
     else if constexpr (FORM == 1) fwd_tile<64, 4>(L, it, smem, partials);
     else if constexpr (FORM == 2) fwd_tile<128, 1>(L, it, smem, partials);
@@ -1158,6 +1191,18 @@ static int build_fwd_plan(FwdPlan& P, const pleas_fwd_layer* ly, int n) {
     P.uploaded = false;
     return PLEAS_OK;
 }
+
+#if PLEAS_FWD_TIMELINE
+extern "C" int pleas_fwd_timeline_read(long long* out, int max_items) {      // study builds only; resets the record
+    int n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_fwd_timeline_n), sizeof(int)) != hipSuccess) return -1;
+    n = std::min(std::min(n, max_items), 32768);
+    if (n > 0 && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fwd_timeline), (size_t)n * 4 * sizeof(long long)) != hipSuccess) return -1;
+    const int zero = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fwd_timeline_n), &zero, sizeof(int));
+    return n;
+}
+#endif
 
 // the streamed form (conv_fwd_stream.hip): one persistent grid with producer / consumer waves
 namespace fwds {

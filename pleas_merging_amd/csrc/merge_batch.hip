@@ -31,7 +31,11 @@ struct MergeItemDev {
     uint32_t inner_v;      // pieces per row
     uint32_t rows_out, rows_src;
     int n_merged, vec;     // vec: 4 (16-B pieces) or 1
-    int first_block, pad;
+    int first_block;
+    // subsampled form (vec == 1): out pixel p = (oh, ow) of `w_out` columns reads source pixel (oh * stride, ow * stride) of an
+    // image with `w_src` columns and `inner_src` pixels; stride == 0: the plain form (source rows are inner_v long)
+    int stride;
+    uint32_t w_out, w_src, inner_src, pad;
 };
 
 __global__ __launch_bounds__(mThreads) void merge_batch_kernel(const MergeItemDev* __restrict__ items,
@@ -75,8 +79,14 @@ __global__ __launch_bounds__(mThreads) void merge_batch_kernel(const MergeItemDe
         float a[mUnroll], b[mUnroll];
 #pragma unroll
         for (int u = 0; u < mUnroll; ++u) {
-            a[u] = PLEAS_GLOBAL(it.w1)[((size_t)o_[u] * it.rows_src + max(r1[u], 0)) * it.inner_v + iv_[u]];
-            b[u] = PLEAS_GLOBAL(it.w2)[((size_t)o_[u] * it.rows_src + max(r2[u], 0)) * it.inner_v + iv_[u]];
+            uint32_t src = iv_[u], row_len = it.inner_v;
+            if (it.stride > 0) {       // block-uniform
+                const uint32_t oh = iv_[u] / it.w_out, ow = iv_[u] - oh * it.w_out;
+                src = (oh * it.w_src + ow) * (uint32_t)it.stride;
+                row_len = it.inner_src;
+            }
+            a[u] = PLEAS_GLOBAL(it.w1)[((size_t)o_[u] * it.rows_src + max(r1[u], 0)) * row_len + src];
+            b[u] = PLEAS_GLOBAL(it.w2)[((size_t)o_[u] * it.rows_src + max(r2[u], 0)) * row_len + src];
         }
 #pragma unroll
         for (int u = 0; u < mUnroll; ++u) {
@@ -128,7 +138,15 @@ static int build_merge_plan(MergePlan& P, const pleas_merge_item* it, int n) {
         const pleas_merge_item& m = it[i];
         if (m.outer < 0 || m.rows_out < 0 || m.inner <= 0 || m.rows_src <= 0 || m.n_merged < 0)
             return bad_arg("merge_batch: tensor geometry");
-        const bool vec = m.inner % 4 == 0;   // pointer alignment is checked per call
+        const bool sub = m.sub_stride > 1;
+        int64_t sub_wo = 0;
+        if (sub) {
+            if (m.sub_h <= 0 || m.sub_w <= 0) return bad_arg("merge_batch: subsampled tensor without an image size");
+            sub_wo = ceil_div((int64_t)m.sub_w, m.sub_stride);
+            if (m.inner != ceil_div((int64_t)m.sub_h, m.sub_stride) * sub_wo || (int64_t)m.sub_h * m.sub_w >= (1ll << 31))
+                return bad_arg("merge_batch: inner must be ceil(sub_h / stride) * ceil(sub_w / stride)");
+        }
+        const bool vec = !sub && m.inner % 4 == 0;   // pointer alignment is checked per call
         const int64_t inner_v = vec ? m.inner / 4 : m.inner;
         const int64_t total_v = m.outer * m.rows_out * inner_v;
         if (total_v >= (1ll << 32) || inner_v >= (1ll << 32)) return bad_arg("merge_batch: tensor too large");
@@ -139,6 +157,10 @@ static int build_merge_plan(MergePlan& P, const pleas_merge_item* it, int n) {
         d.rows_src = (uint32_t)m.rows_src;
         d.n_merged = m.n_merged;
         d.vec = vec ? 4 : 1;
+        d.stride = sub ? m.sub_stride : 0;
+        d.w_out = (uint32_t)sub_wo;
+        d.w_src = sub ? (uint32_t)m.sub_w : 0u;
+        d.inner_src = sub ? (uint32_t)(m.sub_h * m.sub_w) : 0u;
         d.first_block = (int)P.block_item.size();
         const int64_t nb = ceil_div(total_v, mSpan);
         for (int64_t b = 0; b < nb; ++b) P.block_item.push_back(i);
@@ -168,7 +190,7 @@ extern "C" int pleas_merge_batch(const pleas_merge_item* items, int n_items, voi
     for (int i = 0; i < n_items; ++i) {
         const pleas_merge_item& m = items[i];
         if (!m.w1 || !m.w2 || !m.out || !m.row1 || !m.row2) return bad_arg("merge_batch: null pointer");
-        if (m.inner % 4 == 0 && ((((uintptr_t)m.w1 | (uintptr_t)m.w2 | (uintptr_t)m.out) & 15) != 0))
+        if (m.sub_stride <= 1 && m.inner % 4 == 0 && ((((uintptr_t)m.w1 | (uintptr_t)m.w2 | (uintptr_t)m.out) & 15) != 0))
             return bad_arg("merge_batch: tensors with inner % 4 == 0 must be 16-byte aligned");
     }
     hipStream_t stream = (hipStream_t)stream_;
@@ -178,7 +200,9 @@ extern "C" int pleas_merge_batch(const pleas_merge_item* items, int n_items, voi
     key.push_back((int64_t)(uintptr_t)ws);
     for (int i = 0; i < n_items; ++i) {
         const pleas_merge_item& m = items[i];
-        for (int64_t v : {m.outer, m.inner, (int64_t)m.rows_out, (int64_t)m.rows_src, (int64_t)m.n_merged}) key.push_back(v);
+        for (int64_t v : {m.outer, m.inner, (int64_t)m.rows_out, (int64_t)m.rows_src, (int64_t)m.n_merged, (int64_t)m.sub_stride,
+                          (int64_t)m.sub_h, (int64_t)m.sub_w})
+            key.push_back(v);
     }
     MergePlan* hit = g_mplans.find(key);
     if (!hit) {

@@ -618,7 +618,9 @@ class MergeBatch:
         self._fresh = 1
 
     def add(self, w1: torch.Tensor, w2: torch.Tensor, row_axis: int, row1: torch.Tensor, row2: torch.Tensor,
-            n_merged_rows: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+            n_merged_rows: int, out: Optional[torch.Tensor] = None, subsample: int = 1) -> torch.Tensor:
+        """``subsample`` = s > 1 (``[N, C, H, W]`` sources merged along axis 1 only): the output keeps every s-th pixel of
+        every s-th line, ``[N, rows, ceil(H / s), ceil(W / s)]`` -- what a 1x1 convolution with stride s reads."""
         if w1.shape != w2.shape or not w1.is_cuda or w1.dtype != torch.float32 or w2.dtype != torch.float32:
             raise PleasHipError("MergeBatch.add: fp32 CUDA sources of equal shape expected")
         w1, w2 = w1.contiguous(), w2.contiguous()
@@ -626,13 +628,19 @@ class MergeBatch:
         row_axis = row_axis % w1.dim()
         rows_out = int(row1.numel())
         want = shape[:row_axis] + [rows_out] + shape[row_axis + 1:]
+        sub = (0, 0, 0)
+        if subsample > 1:
+            if w1.dim() != 4 or row_axis != 1:
+                raise PleasHipError("MergeBatch.add: subsample needs [N, C, H, W] sources merged along axis 1")
+            sub = (int(subsample), shape[2], shape[3])
+            want = want[:2] + [-(-shape[2] // subsample), -(-shape[3] // subsample)]
         if out is None:
             out = torch.empty(want, dtype=torch.float32, device=w1.device)
         elif list(out.shape) != want or out.dtype != torch.float32 or not out.is_contiguous() or out.device != w1.device:
             raise PleasHipError("MergeBatch.add: out must be a contiguous fp32 tensor of shape %s" % (want,))
         self._keep.append((w1, w2, out, row1, row2))
-        self._geo.append((math.prod(shape[:row_axis]), math.prod(shape[row_axis + 1:]), rows_out, shape[row_axis],
-                          int(n_merged_rows)))
+        self._geo.append((math.prod(shape[:row_axis]), math.prod(want[row_axis + 1:]), rows_out, shape[row_axis],
+                          int(n_merged_rows)) + sub)
         return out
 
     def flush(self) -> None:
@@ -644,7 +652,7 @@ class MergeBatch:
         for i, ((w1, w2, out, row1, row2), geo) in enumerate(zip(self._keep, self._geo)):
             a = self._arr[i]
             a.w1, a.w2, a.out, a.row1, a.row2 = w1.data_ptr(), w2.data_ptr(), out.data_ptr(), row1.data_ptr(), row2.data_ptr()
-            a.outer, a.inner, a.rows_out, a.rows_src, a.n_merged = geo
+            a.outer, a.inner, a.rows_out, a.rows_src, a.n_merged, a.sub_stride, a.sub_h, a.sub_w = geo
         lib = _lib.lib()
         if self._ws is None:
             need = int(lib.pleas_merge_batch_ws_bytes(self._arr, n))

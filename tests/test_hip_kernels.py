@@ -416,6 +416,31 @@ def test_merge_batch_equals_single_tensor_launches(ops):
     assert torch.equal(out, (x1 + x2) * 0.5)
 
 
+def test_merge_batch_subsampled_is_what_a_strided_1x1_layer_reads(ops):
+    """``subsample=s``: the grouped merge writes every s-th pixel of every s-th line (bit-equal to slicing the plain merge),
+    odd image sizes included -- the input of a 1x1 stride-s convolution as a dense tensor."""
+    from pleas_merging_amd.methods.partial_matching import block_maps
+
+    g = torch.Generator().manual_seed(43)
+    batch = ops.MergeBatch(torch.device("cuda"))
+    outs, wants = [], []
+    for shape, s in (((3, 10, 8, 8), 2), ((2, 33, 7, 9), 2), ((4, 64, 28, 28), 2), ((2, 6, 10, 10), 3), ((2, 12, 5, 5), 1)):
+        C = shape[1]
+        p = torch.randperm(C, generator=g)
+        nm = C // 2
+        blk = (torch.arange(nm), p[:nm], torch.arange(nm, C), p[nm:])
+        x1, x2 = torch.randn(shape, generator=g).cuda(), torch.randn(shape, generator=g).cuda()
+        r1, r2, n_merged = block_maps(blk, "cuda")
+        outs.append(batch.add(x1, x2, 1, r1, r2, n_merged, subsample=s))
+        wants.append(ops.merge_blocks(x1, x2, 1, r1, r2, n_merged)[:, :, ::s, ::s])
+    batch.flush()
+    for o, w in zip(outs, wants):
+        assert o.shape == w.shape and o.is_contiguous() and torch.equal(o, w)
+    r = torch.arange(3, dtype=torch.int32, device="cuda")
+    with pytest.raises(ops.PleasHipError):      # only [N, C, H, W] tensors merged along the channel axis have lines to skip
+        batch.add(torch.zeros(2, 3, 4, device="cuda"), torch.zeros(2, 3, 4, device="cuda"), 1, r, r, 0, subsample=2)
+
+
 def test_degenerate_sizes_do_not_break_the_grouped_launches(ops):
     """One channel, one pixel, K shorter than a chunk, an all-separate merge, a 1x1 LAP: the smallest inputs every
     grouped launch may see."""

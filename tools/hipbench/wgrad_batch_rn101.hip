@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <dlfcn.h>
 #include "pleas_hip.h"
 #pragma clang diagnostic ignored "-Wunused-value"
 #pragma clang diagnostic ignored "-Wunused-result"
@@ -29,5 +30,19 @@ int main(int argc, char** argv) {
     for (int i = 0; i < reps; ++i) pleas_wgrad_batch(L.data(), n, ws, wsb, 0, 0);
     hipEventRecord(b, 0); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b);
     printf("layers=%d algorithmic %.1f GFLOP %.1f MB per update; %.3f ms per update (incl. slab reduce) -> %.1f TF/s\n", n, flops / 1e9, bytes / 1e6, ms / reps, flops / (ms / reps * 1e-3) / 1e12);
+    // PLEAS_TIMELINE_OUT=file (study builds of the library only): one more launch, its per-item record (start, end in 10 ns
+    // ticks, hardware id, work) written as int64 quadruples
+    if (const char* out = getenv("PLEAS_TIMELINE_OUT")) {
+        typedef int (*read_fn)(long long*, int);
+        read_fn rd = (read_fn)dlsym(RTLD_DEFAULT, "pleas_wgrad_timeline_read");
+        if (!rd) { printf("no timeline in this build\n"); return 1; }
+        std::vector<long long> rec((size_t)32768 * 4);
+        rd(rec.data(), 32768);                 // reset
+        hipDeviceSynchronize();
+        pleas_wgrad_batch(L.data(), n, ws, wsb, 0, 0); hipDeviceSynchronize();
+        const int got = rd(rec.data(), 32768);
+        FILE* o = fopen(out, "wb"); fwrite(rec.data(), sizeof(long long) * 4, got > 0 ? got : 0, o); fclose(o);
+        printf("timeline: %d items -> %s\n", got, out);
+    }
     return 0;
 }

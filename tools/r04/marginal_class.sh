@@ -1,0 +1,15 @@
+#!/bin/bash
+# Round-4 GPU call: marginal cost of each class of layers inside the grouped launches (all 105 layers vs all but the class)
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O; CS=$R/pleas_merging_amd/csrc; cd $R/tools/hipbench
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -I$R/include -o /tmp/wgrad_replay wgrad_batch_rn101.hip -L$CS -lpleas_hip -Wl,-rpath,$CS 2>/dev/null || exit 1
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -I$R/include -o /tmp/fwd_replay fwd_batch_rn101.hip -L$CS -lpleas_hip -Wl,-rpath,$CS 2>/dev/null || exit 1
+{ echo -n "wgrad all: "; timeout -k 10 60 /tmp/wgrad_replay rn101_layers.txt 20
+  echo -n "fwd   all: "; timeout -k 10 60 /tmp/fwd_replay rn101_layers.txt 30
+  for c in 1x1s1_big 1x1s1_hw196 1x1s1_hw49 3x3s1_big 3x3s1_14 stem 3x3s2 1x1s2; do
+    echo -n "wgrad without $c: "; timeout -k 10 60 /tmp/wgrad_replay lists/rn101_without_$c.txt 20 || exit 1
+    echo -n "fwd   without $c: "; timeout -k 10 60 /tmp/fwd_replay lists/rn101_without_$c.txt 30 || exit 1
+  done
+  for c in stem 3x3s2 1x1s2; do
+    echo -n "wgrad only $c: "; timeout -k 10 60 /tmp/wgrad_replay lists/rn101_$c.txt 20 || exit 1
+    echo -n "fwd   only $c: "; timeout -k 10 60 /tmp/fwd_replay lists/rn101_$c.txt 30 || exit 1
+  done; } > $O/r04_marginal_class.txt 2>&1; cat $O/r04_marginal_class.txt
