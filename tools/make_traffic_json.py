@@ -17,9 +17,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = {   # tag in the PMC file names -> (output file, kernels of one launch, sources, algorithmic bytes, description)
     "fwd": ("fwd_traffic.json", ("fwd_batch_kernel",), ("pleas_merging_amd/csrc/conv_fwd.hip", "pleas_merging_amd/csrc/common.hpp"),
-            4304600000.0, "one ResNet-101 PLeaS update: 105 merged layers, batch 16, full merge (tools/hipbench/fwd_batch_rn101.hip)"),
+            4237100000.0, "one ResNet-101 PLeaS update: 105 merged layers, batch 16, full merge (tools/hipbench/fwd_batch_rn101.hip on lists/rn101_dense_downsample.txt: the three strided 1x1 layers as the dense layers the subsampled merge makes of them)"),
     "wgrad": ("wgrad_traffic.json", ("wgrad_batch_kernel",), ("pleas_merging_amd/csrc/conv.hip", "pleas_merging_amd/csrc/common.hpp"),
-              2226800000.0, "one ResNet-101 PLeaS update: all 105 merged layers, batch 16 (wgrad_batch_rn101.hip; the 3-channel stem as virtual-channel rows since round 4)"),
+              2159300000.0, "one ResNet-101 PLeaS update: all 105 merged layers, batch 16 (wgrad_batch_rn101.hip on lists/rn101_dense_downsample.txt; the 3-channel stem as virtual-channel rows since round 4)"),
     "gram": ("gram_traffic.json", ("gram_batch_kernel",), ("pleas_merging_amd/csrc/gram.hip", "pleas_merging_amd/csrc/common.hpp"),
              5132100000.0, "one ResNet-101 matching batch as bench.py runs it: 240 nodes contracted, 104 BatchNorm nodes derived (gram_batch_rn101.hip, rn101_nodes_derived.txt)"),
     "neq": ("neq_traffic.json", ("neq_batch_kernel",), ("pleas_merging_amd/csrc/normal_eq.hip", "pleas_merging_amd/csrc/common.hpp"),

@@ -27,7 +27,7 @@ if [ "$2" != "skip-bench" ]; then
 fi
 cd $R/tools/hipbench; CS=$R/pleas_merging_amd/csrc
 for h in fwd_batch_rn101 wgrad_batch_rn101 gram_batch_rn101 neq_batch_rn101; do
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -I$R/include -o /tmp/$h $h.hip -L$CS -lpleas_hip -Wl,-rpath,$CS 2>/dev/null || echo "build of $h failed"
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -I$R/include -o /tmp/$h $h.hip -L$CS -lpleas_hip -Wl,-rpath,$CS -ldl 2>/dev/null || echo "build of $h failed"
 done
 cd /tmp && export TMPDIR=/tmp
 run() {  # harness, input file, extra arg, tag, kernel filters...
@@ -40,7 +40,8 @@ run() {  # harness, input file, extra arg, tag, kernel filters...
     [ -n "$f" ] && python3 $R/tools/pmc_summary.py $f "$@" > $O/r04_${V}_pmc_${tag}_$c.txt
   done
 }
-run fwd_batch_rn101 $R/tools/hipbench/rn101_layers.txt "" fwd fwd_batch
-run wgrad_batch_rn101 $R/tools/hipbench/rn101_layers.txt "" wgrad wgrad_batch wgrad_reduce
+# forward / weight gradient: the layer list as the fitter hands it over (strided 1x1 layers as dense layers on the subsampled merge)
+run fwd_batch_rn101 $R/tools/hipbench/lists/rn101_dense_downsample.txt "" fwd fwd_batch
+run wgrad_batch_rn101 $R/tools/hipbench/lists/rn101_dense_downsample.txt "" wgrad wgrad_batch wgrad_reduce
 run gram_batch_rn101 $R/tools/hipbench/rn101_nodes_derived.txt "" gram gram_batch gram_group_reduce
 run neq_batch_rn101 $R/tools/hipbench/rn101_layers.txt 0 neq neq_batch neq_reduce
