@@ -24,6 +24,8 @@ Besides the contract's keys the JSON line carries
                 at the job's batch size (bounded count), N = 1 only; the same sample gives checks.parity_vs_oracle;
   phases_s      one more (untimed, synchronised) job split into spec / matching / LAP / merge + set-up / updates;
   alt_solver    the closed-form PLeaS phase (solver="normal_eq": MFMA normal equations + batched Cholesky), N = 1;
+  library_baseline  the reference's loops with STOCK PyTorch-ROCm operators on the same GPU (torch.cdist, autograd convolutions,
+                torch.optim.Adam, scipy LAP after D2H), bounded sample scaled like cpu_baseline, N = 1 only;
   vendor        the frozen source forwards of the PLeaS phase (vendor convolutions + pleas_bn_act) timed alone;
   checks        invariants of the last timed job's result (permutations valid, losses fell, weights finite) and
                 parity_vs_oracle: the HIP job with the timed knobs against the oracle on the same batches (exit 3 on failure).
@@ -65,6 +67,7 @@ def parse(argv=None):
                          "batch statistics and moves its running statistics; `train` puts the sources in eval mode as ever")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-solver", action="store_true", help="skip the closed-form (normal equations) leg")
+    ap.add_argument("--no-library-baseline", action="store_true", help="skip the stock-PyTorch-ROCm-operators leg on the GPU")
     ap.add_argument("--no-phases", action="store_true", help="skip the extra synchronised job that fills phases_s")
     ap.add_argument("--phase-log", action="store_true", help="debug: log the phases of that job as they finish")
     ap.add_argument("--prefetch-groups", type=int, default=2,
@@ -124,6 +127,12 @@ def self_launch(args) -> int:
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // max(1, args.gpus))))
     return subprocess.call(cmd, env=env)
+
+
+def source_conv_mode():
+    from pleas_merging_amd.methods import source_forward
+
+    return source_forward.SOURCE_CONV
 
 
 def usable_cores():
@@ -509,6 +518,167 @@ def cpu_baseline_and_parity(cfg, spec, m1, m2, pool, n_match, n_pleas, n_sched, 
     return cpu, parity
 
 
+class _NodeTap(torch.fx.Interpreter):
+    """Keeps a tracked node's value at the moment it is produced (before a later in-place ReLU can overwrite it), which is
+    when the reference's cross module evaluates it (activation_matching.py:90-92)."""
+
+    def __init__(self, gm, wanted):
+        super().__init__(gm)
+        self.wanted, self.kept = set(wanted), {}
+
+    def run_node(self, n):
+        out = super().run_node(n)
+        if n.name in self.wanted and torch.is_tensor(out):
+            self.kept[n.name] = out.clone()
+        return out
+
+
+def library_baseline(cfg, spec, m1, m2, pool, n_match, n_pleas, n_sched, sample_match, sample_updates, perm, costs):
+    """The reference's loops on THIS GPU with stock PyTorch-ROCm operators -- what the reference itself would do on the card
+    (SURVEY.md 8(d) last row), beside the own-kernel job: per tracked node ``-torch.cdist`` of the two
+    models' activations, summed per node and per group (activation_matching.py:31-46, :119-134); D2H + scipy's LAP
+    (core/solvers.py:29-31); per update two hooked source forwards, per layer ``l1(ip1)``, ``l2(ip2)``, the index_select /
+    cat assembly of (ip, op), ``((layer(ip) - op) ** 2).mean()``, one backward, the gradient mask, ``torch.optim.Adam`` and
+    the cosine schedule (pleas_merging.py:63-149, :262-291, :358-375).  Vendor kernels only (MIOpen, rocBLAS / Tensile, ATen);
+    only the one-off partial merge (merge_s) is the library's.  Timed on a bounded sample of the job's own batches after one
+    untimed pass (MIOpen's first-use work), counts scaled to the job -- as ``cpu_baseline`` is."""
+    import copy
+
+    import torch.nn as nn
+    from scipy.optimize import linear_sum_assignment
+
+    from pleas_merging_amd.core.utils import Axis
+    from pleas_merging_amd.methods.partial_matching import get_blocks, partial_merge, spread_blocks
+
+    dev = next(m1.parameters()).device
+    nM, nU = min(n_match, sample_match), min(n_pleas, sample_updates)
+    tracked = [ax for pg in spec.values() for ax in pg.node]
+    names = {ax.key for ax in tracked}
+    m1.eval()
+    m2.eval()
+    taps = [_NodeTap(torch.fx.symbolic_trace(m), names) for m in (m1, m2)]
+
+    def cross(x, y, a):
+        xf = torch.movedim(x, a, 0).reshape(x.shape[a], -1)
+        yf = torch.movedim(y, a, 0).reshape(y.shape[a], -1)
+        return -torch.cdist(xf[None], yf[None])[0]
+
+    def matching(loader):
+        per_node = {}
+        with torch.inference_mode():
+            for x, _ in loader:
+                x = x.to(dev)
+                for t in taps:
+                    t.kept = {}
+                    t.run(x)
+                for ax in tracked:
+                    val = cross(taps[0].kept[ax.key], taps[1].kept[ax.key], ax.axis)
+                    per_node[ax] = per_node[ax] + val if ax in per_node else val
+        out = {}
+        for key, pg in spec.items():
+            total = 0
+            for nax in pg.node:
+                total = total + per_node[nax]
+            out[key] = total
+        return out
+
+    matching(pool.loader(0, 1))      # untimed: first use of every operator configuration
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    lib_costs = matching(pool.loader(0, nM))
+    torch.cuda.synchronize()
+    t_match = (time.perf_counter() - t0) / nM
+    t0 = time.perf_counter()
+    lib_perm = {}
+    for k, v in lib_costs.items():      # the reference's solver: D2H, scipy, maximize
+        rows, cols = linear_sum_assignment(v.detach().cpu().numpy(), maximize=True)
+        lib_perm[k] = torch.from_numpy(cols)
+    t_lap = time.perf_counter() - t0
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+    worst_cost = None
+    if nM == n_match:      # the own-kernel job's costs cover the same batches only when nothing was subsampled
+        worst_cost = max(rel(lib_costs[k], costs[k]) for k in spec)
+    del lib_costs, taps
+    # ---- PLeaS updates, the reference's step() with stock autograd
+    t0 = time.perf_counter()
+    m3 = partial_merge(spec, m1, m2, perm, costs, cfg["ratio"], device=dev)
+    t_merge = time.perf_counter() - t0
+    blocks = spread_blocks(spec, get_blocks(spec, perm, costs, cfg["ratio"], False))
+    layers = {n: copy.deepcopy(m).to(dev) for n, m in m3.named_modules() if isinstance(m, (nn.Conv2d, nn.Linear))}
+    src1, src2 = dict(m1.named_modules()), dict(m2.named_modules())
+    params, masks = [], []
+    for name, layer in layers.items():
+        bi, bo = blocks.get(Axis(name + ".weight", 1)), blocks.get(Axis(name + ".weight", 0))
+        ni, mi = (len(bi[0]), len(bi[2])) if bi is not None else (3, 0)
+        no, mo = (len(bo[0]), len(bo[2])) if bo is not None else (1000, 0)
+        for prm in layer.parameters():
+            prm.requires_grad_(True)
+            params.append(prm)
+            mk = torch.ones_like(prm)
+            if prm.dim() >= 2:      # the reference's transposed indexing (pleas_merging.py:57-58)
+                mk[ni:ni + mi, no + mo:no + 2 * mo] = 0.0
+                mk[ni + mi:ni + 2 * mi, no:no + mo] = 0.0
+            masks.append(mk)
+    opt = torch.optim.Adam(params, lr=5e-4)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, n_sched)
+    acts1, acts2, handles = {}, {}, []
+    for model, store in ((m1, acts1), (m2, acts2)):
+        for name, mod in model.named_modules():
+            if isinstance(mod, (nn.Conv2d, nn.Linear, nn.LayerNorm)):
+                handles.append(mod.register_forward_hook(lambda m, i, o, name=name, store=store: store.__setitem__(name, i[0])))
+    sel = lambda t, idx: t.index_select(1, idx)
+
+    def update(x):
+        with torch.no_grad():
+            m1(x)
+            m2(x)
+        opt.zero_grad()
+        total = 0.0
+        for name, layer in layers.items():
+            with torch.no_grad():
+                ip1, ip2 = acts1[name], acts2[name]
+                bo, bi = blocks.get(Axis(name + ".weight", 0)), blocks.get(Axis(name + ".weight", 1))
+                if bo is None:
+                    w = torch.arange(1000, device=dev)
+                    bo = (w, w, w[:0], w[:0])
+                if bi is None:
+                    w = torch.arange(ip1.shape[1], device=dev)
+                    bi = (w, w, w[:0], w[:0])
+                o1, o2 = src1[name](ip1), src2[name](ip2)
+                ip = torch.cat([(sel(ip1, bi[0]) + sel(ip2, bi[1])) / 2, sel(ip1, bi[2]), sel(ip2, bi[3])], 1)
+                op = torch.cat([(sel(o1, bo[0]) + sel(o2, bo[1])) / 2, sel(o1, bo[2]), sel(o2, bo[3])], 1)
+            total = total + ((layer(ip) - op) ** 2).mean()
+        total.backward()
+        for prm, mk in zip(params, masks):
+            prm.grad *= mk
+        opt.step()
+        sched.step()
+        acts1.clear()
+        acts2.clear()
+        return total.detach()
+
+    xs = [x.to(dev) for x, _ in pool.loader(0, nU)]
+    update(xs[0])      # untimed (first use of every backward configuration); its step is part of the state, as in any warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for x in xs:
+        last = update(x)
+    torch.cuda.synchronize()
+    t_step = (time.perf_counter() - t0) / nU
+    for h in handles:
+        h.remove()
+    total = n_match * t_match + t_lap + t_merge + n_pleas * t_step
+    log("library baseline (stock PyTorch-ROCm ops on this GPU): matching batch %.3fs, scipy LAPs %.2fs, update %.3fs -> %.1fs per job"
+        % (t_match, t_lap, t_step, total))
+    return {"value": round(total, 2), "unit": "s", "kind": "stock PyTorch-ROCm operators on the same GPU (torch.cdist, MIOpen / "
+            "Tensile convolutions under autograd, torch.optim.Adam, scipy LAP after D2H): the reference's own loops",
+            "matching_batch_s": round(t_match, 4), "scipy_lap_s": round(t_lap, 3), "merge_s": round(t_merge, 3),
+            "update_s": round(t_step, 4), "loss_last_update": float(last),
+            "worst_group_cost_rel_fro_vs_own_kernels": worst_cost,
+            "sample": "%d matching batches + %d updates of the job's own batches at batch %d after one untimed pass each, all %d "
+                      "LAPs; counts scaled to %d + %d" % (nM, nU, xs[0].shape[0], len(lib_perm), n_match, n_pleas)}
+
+
 def cpu_reference_legs(costs, hip_perm, alt):
     """north_star's CPU path as worded -- "scipy LAP + torch.linalg.lstsq" -- on this box's host cores:
     * ``scipy.optimize.linear_sum_assignment(maximize=True)`` (the reference's solver, core/solvers.py:29-31) on the 71 cost
@@ -732,6 +902,13 @@ def main():
                   "note": "frozen source forwards of the PLeaS phase (MIOpen / Tensile convolutions + pleas_bn_act, both "
                           "models, %d samples per forward) with nothing else on the GPU; rocprofv3 kernel shares: profiles/"
                           % ((cfg["sources_per_forward"] or 2) * args.batch)}
+    library = None
+    if world == 1 and args.emulate_world <= 1 and not args.no_library_baseline:
+        library = library_baseline(cfg, spec, m1, m2, pool, n_match, n_pleas, n_sched, args.cpu_match_batches, args.cpu_updates,
+                                   res["perm"], res["costs"])
+        library["own_kernels_speedup"] = round(library["value"] / value, 2)
+        gc.collect()
+        torch.cuda.empty_cache()
     if rank == 0:  # {kernel: (launches, total_ms, flops, bytes)}
         labels = {
             "gram_partial": "gram_batch_kernel (grouped fp32 MFMA 32x32x2 contraction, one launch per matching batch)",
@@ -802,10 +979,11 @@ def main():
                 "host_gc": "collected once per job while the LAP kernel runs" if args.gc == "lap" else "interpreter default",
                 "inputs": "HBM-resident batches" if args.inputs == "resident" else "pinned host batches, copied host -> device inside the loops",
                 "matching_mode": args.match_mode,
-                "vendor_convolutions": "MIOpen, Winograd kernels %s (MIOPEN_DEBUG_CONV_WINOGRAD=%s; the library's default is "
-                                       "off: the direct kernels are as fast here and keep parity inside the oracle's own spread)"
-                                       % ("off" if os.environ.get("MIOPEN_DEBUG_CONV_WINOGRAD") == "0" else "on",
-                                          os.environ.get("MIOPEN_DEBUG_CONV_WINOGRAD")),
+                "source_convolutions": {"kxk": "k x k layers of the frozen source / twin forwards on the library's own kernel "
+                                                   "(pleas_conv2d_fwd: repeatable bits), 1 x 1 layers on the vendor's GEMM",
+                                            "all": "every convolution of the frozen source / twin forwards on the library's own kernel",
+                                            "vendor": "MIOpen / Tensile for every convolution of the frozen source / twin forwards "
+                                                      "(rounds 1-4; not run-to-run deterministic)"}[source_conv_mode()],
                 "not_in_value": "get_permutation_spec %.2f s (host, once per model)" % spec_s,
             },
             "job_s": {"mean": round(value, 4), "median": round(srt[len(srt) // 2], 4), "min": round(srt[0], 4),
@@ -853,6 +1031,8 @@ def main():
             out["alt_solver_emulated_rank"] = alt_emulated
         if inputs_cmp is not None:
             out["inputs"] = inputs_cmp
+        if library is not None:
+            out["library_baseline"] = library
         if vendor is not None:
             out["vendor"] = vendor
         if bn_reset is not None:

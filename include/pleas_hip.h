@@ -308,6 +308,14 @@ int pleas_fwd_plan_lanes(double* form_ms, int* form_lane, int* form_items);
 int pleas_fwd_plan_units(const pleas_fwd_layer* layers, int n_layers, const double* form_ms, int* units, int max_units);
 int pleas_fwd_batch(const pleas_fwd_layer* layers, int n_layers, float* loss, void* ws, size_t ws_bytes, int ws_fresh,
                     void* stream);
+/* pleas_conv2d_fwd: a plain convolution  y = conv(x, w) (+ bias)  on the tile forms of pleas_fwd_batch (fp32 MFMA 32x32x2,
+ * fixed summation order: bit-for-bit repeatable, unlike MIOpen's split-K 3 x 3 kernels).  Replaces the vendor convolution under
+ * the frozen sources' k x k layers -- the two `model(x)` calls of pleas/methods/pleas_merging.py:267-268 and of the twin
+ * graph, activation_matching.py:49-100 -- so that the same job returns the same assignment and weights run after run.
+ *   x [N][Cin][Hin][Win], w [Cout][Cin][KH][KW] (or [Cout][KH][KW][Cin] with PLEAS_FWD_KPOS_MAJOR), y [N][Cout][Hout][Wout];
+ *   x and w 16-byte aligned; square kernels up to 64 taps; no workspace, no tables: the layer rides in the kernel arguments. */
+int pleas_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int Hin, int Win, int Cout,
+                     int KH, int KW, int stride, int pad, int flags, void* stream);
 /* Host only (no GPU): the plan of the STREAMED form of pleas_fwd_batch (one persistent workgroup per CU walking a list of
  * work items, producer / consumer waves; csrc/conv_fwd_stream.hip) for `layers` on `n_workgroups` workgroups (<= 0: the
  * device's CU count, 256 without a device).  info[8]: work items, workgroups, items of the VEC / FLAT / GEN input forms,

@@ -382,9 +382,10 @@ def _hook_inputs(model, store):
 
 
 def train(batches, model1, model2, model3, spec, perm, costs, ratios, max_steps: int, num_classes=1000, lr=5e-4,
-          separate_classifier=False, model_type="rn50", merging="perm_gradmask", on_update=None):
+          separate_classifier=False, model_type="rn50", merging="perm_gradmask", on_update=None, dtype=torch.float32):
     """Reference: pleas/methods/pleas_merging.py:305-405 (step: :234-302); ``merging`` as in :func:`layer_targets`.
     Adam + cosine schedule on copies of model3's Conv/Linear layers; ``max_steps + 1`` updates.
+    ``dtype=torch.float64`` (with fp64 models and batches): the fp64 ANCHOR of :func:`fp64_anchor`, not the reference's arithmetic.
     ``on_update(idx, layers, per_layer_losses)`` (test aid, not in the reference): called after update ``idx`` with the
     layers being trained and this update's loss per layer, so that a trajectory can be recorded."""
     perm_blocks = spread_blocks(spec, get_blocks(spec, perm, costs, ratios))
@@ -392,7 +393,7 @@ def train(batches, model1, model2, model3, spec, perm, costs, ratios, max_steps:
     handles = _hook_inputs(model1, acts1) + _hook_inputs(model2, acts2)
     model1.eval()
     model2.eval()
-    layers = {n: deepcopy(m).float() for n, m in model3.named_modules() if isinstance(m, (nn.Conv2d, nn.Linear))}
+    layers = {n: deepcopy(m).to(dtype) for n, m in model3.named_modules() if isinstance(m, (nn.Conv2d, nn.Linear))}
     params = []
     for layer in layers.values():
         for p in layer.parameters():
@@ -437,6 +438,26 @@ def train(batches, model1, model2, model3, spec, perm, costs, ratios, max_steps:
     for h in handles:
         h.remove()
     return model3, losses
+
+
+def fp64_anchor(spec, model1, model2, batches, n_match: int, n_updates: int, perm, costs, ratios, max_steps: int,
+                num_classes=1000):
+    """The SAME path in fp64 on the same batches: what the reference's fp32 arithmetic (pleas_merging.py:281-291,
+    activation_matching.py:119-134) and any second fp32 implementation of it both approximate.  Distances TO this anchor are
+    statements about accuracy; distances between two fp32 runs are statements about spread.
+    Matching costs: fp64 models and batches through :func:`matching_costs`.  Training: the fp32-merged model (the merge is
+    exact and shared by both sides) cast to fp64, fp64 sources, ``n_updates`` Adam updates from ``perm`` / ``costs``.
+    Returns (costs64 or None, trained fp64 state dict or None)."""
+    d1, d2 = deepcopy(model1).double().eval(), deepcopy(model2).double().eval()
+    data = [(x.double(), y) for x, y in batches[:max(n_match, n_updates)]]
+    costs64 = matching_costs(spec, d1, d2, data[:n_match], n_match, accumulate=True) if n_match > 0 else None
+    trained = None
+    if n_updates > 0:
+        o3 = partial_merge(spec, model1, model2, perm, costs, ratios).double()
+        o3, _ = train(data[:n_updates], d1, d2, o3, spec, perm, costs, ratios, max_steps, num_classes=num_classes,
+                      dtype=torch.float64)
+        trained = {k: v.clone() for k, v in o3.state_dict().items()}
+    return costs64, trained
 
 
 # ============================================================================ closed form (north star)

@@ -4,14 +4,8 @@ Host side mirrors the reference's ``pleas.core`` / ``pleas.methods`` API; the
 compute is done by hand-written gfx950 HIP kernels behind the C-ABI declared in
 ``include/pleas_hip.h`` (library ``pleas_merging_amd/csrc/libpleas_hip.so``).
 """
-import os as _os
+# Importing this package changes nothing in the process (rounds 1-4 set MIOPEN_DEBUG_CONV_WINOGRAD here): the k x k convolutions
+# of the frozen source / twin forwards -- the only ones whose vendor kernels mattered for parity -- run on the library's own kernel
+# since round 5 (methods/source_forward.py: SOURCE_CONV; PLEAS_SOURCE_CONV=vendor restores the vendor path).
 
-# The frozen source / twin forwards run on the vendor's convolutions.  At 128-160 samples per forward MIOpen's immediate mode
-# picks its Winograd F(2,3) kernels for the 3x3 layers; their rounding is what moves one trained tensor of the ResNet-101 job
-# past 3x the CPU reference's own run-to-run spread (DESIGN.md section 3.3, profiles/r04_timed_config_parity*.json), and the vendor's direct
-# kernels are as fast on this job (6.20 s vs 6.19-6.21 s per job, profiles/r04_bench_nowinograd.json).  So the library asks
-# for the direct kernels unless the caller has decided otherwise: MIOpen reads this variable once, at its first convolution;
-# set MIOPEN_DEBUG_CONV_WINOGRAD=1 before importing this package to keep the vendor's own choice.
-_os.environ.setdefault("MIOPEN_DEBUG_CONV_WINOGRAD", "0")
-
-__version__ = "0.4.0"
+__version__ = "0.5.0"

@@ -73,6 +73,7 @@ SIGNATURES = {
     "pleas_fwd_stream": (None, [c_int]),
     "pleas_allreduce_sum": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "pleas_fwd_batch": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "pleas_conv2d_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
     "pleas_wgrad_batch_ws_bytes": (c_size_t, [c_void_p, c_int]),
     "pleas_wgrad_batch": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "pleas_gram_batch_ws_bytes": (c_size_t, [c_void_p, c_int, POINTER(c_int), c_int]),
@@ -116,7 +117,7 @@ class GramNode(ctypes.Structure):
                 ("scale_y", c_void_p), ("shift_y", c_void_p)]
 
 PROF_KERNELS = ["gram_partial", "gram_finalize", "lsap", "merge_blocks", "masked_adam", "sqerr", "conv_fwd",
-                "conv_wgrad", "normal_eq", "solve", "bn_act"]
+                "conv_wgrad", "normal_eq", "solve", "bn_act", "conv2d"]
 
 
 class PleasHipError(RuntimeError):

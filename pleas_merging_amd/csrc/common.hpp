@@ -51,7 +51,7 @@ typedef __attribute__((address_space(1))) const int gcint;
 
 // ---- opt-in per-kernel timing with HIP events on the launch stream (pleas_prof_* in the C-ABI)
 enum ProfKernel { kProfGramPartial = 0, kProfGramFinalize, kProfLsap, kProfMergeBlocks, kProfMaskedAdam, kProfSqerr,
-                  kProfConvFwd, kProfConvWgrad, kProfNormalEq, kProfSolve, kProfBnAct, kProfCount };
+                  kProfConvFwd, kProfConvWgrad, kProfNormalEq, kProfSolve, kProfBnAct, kProfConv2d, kProfCount };
 extern bool g_prof_on;
 extern unsigned g_prof_mask;   // bit k set: kernel id k is recorded while profiling is on
 void prof_begin(int kernel, double flops, double bytes, hipStream_t stream);

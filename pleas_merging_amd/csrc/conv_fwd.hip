@@ -78,8 +78,9 @@ __device__ __forceinline__ void fwd_load_maps(const FwdLayerDev& L, const int i0
 #pragma unroll
     for (int j = 0; j < TM / 8; ++j) {
         const int co = min(i0 + (tid >> 5) + 8 * j, L.Cout - 1);
-        m1[j] = PLEAS_GLOBAL_I(L.row1)[co];
-        m2[j] = PLEAS_GLOBAL_I(L.row2)[co];
+        // a plain convolution (pleas_conv2d_fwd) has no block maps: every source row is absent, the target is zero
+        m1[j] = L.row1 ? PLEAS_GLOBAL_I(L.row1)[co] : -1;
+        m2[j] = L.row2 ? PLEAS_GLOBAL_I(L.row2)[co] : -1;
         bias_v[j] = L.bias ? PLEAS_GLOBAL(L.bias)[co] : 0.f;
     }
 }
@@ -212,7 +213,7 @@ __device__ __forceinline__ void fwd_epilogue(const FwdLayerDev& L, const FwdItem
     __syncthreads();  // everyone is done with Ct: reuse its first floats for the block sum
     if (lane == 0) smem[wave] = sq;
     __syncthreads();
-    if (tid == 0) partials[L.part_base + it.slot] = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+    if (tid == 0 && partials) partials[L.part_base + it.slot] = (smem[0] + smem[1]) + (smem[2] + smem[3]);
 }
 
 template <int TM, int VECA>
@@ -810,6 +811,19 @@ __global__ __launch_bounds__(fThreads, 2) void fwd_batch_kernel(const FwdLayerDe
     else if constexpr (FORM < 7) fwd_flat_tile<128, FORM - 4>(L, it, smem, partials);
     else fwd_flat_tile<64, FORM - 7>(L, it, smem, partials);
 }
+// A plain convolution (pleas_conv2d_fwd): ONE layer, described in the kernel arguments; the work item is the block index
+// (output-channel tile fastest, as in the grouped plan), no tables, no target, no loss.
+template <int FORM>
+__global__ __launch_bounds__(fThreads, 2) void conv2d_fwd_kernel(const FwdLayerDev L, const int tms) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const FwdItemDev it{0, (int)(blockIdx.x % (unsigned)tms), (int)(blockIdx.x / (unsigned)tms), 0};
+    if constexpr (FORM == 0) fwd_tile<128, 4>(L, it, smem, nullptr);
+    else if constexpr (FORM == 1) fwd_tile<64, 4>(L, it, smem, nullptr);
+    else if constexpr (FORM == 2) fwd_tile<128, 1>(L, it, smem, nullptr);
+    else if constexpr (FORM == 3) fwd_tile<64, 1>(L, it, smem, nullptr);
+    else if constexpr (FORM < 7) fwd_flat_tile<128, FORM - 4>(L, it, smem, nullptr);
+    else fwd_flat_tile<64, FORM - 7>(L, it, smem, nullptr);
+}
 // side streams + events of the library for the concurrent forms (created once per process; no device memory)
 constexpr int fLanes = 3;          // side streams (+ the caller's stream = four hardware queues)
 struct FwdSideStreams {
@@ -1050,6 +1064,52 @@ static bool fwd_schedule_measured(FwdPlan& P) {
     return true;
 }
 
+// Geometry checks, tile height, tile form and LDS bytes of ONE layer (shared by the grouped plan and the plain convolution).
+static int fwd_describe(const pleas_fwd_layer& l, FwdLayerDev& d, size_t& lds_bytes, int& TM_out) {
+    if (l.N <= 0 || l.Cout <= 0 || l.Cin <= 0 || l.Hin <= 0 || l.Win <= 0 || l.KH <= 0 || l.KW <= 0 || l.stride <= 0 ||
+        l.pad < 0 || l.Csrc <= 0 || l.n_merged < 0)
+        return bad_arg("conv_fwd: layer geometry");
+    const int Hout = (l.Hin + 2 * l.pad - l.KH) / l.stride + 1, Wout = (l.Win + 2 * l.pad - l.KW) / l.stride + 1;
+    if (Hout <= 0 || Wout <= 0) return bad_arg("conv_fwd: empty output");
+    if (l.KH * l.KW > 64) return bad_arg("conv_fwd: kernels larger than 64 taps are not supported");
+    const int64_t HWo = (int64_t)Hout * Wout, Ptot = (int64_t)l.N * HWo, Kd = (int64_t)l.Cin * l.KH * l.KW;
+    if (Ptot >= (1ll << 31) || (int64_t)l.Cout * Kd >= (1ll << 32)) return bad_arg("conv_fwd: tensor too large");
+    if (Ptot * std::max(l.Cout, l.Csrc) >= (1ll << 30)) return bad_arg("conv_fwd: outputs of 4 GB and more per call are not supported");
+    d.Cout = l.Cout; d.Cin = l.Cin; d.Hin = l.Hin; d.Win = l.Win; d.Hout = Hout; d.Wout = Wout;
+    d.KH = l.KH; d.KW = l.KW; d.stride = l.stride; d.pad = l.pad; d.Csrc = l.Csrc; d.n_merged = l.n_merged;
+    d.HWo = (uint32_t)HWo; d.Ptot = (uint32_t)Ptot; d.Kd = (uint32_t)Kd;
+    d.dscale = l.dscale;
+    // short-K layers (1x1 with few input channels) are bound by their epilogue's memory traffic, not by the MFMAs:
+    // 64-row tiles (52 KB of LDS, <= 132 registers) let THREE workgroups share a CU and overlap more of it
+    static const int tm64_k = std::getenv("PLEAS_FWD_TM64_K") ? std::atoi(std::getenv("PLEAS_FWD_TM64_K")) : 256;
+    const int TM = (l.Cout > 64 && !(l.KH * l.KW == 1 && l.stride == 1 && Kd <= tm64_k && l.Cin % fBK == 0)) ? 128 : 64;
+    d.variant = (TM == 64 ? 1 : 0) | (Kd % 4 == 0 ? 0 : 2);
+    if (l.flags & PLEAS_FWD_KPOS_MAJOR) {
+        if (l.Cin % fBK != 0) return bad_arg("conv_fwd: kernel-position-major weights need Cin % 32 == 0");
+        d.variant |= 4;
+    }
+    lds_bytes = (size_t)(2 * TM * fLdsA + 2 * fTN * fLdsB) * sizeof(float);  // >= TM*132 floats (epilogue)
+    {
+        // flat-shift form: stride 1, square odd kernel with "same" padding, whole 32-channel blocks, and (for k > 1)
+        // kernel-position-major weights; its LDS must not exceed the general form's (two workgroups per CU)
+        static const bool flat_on = !(std::getenv("PLEAS_FWD_FLAT") && std::atoi(std::getenv("PLEAS_FWD_FLAT")) == 0);
+        const int R = l.KH * l.KW;
+        const bool same = l.stride == 1 && l.KH == l.KW && (l.KH & 1) && l.pad == (l.KH - 1) / 2;
+        const int halo = l.pad * (l.Win + 1);
+        const int kind = R > 1 ? 2 : (HWo % 4 == 0 ? 0 : 1);
+        const int Lr = kind == 2 ? fFlatColsK : fFlatRow1;      // k x k: columns of the [column][36] image, zero row included
+        const size_t flat_lds = std::max((size_t)(2 * TM * fLdsA + (kind == 2 ? fFlatColsK * fFlatPix : 2 * fBK * Lr)) * sizeof(float),
+                                         (size_t)TM * 132 * sizeof(float));
+        if (flat_on && same && l.Cin % fBK == 0 && R <= 32 && (R == 1 || (l.flags & PLEAS_FWD_KPOS_MAJOR)) &&
+            fTN + 2 * halo < Lr && flat_lds <= lds_bytes && (int64_t)l.N * l.Cin * HWo < (1ll << 32)) {
+            d.variant |= 8 | (kind << 4);
+            lds_bytes = flat_lds;
+        }
+    }
+    TM_out = TM;
+    return PLEAS_OK;
+}
+
 static std::mutex g_fplan_mu;
 static size_t falign(size_t v) { return (v + 255) / 256 * 256; }
 
@@ -1065,47 +1125,11 @@ static int build_fwd_plan(FwdPlan& P, const pleas_fwd_layer* ly, int n) {
     int parts = 0;
     for (int i = 0; i < n; ++i) {
         const pleas_fwd_layer& l = ly[i];
-        if (l.N <= 0 || l.Cout <= 0 || l.Cin <= 0 || l.Hin <= 0 || l.Win <= 0 || l.KH <= 0 || l.KW <= 0 || l.stride <= 0 ||
-            l.pad < 0 || l.Csrc <= 0 || l.n_merged < 0)
-            return bad_arg("conv_fwd: layer geometry");
-        const int Hout = (l.Hin + 2 * l.pad - l.KH) / l.stride + 1, Wout = (l.Win + 2 * l.pad - l.KW) / l.stride + 1;
-        if (Hout <= 0 || Wout <= 0) return bad_arg("conv_fwd: empty output");
-        if (l.KH * l.KW > 64) return bad_arg("conv_fwd: kernels larger than 64 taps are not supported");
-        const int64_t HWo = (int64_t)Hout * Wout, Ptot = (int64_t)l.N * HWo, Kd = (int64_t)l.Cin * l.KH * l.KW;
-        if (Ptot >= (1ll << 31) || (int64_t)l.Cout * Kd >= (1ll << 32)) return bad_arg("conv_fwd: tensor too large");
-        if (Ptot * std::max(l.Cout, l.Csrc) >= (1ll << 30)) return bad_arg("conv_fwd: outputs of 4 GB and more per call are not supported");
         FwdLayerDev& d = P.layers[i];
-        d.Cout = l.Cout; d.Cin = l.Cin; d.Hin = l.Hin; d.Win = l.Win; d.Hout = Hout; d.Wout = Wout;
-        d.KH = l.KH; d.KW = l.KW; d.stride = l.stride; d.pad = l.pad; d.Csrc = l.Csrc; d.n_merged = l.n_merged;
-        d.HWo = (uint32_t)HWo; d.Ptot = (uint32_t)Ptot; d.Kd = (uint32_t)Kd;
-        d.dscale = l.dscale;
-        // short-K layers (1x1 with few input channels) are bound by their epilogue's memory traffic, not by the MFMAs:
-        // 64-row tiles (52 KB of LDS, <= 132 registers) let THREE workgroups share a CU and overlap more of it
-        static const int tm64_k = std::getenv("PLEAS_FWD_TM64_K") ? std::atoi(std::getenv("PLEAS_FWD_TM64_K")) : 256;
-        const int TM = (l.Cout > 64 && !(l.KH * l.KW == 1 && l.stride == 1 && Kd <= tm64_k && l.Cin % fBK == 0)) ? 128 : 64;
-        d.variant = (TM == 64 ? 1 : 0) | (Kd % 4 == 0 ? 0 : 2);
-        if (l.flags & PLEAS_FWD_KPOS_MAJOR) {
-            if (l.Cin % fBK != 0) return bad_arg("conv_fwd: kernel-position-major weights need Cin % 32 == 0");
-            d.variant |= 4;
-        }
-        size_t lds_bytes = (size_t)(2 * TM * fLdsA + 2 * fTN * fLdsB) * sizeof(float);  // >= TM*132 floats (epilogue)
-        {
-            // flat-shift form: stride 1, square odd kernel with "same" padding, whole 32-channel blocks, and (for k > 1)
-            // kernel-position-major weights; its LDS must not exceed the general form's (two workgroups per CU)
-            static const bool flat_on = !(std::getenv("PLEAS_FWD_FLAT") && std::atoi(std::getenv("PLEAS_FWD_FLAT")) == 0);
-            const int R = l.KH * l.KW;
-            const bool same = l.stride == 1 && l.KH == l.KW && (l.KH & 1) && l.pad == (l.KH - 1) / 2;
-            const int halo = l.pad * (l.Win + 1);
-            const int kind = R > 1 ? 2 : (HWo % 4 == 0 ? 0 : 1);
-            const int Lr = kind == 2 ? fFlatColsK : fFlatRow1;      // k x k: columns of the [column][36] image, zero row included
-            const size_t flat_lds = std::max((size_t)(2 * TM * fLdsA + (kind == 2 ? fFlatColsK * fFlatPix : 2 * fBK * Lr)) * sizeof(float),
-                                             (size_t)TM * 132 * sizeof(float));
-            if (flat_on && same && l.Cin % fBK == 0 && R <= 32 && (R == 1 || (l.flags & PLEAS_FWD_KPOS_MAJOR)) &&
-                fTN + 2 * halo < Lr && flat_lds <= lds_bytes && (int64_t)l.N * l.Cin * HWo < (1ll << 32)) {
-                d.variant |= 8 | (kind << 4);
-                lds_bytes = flat_lds;
-            }
-        }
+        size_t lds_bytes = 0;
+        int TM = 128;
+        if (const int rc = fwd_describe(l, d, lds_bytes, TM); rc != PLEAS_OK) return rc;
+        const int64_t Ptot = d.Ptot, Kd = d.Kd;
         d.part_base = parts;
         const int tms = (int)ceil_div(l.Cout, TM), tps = (int)ceil_div(Ptot, fTN);
         int slot = 0;
@@ -1282,6 +1306,36 @@ extern "C" size_t pleas_fwd_batch_ws_bytes(const pleas_fwd_layer* layers, int n_
     const size_t streamed = fwds::stream_ws_bytes(layers, n_layers);
     if (streamed == 0) return 0;
     return std::max(tmp.total, streamed);
+}
+
+extern "C" int pleas_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int Hin, int Win,
+                                int Cout, int KH, int KW, int stride, int pad, int flags, void* stream_) {
+    if (!x || !w || !y) return bad_arg("conv2d_fwd: null pointer");
+    if (((uintptr_t)w & 15) != 0 || ((uintptr_t)x & 15) != 0) return bad_arg("conv2d_fwd: x and w must be 16-byte aligned");
+    pleas_fwd_layer l{};
+    l.ip = x; l.w = w; l.bias = bias; l.resid = y;
+    l.N = N; l.Cout = Cout; l.Cin = Cin; l.Hin = Hin; l.Win = Win; l.KH = KH; l.KW = KW; l.stride = stride; l.pad = pad;
+    l.Csrc = 1; l.n_merged = 0; l.dscale = 1.f; l.loss_scale = 0.f; l.flags = flags;
+    FwdLayerDev d{};
+    size_t lds = 0;
+    int TM = 128;
+    if (const int rc = fwd_describe(l, d, lds, TM); rc != PLEAS_OK) return rc;
+    // no block maps: every source row is absent (fwd_load_maps), the masked gathers read the first floats of x
+    d.ip = x; d.w = w; d.bias = bias; d.o1 = x; d.o2 = x; d.row1 = nullptr; d.row2 = nullptr; d.resid = y;
+    d.part_base = 0;
+    const int tms = (int)ceil_div(Cout, TM), tps = (int)ceil_div((int64_t)d.Ptot, fTN);
+    const dim3 grid((unsigned)((int64_t)tms * tps));
+    hipStream_t st = (hipStream_t)stream_;
+    ProfScope prof(kProfConv2d, 2.0 * Cout * (double)d.Kd * (double)d.Ptot,
+                   ((double)Cin * N * Hin * Win + (double)Cout * d.Ptot) * sizeof(float), st);
+    switch (fwd_form_of(d.variant)) {
+#define PLEAS_CONV_LAUNCH(F) case F: hipLaunchKernelGGL(conv2d_fwd_kernel<F>, grid, dim3(fThreads), lds, st, d, tms); break
+        PLEAS_CONV_LAUNCH(0); PLEAS_CONV_LAUNCH(1); PLEAS_CONV_LAUNCH(2); PLEAS_CONV_LAUNCH(3); PLEAS_CONV_LAUNCH(4);
+        PLEAS_CONV_LAUNCH(5); PLEAS_CONV_LAUNCH(6); PLEAS_CONV_LAUNCH(7); PLEAS_CONV_LAUNCH(8); PLEAS_CONV_LAUNCH(9);
+#undef PLEAS_CONV_LAUNCH
+    }
+    PLEAS_LAUNCH_CHECK("conv2d_fwd_kernel");
+    return PLEAS_OK;
 }
 
 extern "C" int pleas_fwd_batch(const pleas_fwd_layer* layers, int n_layers, float* loss, void* ws, size_t ws_bytes,

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(64) void sqerr_final_kernel(const float* __restrict
 
 using namespace pleas;
 
-extern "C" const char* pleas_version(void) { return "pleas_hip 0.4.0 gfx950"; }
+extern "C" const char* pleas_version(void) { return "pleas_hip 0.5.0 gfx950"; }
 extern "C" const char* pleas_last_error(void) { return g_last_error; }
 
 extern "C" void pleas_prof_enable(int on) { g_prof_on = on != 0; }

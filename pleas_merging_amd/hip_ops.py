@@ -769,6 +769,29 @@ class FwdBatch:
                                          _stream()), "pleas_fwd_batch")
 
 
+def conv2d(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], stride: int, pad: int, kpos_major: bool = False,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``F.conv2d(x, w, bias, stride, pad)`` for dense, undilated, square geometries on the grouped forward's tile forms
+    (``pleas_conv2d_fwd``): fp32 MFMA, a fixed summation order -- the same bits run after run, which MIOpen's 3 x 3
+    kernels are not (they split K with atomics on small images / batches; tools/r05/probe_conv_classes.py).
+    ``kpos_major``: ``w`` is ``[Cout][KH][KW][Cin]`` (needs Cin % 32 == 0; the flat-shift forms of stride-1 layers)."""
+    _need_gpu(x, w)
+    if x.dim() != 4 or w.dim() != 4 or not x.is_contiguous() or not w.is_contiguous():
+        raise PleasHipError("conv2d: contiguous 4-D tensors expected")
+    N, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    KH, KW = (w.shape[1], w.shape[2]) if kpos_major else (w.shape[2], w.shape[3])
+    if (w.shape[3] if kpos_major else w.shape[1]) != Cin:
+        raise PleasHipError("conv2d: %d input channels vs a weight of %s" % (Cin, tuple(w.shape)))
+    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    if out is None:
+        out = torch.empty((N, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    check(_lib.lib().pleas_conv2d_fwd(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(),
+                                      N, Cin, H, W, Cout, KH, KW, stride, pad, FwdBatch.KPOS_MAJOR if kpos_major else 0,
+                                      _stream()), "pleas_conv2d_fwd")
+    return out
+
+
 class WgradBatch:
     """Weight gradients of all merged layers of one update in ONE grouped launch (``pleas_wgrad_batch``).
     ``add`` per layer (operands must stay unmodified until ``flush``), ``flush`` once per update."""

@@ -63,6 +63,22 @@ def _out_of_place(twin: torch.fx.Graph, node: torch.fx.Node, lookup: Callable, s
     return None
 
 
+def _own_conv(twin: torch.fx.Graph, node: torch.fx.Node, side: int, model: nn.Module, env) -> Optional[torch.fx.Node]:
+    """The twin-graph call of a k x k convolution on the library's own kernel (``source_forward.HipConv``: bit-for-bit
+    repeatable, which the vendor's 3 x 3 kernels are not), or None when ``node`` is not one / the mode says vendor."""
+    from .source_forward import HipConv, own_conv_ok
+
+    if node.op != "call_module" or len(node.args) != 1 or node.kwargs:
+        return None
+    try:
+        mod = model.get_submodule(node.target)
+    except AttributeError:
+        return None
+    if not own_conv_ok(mod):
+        return None
+    return _node(twin, "call_function", HipConv(mod, "%d_%s" % (side, node.name)), (env[node.args[0]],), "hip_conv")
+
+
 def _node(graph: torch.fx.Graph, op: str, target, args=(), name: str = "n") -> torch.fx.Node:
     """``graph.create_node`` with an explicit (already valid) base name: without one fx derives it from the target
     through a per-character Python loop (``_snake_case``), ~35 us per node and 0.1 s per job for our ~2000 nodes."""
@@ -154,9 +170,11 @@ def _build_twin(model1: nn.Module, model2: nn.Module, axes: Iterable[Axis], emit
                 env[side][node] = new
                 made.append(new)
                 continue
-            new = twin.node_copy(node, lambda n, side=side: env[side][n])
-            if node.op in ("call_module", "get_attr"):
-                new.target = "%d.%s" % (side, node.target)
+            new = _own_conv(twin, node, side, (model1, model2)[side], env[side])
+            if new is None:
+                new = twin.node_copy(node, lambda n, side=side: env[side][n])
+                if node.op in ("call_module", "get_attr"):
+                    new.target = "%d.%s" % (side, node.target)
             env[side][node] = new
             made.append(new)
         for a in want.get(node.name, ()):
@@ -286,6 +304,10 @@ def _build_split_twin(model1: nn.Module, model2: nn.Module, axes: Iterable[Axis]
             new = _out_of_place(twin, node, lambda n, side=side: env[side][n], submods)
             if new is not None:
                 env[side][node] = new
+                continue
+            own = _own_conv(twin, node, side, (model1, model2)[side], env[side])
+            if own is not None:
+                env[side][node] = own
                 continue
             new = twin.node_copy(node, lambda n, side=side: env[side][n])
             if node.op in ("call_module", "get_attr"):

@@ -11,6 +11,9 @@ be fused.  ``fuse_bn_act`` rewrites an fx trace of the model:
     bn(x) -> relu -> MaxPool2d         =>  bn_act_maxpool(x, scale, shift, kernel, stride, padding, relu=True)
                                            (the stem: the full-resolution ReLU output is never written)
 
+    Conv2d (k x k, dense, undilated)   =>  HipConv(conv)(x): ``hip_ops.conv2d`` -- the grouped forward's tile forms as a plain
+                                           convolution, bit-for-bit repeatable (``SOURCE_CONV``)
+
 ``scale = weight / sqrt(running_var + eps)`` and ``shift = bias - running_mean * scale`` are computed
 once in fp64.  The hooked modules are the SAME objects in the rewritten GraphModule, so hooks
 registered on the original model keep firing; conv outputs are never written in place.
@@ -19,6 +22,7 @@ Values differ from the vendor BN kernel by fp32 rounding only (one fma instead o
 from __future__ import annotations
 
 import operator
+import os
 from typing import Callable, Optional
 
 import torch
@@ -27,6 +31,65 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import hip_ops
+
+
+# Which convolutions of the frozen source / twin forwards run on the library's own kernel instead of the vendor's:
+#   "kxk"    (default) dense, undilated, square k x k layers with k > 1.  MIOpen's immediate-mode picks for them split K with
+#            atomics on small images / batches: the SAME forward differs from itself run to run from the first 3 x 3 layer on
+#            (ResNet-101: layer4's at 128 samples, layer2's at 16, layer1's at 4), which flipped near-tie assignments between two
+#            runs of one job (GPUTEST_r04).  Its deterministic solvers (torch.backends.cudnn.deterministic) are 6-15x slower
+#            per 3 x 3 layer; the own kernel is as fast as the non-deterministic pick (22.8 vs 23.3 ms per 128-sample
+#            ResNet-101 forward) and needs no layout transposes.  1 x 1 layers stay on the vendor's GEMM (repeatable, measured).
+#   "all"    1 x 1 layers too;  "vendor"  none (rounds 1-4).      profiles/r05_probe_conv_classes_128.txt
+SOURCE_CONV = os.environ.get("PLEAS_SOURCE_CONV", "kxk")
+
+
+def own_conv_ok(mod: nn.Module, mode: Optional[str] = None) -> bool:
+    """Does ``mod`` go through ``hip_ops.conv2d`` under ``mode`` (default: ``SOURCE_CONV``)?"""
+    mode = SOURCE_CONV if mode is None else mode
+    if mode == "vendor" or type(mod) is not nn.Conv2d:
+        return False
+    if not (mod.groups == 1 and mod.dilation == (1, 1) and mod.padding_mode == "zeros" and isinstance(mod.padding, tuple)
+            and mod.stride[0] == mod.stride[1] and mod.padding[0] == mod.padding[1] and mod.kernel_size[0] == mod.kernel_size[1]):
+        return False
+    k = mod.kernel_size[0]
+    return mod.weight.dtype == torch.float32 and k * k <= 64 and (k > 1 or mode == "all")
+
+
+class HipConv:
+    """Graph callable standing in for a frozen ``nn.Conv2d``: ``hip_ops.conv2d`` on CUDA fp32 inputs without autograd, the
+    module itself otherwise.  ``fire_hooks``: the module's forward hooks are called as its own ``__call__`` would (the
+    PLeaS taps sit on the ORIGINAL modules, pleas_merging.py:197-231).  k x k weights with Cin % 32 == 0 are kept
+    kernel-position-major (the flat-shift tile forms); the copy follows the parameter's version counter."""
+
+    def __init__(self, conv: nn.Conv2d, tag: str, fire_hooks: bool = True):
+        self.conv, self.fire_hooks = conv, fire_hooks
+        self.k, self.stride, self.pad = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        self.kpos = self.k > 1 and conv.weight.shape[1] % 32 == 0
+        self._w = self._stamp = None
+        self.__name__ = self.__qualname__ = "hip_conv_%s" % tag
+
+    def weight(self) -> torch.Tensor:
+        w = self.conv.weight
+        stamp = (w.data_ptr(), w._version)
+        if self._stamp != stamp:
+            with torch.no_grad():
+                self._w = (w.detach().permute(0, 2, 3, 1) if self.kpos else w.detach()).contiguous()
+            self._stamp = stamp
+        return self._w
+
+    def __call__(self, x):
+        conv = self.conv
+        if (not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4 or not conv.weight.is_cuda
+                or (torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad))):
+            return conv(x)                      # the module's own path, hooks included
+        y = hip_ops.conv2d(x if x.is_contiguous() else x.contiguous(), self.weight(), conv.bias, self.stride, self.pad, self.kpos)
+        if self.fire_hooks and conv._forward_hooks:
+            for hook in list(conv._forward_hooks.values()):
+                out = hook(conv, (x,), y)
+                if out is not None:
+                    y = out
+        return y
 
 
 def _bn_act(x, scale, shift, res, relu):
@@ -126,7 +189,7 @@ def _train_fold(bn: nn.BatchNorm2d, tag: str, state: Optional[BatchesPerForward]
 
 
 def fuse_bn_act(model: nn.Module, op: Callable = _bn_act, train_stats: bool = False,
-                pool_op: Optional[Callable] = None) -> Optional[torch.fx.GraphModule]:
+                pool_op: Optional[Callable] = None, conv: Optional[str] = None) -> Optional[torch.fx.GraphModule]:
     """fx copy of ``model`` (sharing its submodules) with every eval-mode BatchNorm2d chain replaced by
     ``op(x, scale, shift, residual_or_None, relu)`` -- the HIP kernel ``hip_ops.bn_act`` unless a test
     passes its own.  Returns None when the model cannot be traced or holds nothing to fold; the caller
@@ -138,7 +201,10 @@ def fuse_bn_act(model: nn.Module, op: Callable = _bn_act, train_stats: bool = Fa
     ReLU read or write it seven times.
 
     ``pool_op(x, scale, shift, kernel, stride, padding, relu)`` takes a BN -> ReLU chain whose only consumer is a max
-    pooling (``hip_ops.bn_act_maxpool`` with the default ``op``; with a caller's ``op`` only when passed too)."""
+    pooling (``hip_ops.bn_act_maxpool`` with the default ``op``; with a caller's ``op`` only when passed too).
+
+    ``conv`` ("kxk" / "all" / "vendor", default ``SOURCE_CONV``): which Conv2d calls become ``HipConv`` calls -- only with
+    the default ``op`` (a test's CPU ``op`` keeps the modules) and never for a model in train mode (autograd may be on)."""
     if pool_op is None and op is _bn_act:
         pool_op = _bn_act_pool
     try:
@@ -198,6 +264,14 @@ def fuse_bn_act(model: nn.Module, op: Callable = _bn_act, train_stats: bool = Fa
         for dead in reversed(chain):
             graph.erase_node(dead)
         folded += 1
+    if op is _bn_act and not model.training:
+        for node in list(graph.nodes):
+            if node.op == "call_module" and len(node.args) == 1 and not node.kwargs and own_conv_ok(mods.get(node.target), conv):
+                with graph.inserting_before(node):
+                    own = graph.create_node("call_function", HipConv(mods[node.target], node.name), (node.args[0],), {}, name=node.name + "_hip")
+                node.replace_all_uses_with(own)
+                graph.erase_node(node)
+                folded += 1
     if folded == 0:
         return None
     graph.lint()

@@ -5,9 +5,12 @@ far as ONE MI355X allows.
     on one GPU): batch-sharded matching + one all-reduce of the 41 MB cost arena, sample-sharded PLeaS updates with the
     default ``2 * world`` updates per source forward (one full group of 4 and the left-over update), look-ahead, one
     all-reduce of the gradient arena per update -- with and without ``shard_optimizer`` -- against the single-process HIP
-    job on the same inputs: identical assignments, weights to 2e-5 (or 3x what the single-process job differs from
-    ITSELF by when run twice: the vendor convolutions are not run-to-run deterministic at 101 layers), both ranks
-    bit-identical.
+    job on the same inputs.  MATCHING is compared on its own (costs; assignments identical or, in a near-tie group, equal
+    to the LAP of the rank's own costs and within 1e-6 of the optimum under the single-process costs -- always checked);
+    the FIT of every run starts from ONE fixed assignment (the single-process job's), so a near-tie flip cannot leak into
+    the weight comparison.  Weights: per tensor within max(floor, 3x the largest pairwise distance among FOUR runs of
+    the single-process job), or -- Adam's first updates are sign-like -- a bounded share of coordinates one visible
+    step apart and the rest inside the floor; bias vectors by absolute travel in units of lr.  Both ranks bit-identical.
 (b) The same job in a ONE-rank ``nccl`` process group with PLEAS_FORCE_COLLECTIVES=1: ``all_reduce`` of the cost and
     gradient arenas, ``reduce_scatter_tensor`` / ``all_gather_into_tensor`` of the sharded optimiser really go through
     RCCL (counted), leave the result bit-identical to the job without a process group, and are timed on the job's own
@@ -53,7 +56,9 @@ def _make_inputs(path):
     torch.save({"sd": sds, "match": match, "train": train}, path)
 
 
-def _job(path, data_parallel, shard=False, time_collectives=False, calls=None):
+def _job(path, data_parallel, shard=False, time_collectives=False, calls=None, fixed=None):
+    """Matching in the job's own partitioning (returned as it came out); merge + fit from ``fixed`` -- a file holding ONE
+    assignment and its costs -- when given, so that every run that is compared weight for weight merged the same blocks."""
     from pleas.core.compiler import get_permutation_spec
     from pleas.methods.activation_matching import activation_matching
     from pleas.methods.partial_matching import partial_merge
@@ -70,17 +75,23 @@ def _job(path, data_parallel, shard=False, time_collectives=False, calls=None):
     spec = get_permutation_spec(m1, ((1, 3, 224, 224),))
     match = [(x, None) for x in blob["match"]]
     perm, costs = activation_matching(spec, m1, m2, match, N_MATCH, output_costs=True)
+    own_perm, own_costs = perm, costs
+    if fixed is not None:
+        keys = {str(k): k for k in spec}
+        blob_f = torch.load(fixed)
+        perm = {keys[k]: v for k, v in blob_f["perm"].items()}
+        costs = {keys[k]: v.cuda() for k, v in blob_f["costs"].items()}
     m3 = partial_merge(spec, m1, m2, perm, costs, RATIO)
     merged_stem = m3.state_dict()["conv1.weight"].detach().cpu().clone()
     fit = PleasFitter(m1, m2, m3, spec, perm, costs, RATIO, N_UPDATES - 1, data_parallel=data_parallel, shard_optimizer=shard)
     assert list(fit.steps(blob["train"])) == list(range(N_UPDATES))       # default sources_per_forward: 2 * world
     loss = fit.loss_sum.clone()
     job_calls = dict(calls) if calls is not None else None      # the job's own collectives, before any are timed below
-    timings = _time_collectives(costs, fit) if time_collectives else None
+    timings = _time_collectives(own_costs, fit) if time_collectives else None
     info = {"world": fit.world, "shard": fit.shard_optimizer, "fast_updates": fit.fast_updates}
     sd = {k: v.cpu() for k, v in fit.finish().state_dict().items()}
     torch.cuda.synchronize()
-    return {"perm": {str(k): v.cpu() for k, v in perm.items()}, "costs": {str(k): v.cpu() for k, v in costs.items()},
+    return {"perm": {str(k): v.cpu() for k, v in own_perm.items()}, "costs": {str(k): v.cpu() for k, v in own_costs.items()},
             "sd": sd, "loss": loss.cpu(), "info": info, "timings": timings, "merged_stem": merged_stem,
             "calls": job_calls, "state_axes": {str(k): sorted({ax.key for ax in g.state}) for k, g in spec.items()},
             "layers": [p.name for p in fit.plans]}
@@ -120,7 +131,7 @@ def _time_collectives(costs, fit, reps=5):
     return out
 
 
-def _worker(rank, world, port, path, out_path, backend, shard, force):
+def _worker(rank, world, port, path, out_path, backend, shard, force, fixed, device):
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
@@ -129,9 +140,9 @@ def _worker(rank, world, port, path, out_path, backend, shard, force):
         os.environ["PLEAS_FORCE_COLLECTIVES"] = "1"
     import torch.distributed as dist
 
-    torch.cuda.set_device(0)
+    torch.cuda.set_device(device)
     if backend == "nccl":
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
     else:
         dist.init_process_group(backend, rank=rank, world_size=world)
     calls = collections.Counter()
@@ -141,17 +152,20 @@ def _worker(rank, world, port, path, out_path, backend, shard, force):
             return _fn(*a, **kw)
         setattr(dist, name, counted)
     try:
-        res = _job(path, data_parallel=True, shard=shard, time_collectives=force, calls=calls)
+        res = _job(path, data_parallel=True, shard=shard, time_collectives=force, calls=calls, fixed=fixed)
         torch.save(res, out_path % rank)
     finally:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def _spawn(world, port, path, tmp, backend, shard, force, timeout=600):
+def _spawn(world, port, path, tmp, backend, shard, force, fixed=None, timeout=600, devices=None):
+    """``devices``: the device of every rank (default: all on device 0 -- two ranks on ONE card need gloo)."""
     ctx = mp.get_context("spawn")
     out_path = os.path.join(tmp, "res_%s_%s_%%d.pt" % (backend, "shard" if shard else "plain"))
-    procs = [ctx.Process(target=_worker, args=(r, world, port, path, out_path, backend, shard, force)) for r in range(world)]
+    devices = devices or [0] * world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, path, out_path, backend, shard, force, fixed, devices[r]))
+             for r in range(world)]
     for p in procs:
         p.start()
     deadline = time.time() + timeout
@@ -165,6 +179,9 @@ def _spawn(world, port, path, tmp, backend, shard, force, timeout=600):
     return [torch.load(out_path % r) for r in range(world)]
 
 
+REPEATS = 4      # runs of the single-process job the yardstick is taken from (largest pairwise distance per tensor)
+
+
 @pytest.fixture(scope="module")
 def single(tmp_path_factory):
     tmp = str(tmp_path_factory.mktemp("dp"))
@@ -172,71 +189,108 @@ def single(tmp_path_factory):
     _make_inputs(path)
     want = _job(path, data_parallel=False)
     assert want["info"]["world"] == 1
-    # The yardstick: the SAME single-process job once more.  The vendor's convolution kernels need not be run-to-run
-    # deterministic (split-K GEMMs with atomics at these small batch sizes), and 101 layers amplify that; what two runs of
-    # one program differ by is what two partitionings of it can be held to.
-    again = _job(path, data_parallel=False)
-    spread = {"costs": {k: _rel(again["costs"][k], v) for k, v in want["costs"].items()},
-              "sd": {k: _rel(again["sd"][k], v) for k, v in want["sd"].items() if v.dtype.is_floating_point},
-              "perm_equal": all(torch.equal(again["perm"][k], v) for k, v in want["perm"].items())}
-    print("single-process job twice: worst cost rel-fro %.2e, worst weight rel-fro %.2e, assignments equal: %s"
-          % (max(spread["costs"].values()), max(v for k, v in spread["sd"].items() if k != "conv1.weight"), spread["perm_equal"]))
+    # ONE assignment for every fit that is compared weight for weight: the first run's
+    fixed = os.path.join(tmp, "fixed.pt")
+    torch.save({"perm": want["perm"], "costs": want["costs"]}, fixed)
+    # The yardstick: the SAME single-process job REPEATS times.  Whatever is not run-to-run deterministic in it (vendor
+    # convolutions that split K with atomics, amplified by 101 layers) bounds what two partitionings of the job can be
+    # held to; ONE repeat is one draw of that distance (GPUTEST_r04: fc.bias 2.43e-5 against 3 x a single 6.5e-6).
+    runs = [want] + [_job(path, data_parallel=False, fixed=fixed) for _ in range(REPEATS - 1)]
+    pairs = [(a, b) for i, a in enumerate(runs) for b in runs[i + 1:]]
+    floats = [k for k, v in want["sd"].items() if v.dtype.is_floating_point]
+    spread = {"costs": {k: max(_rel(a["costs"][k], b["costs"][k]) for a, b in pairs) for k in want["costs"]},
+              "sd": {k: max(_rel(a["sd"][k], b["sd"][k]) for a, b in pairs) for k in floats},
+              "max_abs": {k: max(float((a["sd"][k] - b["sd"][k]).abs().max()) for a, b in pairs) for k in floats},
+              "share": {k: max(_step_share(a["sd"][k], b["sd"][k])[0] for a, b in pairs) for k in floats},
+              "perm_equal": all(torch.equal(r["perm"][k], v) for r in runs[1:] for k, v in want["perm"].items())}
+    print("single-process job %d times: worst pairwise cost rel-fro %.2e, worst weight rel-fro %.2e, assignments equal: %s"
+          % (REPEATS, max(spread["costs"].values()), max(v for k, v in spread["sd"].items() if k != "conv1.weight"),
+             spread["perm_equal"]))
     want["spread"] = spread
-    return tmp, path, want
+    return tmp, path, want, fixed
 
 
-COST_TOL, WEIGHT_TOL = 1e-5, 2e-5      # floors; a tensor may differ by 3x what two runs of the single-process job differ by
+COST_TOL, WEIGHT_TOL = 1e-5, 2e-5      # floors; a tensor may differ by 3x the largest distance between two runs of the single-process job
+LR, SHARE, MAX_FLIPS = 5e-4, 3e-3, 2   # Adam's step; share of coordinates that may sit one visible step apart (test_hip_fullsize)
 
 
-def _compare(res, want, exact):
-    """``exact``: the run must reproduce ``want`` as well as ``want`` reproduces itself (bit for bit when the
-    single-process job is deterministic).  Otherwise rel-fro per tensor within max(floor, 3 x the job's own spread)."""
+def _step_share(a, b):
+    """(share of coordinates more than lr / 10 apart -- a first, sign-like Adam step that went the other way --, rel-fro of
+    all the OTHER coordinates): the two numbers test_hip_fullsize._merge_and_train gates on."""
+    d = (a.double() - b.double()).abs()
+    far = d > LR / 10
+    return float(far.double().mean()), float((d * ~far).norm() / b.double().norm().clamp_min(1e-30))
+
+
+def _compare_matching(res, want, exact):
+    """Costs and assignments of a run's OWN matching against the single-process job's.  Never skipped: when the yardstick
+    runs themselves flip a near-tie group, the rule below is exactly what still holds (GPUTEST_r04)."""
+    from oracle import pleas_oracle as orc
+
     spread = want["spread"]
-    deterministic = spread["perm_equal"] and max(spread["costs"].values()) == 0.0 and max(spread["sd"].values()) == 0.0
-    worst = {"cost": 0.0, "weight": 0.0}
-    # A group whose optimum is a near tie may be assigned differently by two partitionings of the job (the all-reduce sums
-    # the batches' costs in another order): accepted when the other assignment is within 1e-6 of the optimum under THIS job's
-    # costs (the rule of test_hip_fullsize._check_matching), for at most two groups; the tensors that carry such a group's
-    # axes are then merged differently and are left out of the weight comparison (layers are fitted independently).
-    flipped, skip = [], set()
+    deterministic = spread["perm_equal"] and max(spread["costs"].values()) == 0.0
+    flipped, worst = [], 0.0
     value = lambda cost, perm: float(cost.double()[torch.arange(len(perm)), perm].sum())
     for k, v in want["perm"].items():
-        if spread["perm_equal"] and not torch.equal(res["perm"][k], v):
-            best, mine = value(want["costs"][k], v), value(want["costs"][k], res["perm"][k])
-            gap = (best - mine) / abs(best)
-            assert not (exact and deterministic) and 0 <= gap < 1e-6, (k, gap)
-            flipped.append((k, int((res["perm"][k] != v).sum()), gap))
-            skip.update(want["state_axes"][k])
         r = _rel(res["costs"][k], want["costs"][k])
-        worst["cost"] = max(worst["cost"], r)
+        worst = max(worst, r)
         if exact and deterministic:
             assert torch.equal(res["costs"][k], want["costs"][k]), k
         else:
             assert r <= max(COST_TOL, 3 * spread["costs"][k]), (k, r, spread["costs"][k])
+        if not torch.equal(res["perm"][k], v):
+            # a near tie decided by the summation order: the integer path must be exact on the run's own costs, and the
+            # assignment within 1e-6 of the optimum under the single-process costs (rule of test_hip_fullsize._check_matching)
+            assert not (exact and deterministic), k
+            assert torch.equal(orc.solve_lsa(res["costs"][k]), res["perm"][k]), k
+            best, mine = value(want["costs"][k], v), value(want["costs"][k], res["perm"][k])
+            gap = (best - mine) / abs(best)
+            assert 0 <= gap < 1e-6, (k, gap)
+            flipped.append((k, int((res["perm"][k] != v).sum()), gap))
+    assert len(flipped) <= MAX_FLIPS, flipped
+    if flipped:
+        print("near-tie groups assigned differently (units, optimality gap):", flipped)
+    return worst
+
+
+def _compare(res, want, exact):
+    """``exact``: the run must reproduce ``want`` as well as ``want`` reproduces itself (bit for bit when the
+    single-process job is deterministic).  Otherwise per tensor: rel-fro within max(floor, 3 x the job's own spread), or
+    Adam's signature -- a bounded share of coordinates one visible step apart, every other coordinate inside the floor;
+    bias vectors: largest absolute distance within max(lr / 10, 3 x the job's own)."""
+    spread = want["spread"]
+    deterministic = (spread["perm_equal"] and max(spread["costs"].values()) == 0.0 and max(spread["sd"].values()) == 0.0)
+    worst = {"cost": _compare_matching(res, want, exact), "weight": 0.0}
     for k, v in want["sd"].items():
         if not v.dtype.is_floating_point:
             continue
         if exact and deterministic:
             assert torch.equal(res["sd"][k], v), k
-        elif k != "conv1.weight" and k not in skip:      # degenerate stem: gated by the caller
-            r = _rel(res["sd"][k], v)
-            worst["weight"] = max(worst["weight"], r)
-            assert r <= max(WEIGHT_TOL, 3 * spread["sd"][k]), (k, r, spread["sd"][k])
-    assert len(flipped) <= 2, flipped
-    if flipped:
-        print("near-tie groups assigned differently (units, optimality gap):", flipped)
+            continue
+        if k == "conv1.weight":      # degenerate stem: gated by the caller
+            continue
+        r = _rel(res["sd"][k], v)
+        worst["weight"] = max(worst["weight"], r)
+        if v.dim() == 1:             # bias vectors: travel in units of lr, not a relative norm with a floor
+            d = float((res["sd"][k] - v).abs().max())
+            assert d <= max(LR / 10, 3 * spread["max_abs"][k]), (k, d, spread["max_abs"][k])
+            continue
+        if r <= max(WEIGHT_TOL, 3 * spread["sd"][k]):
+            continue
+        share, rest = _step_share(res["sd"][k], v)
+        assert share <= max(SHARE, 3 * spread["share"][k]) and rest <= max(WEIGHT_TOL, 3 * spread["sd"][k]), \
+            (k, r, spread["sd"][k], share, rest)
     if exact and deterministic:
         assert torch.equal(res["loss"], want["loss"])
     else:
-        keep = torch.tensor([not any(a.rsplit(".", 1)[0] == n for a in skip) for n in want["layers"]])
-        assert torch.allclose(res["loss"][keep], want["loss"][keep], rtol=1e-4, atol=1e-7)
+        assert torch.allclose(res["loss"], want["loss"], rtol=1e-4, atol=1e-7)
     return worst
 
 
 @pytest.mark.parametrize("shard", [False, True])
 def test_rn101_two_rank_job_equals_single_process_job(single, shard):
-    tmp, path, want = single
-    results = _spawn(2, 29671 + int(shard), path, tmp, "gloo", shard, force=False)
+    tmp, path, want, fixed = single
+    results = _spawn(2, 29671 + int(shard), path, tmp, "gloo", shard, force=False, fixed=fixed)
     for rank, res in enumerate(results):
         assert res["info"]["world"] == 2 and res["info"]["shard"] == shard
         assert res["info"]["fast_updates"] >= 2           # the group's later updates relaunch patched tables
@@ -256,8 +310,8 @@ def test_rn101_two_rank_job_equals_single_process_job(single, shard):
 
 @pytest.mark.parametrize("shard", [False, True])
 def test_rn101_one_rank_rccl_group_with_forced_collectives(single, shard):
-    tmp, path, want = single
-    (res,) = _spawn(1, 29681 + int(shard), path, tmp, "nccl", shard, force=True)
+    tmp, path, want, fixed = single
+    (res,) = _spawn(1, 29681 + int(shard), path, tmp, "nccl", shard, force=True, fixed=fixed)
     assert res["info"]["world"] == 1 and res["info"]["shard"] == shard
     calls = res["calls"]
     if shard:      # cost arena + per update: losses (all-reduce), gradients (reduce-scatter), parameters (all-gather)
@@ -278,3 +332,24 @@ def test_rn101_one_rank_rccl_group_with_forced_collectives(single, shard):
     if os.path.isdir(out_dir) and not shard:
         with open(os.path.join(out_dir, "r03_rccl_one_rank.json"), "w") as f:
             json.dump({"calls_in_job": calls, **t}, f, indent=1)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two MI355X: real RCCL between two devices over xGMI")
+@pytest.mark.parametrize("shard", [False, True])
+def test_rn101_two_gpus_rccl_job_equals_single_process_job(single, shard):
+    """(c) The first box with two devices runs this without anyone writing new code: the SAME job, one rank per GPU, backend
+    ``nccl`` (= RCCL over xGMI): ``all_reduce`` of the cost arena and of the gradient arena, ``reduce_scatter_tensor`` /
+    ``all_gather_into_tensor`` of the sharded optimiser between two devices, held to the gates of the gloo rehearsal."""
+    tmp, path, want, fixed = single
+    results = _spawn(2, 29691 + int(shard), path, tmp, "nccl", shard, force=False, fixed=fixed, devices=[0, 1])
+    for rank, res in enumerate(results):
+        assert res["info"]["world"] == 2 and res["info"]["shard"] == shard
+        worst = _compare(res, want, exact=False)
+        print("two GPUs, rank %d shard %s: costs %.2e, weights (non-stem) %.2e; calls %s"
+              % (rank, shard, worst["cost"], worst["weight"], res["calls"]))
+        if shard:
+            assert res["calls"].get("reduce_scatter_tensor", 0) >= N_UPDATES and res["calls"].get("all_gather_into_tensor", 0) >= N_UPDATES
+        else:
+            assert res["calls"].get("all_reduce", 0) >= 1 + N_UPDATES
+    for k, v in results[0]["sd"].items():
+        assert torch.equal(v, results[1]["sd"][k]), k
