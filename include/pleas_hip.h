@@ -316,16 +316,6 @@ int pleas_fwd_batch(const pleas_fwd_layer* layers, int n_layers, float* loss, vo
  *   x and w 16-byte aligned; square kernels up to 64 taps; no workspace, no tables: the layer rides in the kernel arguments. */
 int pleas_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int Hin, int Win, int Cout,
                      int KH, int KW, int stride, int pad, int flags, void* stream);
-/* Host only (no GPU): the plan of the STREAMED form of pleas_fwd_batch (one persistent workgroup per CU walking a list of
- * work items, producer / consumer waves; csrc/conv_fwd_stream.hip) for `layers` on `n_workgroups` workgroups (<= 0: the
- * device's CU count, 256 without a device).  info[8]: work items, workgroups, items of the VEC / FLAT / GEN input forms,
- * bubble ticks (steps in which the MFMA waves wait: record pipeline, first image of a FLAT item, epilogue of a short
- * predecessor), ticks of the shortest and of the longest workgroup list. */
-int pleas_fwd_stream_plan_info(const pleas_fwd_layer* layers, int n_layers, int n_workgroups, int* info);
-/* STUDY switch: route pleas_fwd_batch through the streamed form (default 0; PLEAS_FWD_STREAM=1 in the environment sets the
- * initial value).  Same results to rounding of the summation order; measured slower than the default forms. */
-void pleas_fwd_stream(int on);
-
 typedef struct pleas_wgrad_layer {
     const float* resid; /* [N][Cout][Hout*Wout] */
     const float* ip;    /* [N][Cin][Hin][Win]   */

@@ -69,8 +69,6 @@ SIGNATURES = {
     "pleas_fwd_batch_ws_bytes": (c_size_t, [c_void_p, c_int]),
     "pleas_fwd_plan_lanes": (c_int, [c_void_p, c_void_p, c_void_p]),
     "pleas_fwd_plan_units": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int]),
-    "pleas_fwd_stream_plan_info": (c_int, [c_void_p, c_int, c_int, c_void_p]),
-    "pleas_fwd_stream": (None, [c_int]),
     "pleas_allreduce_sum": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "pleas_fwd_batch": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "pleas_conv2d_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),

@@ -1228,23 +1228,6 @@ extern "C" int pleas_fwd_timeline_read(long long* out, int max_items) {      // 
 }
 #endif
 
-// the streamed form (conv_fwd_stream.hip): one persistent grid with producer / consumer waves
-namespace fwds {
-size_t stream_ws_bytes(const pleas_fwd_layer* layers, int n_layers);
-int stream_plan_info(const pleas_fwd_layer* layers, int n_layers, int n_wg, int* info);
-int stream_launch(const pleas_fwd_layer* layers, int n_layers, float* loss, void* ws, size_t ws_bytes, int ws_fresh,
-                  hipStream_t stream);
-}  // namespace fwds
-// STUDY switch (round 4): the streamed form is correct on every test of the grouped forward but
-// SLOWER than the one-item-per-workgroup forms (5.0 vs 2.8 ms per ResNet-101 update): while a wave issues fp32 MFMAs back
-// to back the other waves of its SIMD issue nothing at all, so producer and MFMA waves take turns instead of overlapping
-// (tools/hipbench/mfma_side_rates.hip).  Off unless PLEAS_FWD_STREAM=1 or pleas_fwd_stream(1).
-static int g_fwd_stream = -1;
-static bool fwd_streamed() {
-    if (g_fwd_stream < 0) g_fwd_stream = (std::getenv("PLEAS_FWD_STREAM") && std::atoi(std::getenv("PLEAS_FWD_STREAM")) != 0) ? 1 : 0;
-    return g_fwd_stream == 1;
-}
-
 }  // namespace pleas
 
 using namespace pleas;
@@ -1292,20 +1275,11 @@ extern "C" int pleas_fwd_plan_units(const pleas_fwd_layer* layers, int n_layers,
     return (int)tmp.units.size();
 }
 
-extern "C" void pleas_fwd_stream(int on) { g_fwd_stream = on ? 1 : 0; }
-
-extern "C" int pleas_fwd_stream_plan_info(const pleas_fwd_layer* layers, int n_layers, int n_workgroups, int* info) {
-    if (!layers || n_layers <= 0 || !info) return bad_arg("fwd_stream_plan_info: empty layer list / null output");
-    return fwds::stream_plan_info(layers, n_layers, n_workgroups, info);
-}
-
 extern "C" size_t pleas_fwd_batch_ws_bytes(const pleas_fwd_layer* layers, int n_layers) {
     if (!layers || n_layers <= 0) return 0;
     FwdPlan tmp;
     if (build_fwd_plan(tmp, layers, n_layers) != PLEAS_OK) return 0;
-    const size_t streamed = fwds::stream_ws_bytes(layers, n_layers);
-    if (streamed == 0) return 0;
-    return std::max(tmp.total, streamed);
+    return tmp.total;
 }
 
 extern "C" int pleas_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int Hin, int Win,
@@ -1348,7 +1322,6 @@ extern "C" int pleas_fwd_batch(const pleas_fwd_layer* layers, int n_layers, floa
         if (((uintptr_t)l.ip & 15) != 0) return bad_arg("conv_fwd: the merged input must be 16-byte aligned");
     }
     hipStream_t stream = (hipStream_t)stream_;
-    if (fwd_streamed()) return fwds::stream_launch(layers, n_layers, loss, ws, ws_bytes, ws_fresh, stream);
     std::lock_guard<std::mutex> lk(g_fplan_mu);
     std::vector<int64_t> key;
     key.push_back(n_layers);

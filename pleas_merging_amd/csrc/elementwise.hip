@@ -481,17 +481,33 @@ extern "C" int pleas_sqerr(const float* a, const float* b, int64_t n, float scal
 
 // ------------------------------------------------------------------------------------------
 // Bias gradient of a merged layer: gb[c] = sum over samples and pixels of resid[n][c][p] (pleas_merging.py:287, the bias
-// node of autograd's backward).  One workgroup per channel, fixed summation order (thread t takes elements t, t + 256, ...
-// of the channel's (n, p) range, then a tree over the threads): deterministic, no atomics.
+// node of autograd's backward).  One workgroup per channel; fixed summation order -- thread t takes pixels t, t + 256, ... of
+// every sample in turn (nested loops, no division; consecutive lanes read consecutive addresses; 16-byte loads when HW % 4 == 0),
+// then a tree over the threads: deterministic, no atomics.
 __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, int N, int C, long long HW,
                                                           float* __restrict__ out) {
     __shared__ float red[256];
     const int c = blockIdx.x, tid = threadIdx.x;
-    const long long total = (long long)N * HW;
     float s = 0.f;
-    for (long long i = tid; i < total; i += 256) {
-        const long long n = i / HW, p = i - n * HW;
-        s += x[((size_t)n * C + c) * HW + p];
+    if ((HW & 3) == 0 && (((uintptr_t)x) & 15) == 0) {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const long long q = HW >> 2;
+        for (int n = 0; n < N; ++n) {
+            const f32x4* row = reinterpret_cast<const f32x4*>(x + ((size_t)n * C + c) * HW);
+            float a = 0.f;
+            for (long long i = tid; i < q; i += 256) {
+                const f32x4 v = row[i];
+                a += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+            s += a;
+        }
+    } else {
+        for (int n = 0; n < N; ++n) {
+            const float* row = x + ((size_t)n * C + c) * HW;
+            float a = 0.f;
+            for (long long p = tid; p < HW; p += 256) a += row[p];
+            s += a;
+        }
     }
     red[tid] = s;
     __syncthreads();

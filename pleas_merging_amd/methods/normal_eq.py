@@ -24,15 +24,19 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .pleas_merging import PleasFitter, _LayerPlan
+from .pleas_merging import PleasFitter, _LayerPlan, dp_sum_
 
 
 class NormalEqFitter(PleasFitter):
     """Accumulates A and B^T for every merged layer; ``solve`` writes the closed-form weights."""
 
-    def __init__(self, *args, ridge: float = 1e-6, **kwargs):
+    def __init__(self, *args, ridge: float = 1e-6, shard_solve: bool = True, **kwargs):
         super().__init__(*args, **kwargs)
         self.ridge = ridge
+        # data parallel: rank r factorises only ITS layers (dealt by K^3, largest first) and the solved parameter arena is
+        # summed once over the ranks (the others' layers are zero there): the solve shrinks with the ranks instead of being
+        # repeated on every one (DESIGN.md section 5: 0.2 s of an 8-rank job's 1.6 s)
+        self.shard_solve = bool(shard_solve)
         dev = self.device
         self.K: List[int] = []
         for plan in self.plans:
@@ -129,8 +133,6 @@ class NormalEqFitter(PleasFitter):
     @torch.no_grad()
     def solve(self) -> Dict[str, float]:
         """Closed-form weights for every layer -> the parameter arena.  Returns per-layer info."""
-        from .pleas_merging import dp_sum_
-
         dp_sum_(self.A_flat, self.world)
         dp_sum_(self.B_flat, self.world)
         for s in self.bias_stats.values():
@@ -153,7 +155,11 @@ class NormalEqFitter(PleasFitter):
         self.neq.finalize([(self.A[i], g) for i, g in sorted(geos.items())])
         info: Dict[str, float] = {}
         jobs, finals = [], []   # (W, rows, free, A_FF, rhs, A_FF backup) per solve; (plan, W, layout) per layer
+        owner = solve_owners(self.K, [p.w_shape[0] for p in self.plans], self.world if self.shard_solve else 1)
         for idx, plan in enumerate(self.plans):
+            if owner[idx] != self.rank % max(1, self.world):
+                info[plan.name] = float(self.K[idx])
+                continue
             K, co = self.K[idx], plan.w_shape[0]
             A = self.A[idx]
             A = torch.tril(A) + torch.tril(A, -1).t()          # kernels fill the lower triangle only
@@ -208,7 +214,40 @@ class NormalEqFitter(PleasFitter):
                 plan.b.copy_(W[:, -1])
                 W = W[:, :-1]
             plan.w.copy_(from_kpos(W.contiguous()))
+        if self.shard_solve and self.world > 1:
+            exchange_solved_(self.p, [[t for t in (plan.w, plan.b) if t is not None] for plan in self.plans], owner, self.rank,
+                             self.world)
+            info["solve_shards"] = float(self.world)
         return info
+
+
+def exchange_solved_(arena: torch.Tensor, layer_views: List[List[torch.Tensor]], owner: List[int], rank: int, world: int) -> None:
+    """After a layer-sharded solve: every layer's parameters (views of ``arena``) were written by exactly one rank.  The
+    others' layers are zeroed here and the arena is summed ONCE over the ranks -- x + 0 is exact, so every rank ends with
+    the owner's bits.  Without peers (PLEAS_EMULATE_WORLD: a projection, not a result) nothing is zeroed."""
+    import torch.distributed as dist
+
+    if world <= 1 or not dist.is_initialized():
+        return
+    for views, r in zip(layer_views, owner):
+        if r != rank:
+            for t in views:
+                t.zero_()
+    dp_sum_(arena, world)
+
+
+def solve_owners(K: List[int], cout: List[int], world: int) -> List[int]:
+    """Which rank factorises which layer: longest-processing-time dealing on the solve's flops (K^3 / 3 + 2 Cout K^2), ties by
+    index -- a pure function of the layer list, so every rank computes the same table."""
+    if world <= 1:
+        return [0] * len(K)
+    cost = [k ** 3 / 3.0 + 2.0 * co * k * k for k, co in zip(K, cout)]
+    load, owner = [0.0] * world, [0] * len(K)
+    for idx in sorted(range(len(K)), key=lambda i: (-cost[i], i)):
+        r = min(range(world), key=lambda j: (load[j], j))
+        owner[idx] = r
+        load[r] += cost[idx]
+    return owner
 
 
 def _row_patterns(free: torch.Tensor):

@@ -466,8 +466,9 @@ class FrozenSources:
                     per_group += sum(t.numel() * t.element_size() for t in base.values())
         return taken
 
+    @torch.no_grad()
     def run_eager(self, x: torch.Tensor, after_current: bool = True) -> None:
-        """Both source forwards, dispatched op by op; the hooks fill ``tap1`` / ``tap2`` (callers that read them right
+        """Both source forwards (frozen: never under autograd), dispatched op by op; the hooks fill ``tap1`` / ``tap2`` (callers that read them right
         away must synchronise: the models run on side streams).  ``after_current=False``: the side streams are not
         ordered after the current stream's queue (``prefetch``); model2's stream then follows model1's up to here, which
         is where the batch was put together."""

@@ -96,6 +96,46 @@ def _bn_reset_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _sharded_solve_worker(rank, world, port, q):
+    """The exchange of the layer-sharded closed-form solve (methods/normal_eq.py: solve_owners + exchange_solved_): every rank
+    solves ITS layers only (here with a CPU solver on identical A, B), zeroes the others' and sums the parameter arena once;
+    all ranks must end with the single-process solution bit for bit."""
+    _init(rank, world, port)
+    from pleas_merging_amd.methods.normal_eq import exchange_solved_, solve_owners
+
+    g = torch.Generator().manual_seed(3)
+    K, cout = [7, 40, 12, 40, 3, 25, 18], [5, 9, 4, 16, 8, 2, 6]
+    owner = solve_owners(K, cout, world)
+    systems = []
+    for k, co in zip(K, cout):
+        U = torch.randn(4 * k, k, generator=g)
+        systems.append((U.t() @ U, torch.randn(co, k, generator=g)))
+    sizes = [co * k + co for k, co in zip(K, cout)]            # weight + bias per layer
+    full, mine = torch.zeros(sum(sizes)), torch.zeros(sum(sizes))
+    views = []
+    off = 0
+    for (A, Bt), k, co in zip(systems, K, cout):
+        views.append((off, co * k, co))
+        off += co * k + co
+    solve = lambda A, Bt: torch.linalg.solve(A, Bt.t()).t().contiguous()
+    layer_views = []
+    for i, ((A, Bt), (o, nw, nb)) in enumerate(zip(systems, views)):
+        W = solve(A, Bt)
+        full[o:o + nw] = W.flatten()
+        full[o + nw:o + nw + nb] = float(i + 1)
+        w_view, b_view = mine[o:o + nw], mine[o + nw:o + nw + nb]
+        w_view.fill_(-7.0)                                      # stale values a non-owner holds before the exchange
+        b_view.fill_(-7.0)
+        if owner[i] == rank:
+            w_view.copy_(W.flatten())
+            b_view.fill_(float(i + 1))
+        layer_views.append([w_view, b_view])
+    exchange_solved_(mine, layer_views, owner, rank, world)
+    ok = torch.equal(mine, full) and sorted(set(owner)) == list(range(world))
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
 def _run(worker, port):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -118,6 +158,25 @@ def test_sharded_pleas_gradient_gloo():
 
 def test_sharded_bn_reset_equals_sequential_gloo():
     _run(_bn_reset_worker, 29613)
+
+
+def test_layer_sharded_solve_exchange_gloo():
+    _run(_sharded_solve_worker, 29614)
+
+
+def test_solve_owners_balance_and_determinism():
+    from pleas_merging_amd.methods.normal_eq import solve_owners
+
+    K = [147] + [64, 576, 64] * 3 + [256, 1152, 128] * 4 + [512, 2304, 256] * 23 + [1024, 4608, 512] * 3 + [2048]
+    cout = [64] + [64, 64, 256] * 3 + [128, 128, 512] * 4 + [256, 256, 1024] * 23 + [512, 512, 2048] * 3 + [1000]
+    assert solve_owners(K, cout, 1) == [0] * len(K)
+    for world in (2, 4, 8):
+        owner = solve_owners(K, cout, world)
+        assert owner == solve_owners(list(K), list(cout), world) and set(owner) == set(range(world))
+        load = [0.0] * world
+        for k, co, r in zip(K, cout, owner):
+            load[r] += k ** 3 / 3.0 + 2.0 * co * k * k
+        assert max(load) <= 1.25 * (sum(load) / world), (world, load)      # ResNet-101's layers at 8 ranks: within a quarter of even
 
 
 def test_dp_slice_rejects_ragged_batches():

@@ -201,3 +201,26 @@ def test_bench_self_launches_two_ranks():
     assert line["checks"]["perms_are_permutations"] and line["checks"]["weights_finite"]
     assert set(line["phases_s"]) >= {"spec", "matching", "lap", "merge_and_setup", "updates"}
     assert line["roofline"]["launches"] > 0 and "cpu_baseline" not in line
+
+
+def test_bench_two_ranks_closed_form_line():
+    """`python bench.py --gpus 2 --solver normal_eq`: the job whose exchange does not grow with the updates (whole batches per
+    rank, ONE all-reduce of the A / B arenas, layer-sharded Cholesky, ONE sum of the solved parameter arena) as a supported
+    bench line -- tagged ALT-SOLVER, weights finite, no fp64 fall-backs on this pair."""
+    import json
+    import subprocess
+
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "gloo", "--all-ranks-on-gpu0",
+           "--solver", "normal_eq", "--steps", "1", "--warmup", "1", "--arch", "resnet18", "--batch", "4", "--match-batches", "3",
+           "--updates", "9", "--prefetch-groups", "1", "--prefetch-memory", "0.05", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["metric"].startswith("ALT-SOLVER") and line["config"]["solver"] == "normal_eq"
+    assert line["checks"]["ok"] and line["checks"]["weights_finite"] and line["checks"]["fp64_fallbacks"] == 0
+    assert line["value"] > 0 and "cpu_baseline" not in line and "library_baseline" not in line

@@ -917,7 +917,7 @@ def test_fwd_batch_flat_forms_random_geometries(ops):
 
 def test_channel_sum_is_the_bias_gradient(ops):
     g = torch.Generator().manual_seed(3)
-    for shape in [(16, 1000), (4, 70, 14, 14), (3, 9, 5, 7), (1, 1, 1, 1), (300, 5)]:
+    for shape in [(16, 1000), (4, 70, 14, 14), (3, 9, 5, 7), (1, 1, 1, 1), (300, 5), (2, 64, 112, 112), (3, 17, 33, 4)]:
         x = torch.randn(shape, generator=g)
         out = torch.full((shape[1],), float("nan"), device="cuda")
         ops.channel_sum(x.cuda(), out)
@@ -926,23 +926,6 @@ def test_channel_sum_is_the_bias_gradient(ops):
         again = torch.empty_like(out)
         ops.channel_sum(x.cuda(), again)
         assert torch.equal(out, again)      # deterministic
-
-
-def test_fwd_batch_streamed_form(ops):
-    """The STUDY form of pleas_fwd_batch (one persistent workgroup per CU, producer / consumer waves, csrc/conv_fwd_stream.hip;
-    off by default) on the same cases as the default forms: every geometry class of FWD_CASES and the random
-    multi-layer launch, whose workgroups walk several items (record ring, epilogue of an item under the next item's MFMAs)."""
-    from pleas_merging_amd import _lib
-
-    lib = _lib.lib()
-    lib.pleas_fwd_stream(1)
-    try:
-        for case in FWD_CASES:
-            test_fwd_batch_matches_conv_and_target.__wrapped__(ops, *case) if hasattr(
-                test_fwd_batch_matches_conv_and_target, "__wrapped__") else test_fwd_batch_matches_conv_and_target(ops, *case)
-        test_fwd_batch_flat_forms_random_geometries(ops)
-    finally:
-        lib.pleas_fwd_stream(0)
 
 
 # ------------------------------------------------------------------------------------------ exchange step through the C-ABI

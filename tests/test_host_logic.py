@@ -277,30 +277,6 @@ def test_forward_launch_units_partition_every_form():
     assert len([u for u in split if u[0] == 7]) >= 2 and len([u for u in split if u[0] == 4]) >= 2   # the two 2.56 ms forms
 
 
-def test_streamed_forward_plan_on_the_host():
-    """Host side of the STREAMED form of pleas_fwd_batch (study switch, csrc/conv_fwd_stream.hip; no GPU): the ResNet-101
-    update's items are dealt to one list per CU, every item takes one of the three input forms, and the lists end within
-    a few ticks of each other."""
-    from pleas_merging_amd import _lib
-
-    sys.path.insert(0, os.path.join(REPO, "tests"))
-    from sanitize_driver_layers import resnet_layers
-
-    lib = _lib.lib()
-    layers = resnet_layers("resnet101")
-    arr = (_lib.FwdLayer * len(layers))()
-    for f, (co, ci, h, w, k, s_, p_) in zip(arr, layers):
-        f.N, f.Cout, f.Cin, f.Hin, f.Win, f.KH, f.KW, f.stride, f.pad = 16, co, ci, h, w, k, k, s_, p_
-        f.Csrc, f.n_merged, f.flags = co, co, (1 if (k > 1 and ci % 32 == 0) else 0)
-    info = (ctypes.c_int * 8)()
-    assert lib.pleas_fwd_stream_plan_info(arr, len(layers), 256, info) == 0
-    items, wgs, vec, flat, gen, bubbles, tmin, tmax = list(info)
-    assert wgs == 256 and items > 20000 and vec + flat + gen == items and flat > 1000 and vec > 10000
-    assert tmax - tmin <= 0.05 * tmax, (tmin, tmax)            # longest-processing-time dealing: balanced lists
-    assert bubbles < 0.2 * 256 * tmax
-    assert lib.pleas_fwd_stream_plan_info(arr, 0, 256, info) != 0 and lib.pleas_fwd_stream_plan_info(None, 3, 256, info) != 0
-
-
 def test_host_code_under_sanitizers():
     """SURVEY.md section 5 (sanitizers): the host halves of csrc/*.hip -- plan builders, XCD item ordering, lane dealing,
     lag classes, the host LAP, argument checks -- compiled with -fsanitize=address,undefined (device code as always) and
