@@ -400,10 +400,19 @@ int pleas_prof_collect(int kernel, int64_t* launches, double* total_ms, double* 
 /* Tuning hook for experiments: split-K target workgroup count and minimum K chunks per split. */
 void pleas_gram_tune(int target_blocks, int min_chunks_per_split);
 void pleas_gram_batch_tune(int item_chunks, int xcd_order);
-/* STUDY switch, off by default (also PLEAS_GRAM_SPLIT_BF16=1 in the environment, read once): the contraction kernels'
- * 16-byte variants compute every fp32 product as six bf16-MFMA products of a three-way bf16 split of both operands
- * (fp32 accumulate) instead of on the fp32 MFMA.  The headline path and every parity test run with it OFF; results and
- * timings with it ON are reported as a study only (tools/probe_gram_split.py). */
+/* Arithmetic of the contraction kernels (matching contraction, grouped forward, weight gradient, plain convolution).
+ *   PLEAS_ARITH_FP32       (default) exact fp32 MFMA, v_mfma_f32_32x32x2_f32: bitwise an fmaf chain;
+ *   PLEAS_ARITH_SPLIT_BF16 every fp32 operand as the exact sum of three bf16 values, six v_mfma_f32_32x32x16_bf16 products per
+ *                          k step with fp32 accumulation (the three dropped terms are below half an fp32 ulp of the product):
+ *                          fp32 accuracy at 2.67x less matrix-pipe time.  Tile forms without a split variant (scalar-load
+ *                          forms: 7 x 7 images, strided layers, the stem) keep the exact arithmetic inside the same launch.
+ * Process-wide; plans are keyed by it.  PLEAS_ARITH=split_bf16 in the environment sets the initial value.  The headline
+ * numbers and every default-path test run with PLEAS_ARITH_FP32; bench.py reports the other as `alt_arith`. */
+#define PLEAS_ARITH_FP32 0
+#define PLEAS_ARITH_SPLIT_BF16 1
+void pleas_arith(int mode);
+int pleas_arith_get(void);
+/* round-3 name of pleas_arith(on ? PLEAS_ARITH_SPLIT_BF16 : PLEAS_ARITH_FP32) */
 void pleas_gram_split_bf16(int on);
 void pleas_wgrad_tune(int item_chunks);
 

@@ -54,6 +54,8 @@ SIGNATURES = {
                                    POINTER(ctypes.c_double)]),
     "pleas_gram_tune": (None, [c_int, c_int]),
     "pleas_gram_split_bf16": (None, [c_int]),
+    "pleas_arith": (None, [c_int]),
+    "pleas_arith_get": (c_int, []),
     "pleas_gram_batch_tune": (None, [c_int, c_int]),
     "pleas_wgrad_tune": (None, [c_int]),
     "pleas_target_residual": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

@@ -49,6 +49,53 @@ typedef __attribute__((address_space(1))) const int gcint;
 #define PLEAS_GLOBAL_W(p) ((::pleas::gfloat*)(p))
 #define PLEAS_GLOBAL_I(p) ((::pleas::gcint*)(p))
 
+// ---- alternative arithmetic of the contraction kernels (pleas_arith): an fp32 value as the EXACT sum of three bf16 values,
+// v = h1 + h2 + h3 (8 + 8 + 8 significant bits, each the round-to-nearest bf16 of what the previous ones left; bf16 has
+// fp32's exponent range), so that an fp32 product becomes six bf16-MFMA products with fp32 accumulation:
+//   x * y = x1 y1 + (x1 y2 + x2 y1) + (x2 y2 + x1 y3 + x3 y1)  + terms <= 2^-26 |x y| (dropped: below half an fp32 ulp)
+// Six v_mfma_f32_32x32x16_bf16 (32 cycles each, K = 16) replace eight v_mfma_f32_32x32x2_f32 (64 cycles each, K = 2): 2.67x
+// less matrix-pipe time at fp32 accuracy.  The split is done once per element when a K chunk goes from registers to LDS.
+// Not for inf / NaN operands (inf - inf in the residual).
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+constexpr int kSplitRow = 104;   // bf16 per LDS row of a split image: 3 planes x 32 k + 8 pad = 208 B (13 16-byte slots: odd,
+                                 // so the 16 rows of a ds_read_b128 lane group fall on 16 different slots)
+__device__ __forceinline__ uint32_t split_bf16_pair(float a, float b) {
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));      // a in the low half
+}
+// two values at a time: one v_cvt_pk_bf16_f32 per pair and plane, the bf16 values back as floats by a shift / a mask
+__device__ __forceinline__ void split3_pair(float a, float b, uint32_t (&p)[3]) {
+    p[0] = split_bf16_pair(a, b);
+    const float ra = a - __builtin_bit_cast(float, p[0] << 16), rb = b - __builtin_bit_cast(float, p[0] & 0xffff0000u);
+    p[1] = split_bf16_pair(ra, rb);
+    p[2] = split_bf16_pair(ra - __builtin_bit_cast(float, p[1] << 16), rb - __builtin_bit_cast(float, p[1] & 0xffff0000u));
+}
+// four consecutive k of one row -> the row's three planes of an LDS split image (`row` points at the row's plane 0, `col` = k)
+__device__ __forceinline__ void split3_store4(__bf16* row, int col, float v0, float v1, float v2, float v3) {
+    uint32_t lo[3], hi[3];
+    split3_pair(v0, v1, lo);
+    split3_pair(v2, v3, hi);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2_t*>(row + p * 32 + col) = u32x2_t{lo[p], hi[p]};
+}
+// the six products of one 16-deep k step, smallest terms first
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ f32x16_t split3_mfma(const bf16x8_t (&a)[3], const bf16x8_t (&b)[3], f32x16_t c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+    return c;
+}
+// process-wide arithmetic switch (pleas_arith): 0 = exact fp32 MFMA (default), 1 = split bf16 where a kernel has the form
+int arith_mode();
+
+
 // ---- opt-in per-kernel timing with HIP events on the launch stream (pleas_prof_* in the C-ABI)
 enum ProfKernel { kProfGramPartial = 0, kProfGramFinalize, kProfLsap, kProfMergeBlocks, kProfMaskedAdam, kProfSqerr,
                   kProfConvFwd, kProfConvWgrad, kProfNormalEq, kProfSolve, kProfBnAct, kProfConv2d, kProfCount };

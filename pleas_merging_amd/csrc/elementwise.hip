@@ -268,6 +268,21 @@ using namespace pleas;
 extern "C" const char* pleas_version(void) { return "pleas_hip 0.5.0 gfx950"; }
 extern "C" const char* pleas_last_error(void) { return g_last_error; }
 
+// ---- arithmetic of the contraction kernels: -1 = not decided yet (PLEAS_ARITH read once), 0 = exact fp32 MFMA, 1 = split bf16
+static int g_arith = -1;
+namespace pleas {
+int arith_mode() {
+    if (g_arith < 0) {
+        const char* e = std::getenv("PLEAS_ARITH");
+        const char* legacy = std::getenv("PLEAS_GRAM_SPLIT_BF16");
+        g_arith = ((e && (std::strcmp(e, "split_bf16") == 0 || std::strcmp(e, "1") == 0)) || (legacy && legacy[0] == '1')) ? 1 : 0;
+    }
+    return g_arith;
+}
+}  // namespace pleas
+extern "C" void pleas_arith(int mode) { g_arith = mode == PLEAS_ARITH_SPLIT_BF16 ? 1 : 0; }
+extern "C" int pleas_arith_get(void) { return pleas::arith_mode(); }
+
 extern "C" void pleas_prof_enable(int on) { g_prof_on = on != 0; }
 
 extern "C" void pleas_prof_select(unsigned kernel_mask) { g_prof_mask = kernel_mask; }

@@ -64,29 +64,13 @@ struct Stage {
 // bound by the conversions' issue slots (measured: 0.88 of the fp32 peak).  LDS is single-buffered here (two barriers per
 // chunk, the next chunk waits in registers); two workgroups per CU alternate between converting and multiplying.
 // Not for inf / NaN operands (inf - inf in the residual).
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-constexpr int kSplitLd = 104;   // bf16 per LDS row of the split image: 3 planes x 32 k + 8 pad = 208 B (13 16-byte slots:
-                                // odd, so the 16 rows of a ds_read_b128 lane group fall on 16 different slots)
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-// Two values at a time: one v_cvt_pk_bf16_f32 per pair and plane, the bf16 values back as floats by a shift / a mask
-// (11 vector instructions per pair; element by element the compiler spent 15).
-__device__ __forceinline__ uint32_t bf16_pair(float a, float b) {
-    const f32x2 v = {a, b};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));      // a in the low half
-}
-__device__ __forceinline__ void split3_pair(float a, float b, uint32_t (&p)[3]) {
-    p[0] = bf16_pair(a, b);
-    const float ra = a - __builtin_bit_cast(float, p[0] << 16), rb = b - __builtin_bit_cast(float, p[0] & 0xffff0000u);
-    p[1] = bf16_pair(ra, rb);
-    p[2] = bf16_pair(ra - __builtin_bit_cast(float, p[1] << 16), rb - __builtin_bit_cast(float, p[1] & 0xffff0000u));
-}
-__device__ __forceinline__ void split3(const float (&v)[4], uint2 (&h)[3]) {      // h[plane] = four bf16, k order kept
+constexpr int kSplitLd = kSplitRow;      // common.hpp: three bf16 planes per LDS row
+__device__ __forceinline__ void split3(const float (&v)[4], u32x2_t (&h)[3]) {      // h[plane] = four bf16, k order kept
     uint32_t lo[3], hi[3];
     split3_pair(v[0], v[1], lo);
     split3_pair(v[2], v[3], hi);
 #pragma unroll
-    for (int p = 0; p < 3; ++p) h[p] = make_uint2(lo[p], hi[p]);
+    for (int p = 0; p < 3; ++p) h[p] = u32x2_t{lo[p], hi[p]};
 }
 
 // One workgroup's share: output tile (tm, tn) over K chunks [c_begin, c_end) -> slab `split`.
@@ -211,13 +195,13 @@ __device__ __forceinline__ void gram_tile(const GramGeom& g, float* smem, const 
             }
             if constexpr (SPLIT) {
                 static_assert(!SPLIT || VEC == 4, "the split image is written four k at a time");
-                uint2 ha[3], hb[3];
+                u32x2_t ha[3], hb[3];
                 split3(ra.v[q], ha);
                 split3(rb.v[q], hb);
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {
-                    *reinterpret_cast<uint2*>(As16 + row * kSplitLd + p * kBK + scol) = ha[p];
-                    *reinterpret_cast<uint2*>(Bs16 + row * kSplitLd + p * kBK + scol) = hb[p];
+                    *reinterpret_cast<u32x2_t*>(As16 + row * kSplitLd + p * kBK + scol) = ha[p];
+                    *reinterpret_cast<u32x2_t*>(Bs16 + row * kSplitLd + p * kBK + scol) = hb[p];
                 }
             } else if constexpr (VEC == 4) {
                 f32x4 va = {ra.v[q][0], ra.v[q][1], ra.v[q][2], ra.v[q][3]};
@@ -611,16 +595,9 @@ extern "C" void pleas_gram_tune(int target_blocks, int min_chunks_per_split) {
     if (min_chunks_per_split > 0) g_min_chunks = min_chunks_per_split;
 }
 
-// Study switch: -1 = not set yet (read PLEAS_GRAM_SPLIT_BF16 once), 0 = exact fp32 MFMA (default).
-static int g_split_bf16 = -1;
-static bool split_bf16() {
-    if (g_split_bf16 < 0) {
-        const char* e = std::getenv("PLEAS_GRAM_SPLIT_BF16");
-        g_split_bf16 = (e && e[0] == '1') ? 1 : 0;
-    }
-    return g_split_bf16 == 1;
-}
-extern "C" void pleas_gram_split_bf16(int on) { g_split_bf16 = on ? 1 : 0; }
+// the matching contraction under pleas_arith(PLEAS_ARITH_SPLIT_BF16): gram_tile<TILE, 4, SPLIT = 1> on 16-byte-loadable nodes
+static bool split_bf16() { return arith_mode() == 1; }
+extern "C" void pleas_gram_split_bf16(int on) { pleas_arith(on ? PLEAS_ARITH_SPLIT_BF16 : PLEAS_ARITH_FP32); }   // round-3 name
 
 extern "C" size_t pleas_gram_ws_bytes(int B, int C, int64_t HW) {
     if (B <= 0 || C <= 0 || HW <= 0) return 0;

@@ -45,6 +45,7 @@ def test_conv2d_vs_fp64_and_repeatable(geo):
     got = hip_ops.conv2d(x, wk, b, stride, pad, kpos)
     assert got.shape == want.shape
     rel = lambda a: float((a.double() - want).norm() / want.norm())
+    print("conv2d %s: own %.2e, vendor %.2e from fp64" % (geo, rel(got), rel(ref)))
     assert rel(got) <= max(2e-6, 3 * rel(ref)), (rel(got), rel(ref))
     for _ in range(4):      # fixed summation order: the same bits every time
         assert torch.equal(hip_ops.conv2d(x, wk, b, stride, pad, kpos), got)
@@ -78,15 +79,30 @@ def test_source_forward_is_repeatable_and_matches_the_modules():
         for k in a:
             assert torch.equal(a[k], b[k]), k
     src.close()
-    with torch.no_grad():
-        want = {}
-        hooks = [mod.register_forward_hook(lambda m_, i, o, n=n: want.__setitem__(n, o))
-                 for n, mod in models[0].named_modules() if isinstance(mod, (torch.nn.Conv2d, torch.nn.Linear))]
-        models[0](x)
+    # accuracy: 101 layers amplify rounding differences (layer 4 of two fp32 forwards of this model differs by 1e-4..1e-3), so
+    # both fp32 paths are held to an fp64 forward of the same model: the fused path (own k x k convolutions, folded BatchNorm)
+    # must be as close to it, layer by layer, as the model's own modules (vendor convolutions, vendor BatchNorm) are
+    import copy
+
+    def taps_of(model, inp):
+        got = {}
+        hooks = [mod.register_forward_hook(lambda m_, i, o, n=n: got.__setitem__(n, o))
+                 for n, mod in model.named_modules() if isinstance(mod, (torch.nn.Conv2d, torch.nn.Linear))]
+        with torch.no_grad():
+            model(inp)
         for h in hooks:
             h.remove()
-    worst = max(float((runs[0][0][k] - want[k]).norm() / want[k].norm()) for k in want)
-    assert worst < 2e-5, worst
+        return got
+
+    vendor = taps_of(models[0], x)
+    exact = taps_of(copy.deepcopy(models[0]).double(), x.double())
+    rel = lambda a, b: float((a.double() - b).norm() / b.norm())
+    worst = (0.0, 0.0, "")
+    for k in exact:
+        own_err, ven_err = rel(runs[0][0][k], exact[k]), rel(vendor[k], exact[k])
+        assert own_err <= max(3 * ven_err, 2e-6), (k, own_err, ven_err)
+        worst = max(worst, (own_err, ven_err, k))
+    print("fused source forward vs fp64, worst layer %s: %.2e (the model's own modules there: %.2e)" % (worst[2], worst[0], worst[1]))
 
 
 def test_rn101_job_twice_is_bit_identical(tmp_path):
