@@ -74,6 +74,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-solver", action="store_true", help="skip the closed-form (normal equations) leg")
     ap.add_argument("--no-library-baseline", action="store_true", help="skip the stock-PyTorch-ROCm-operators leg on the GPU")
+    ap.add_argument("--no-alt-arith", action="store_true", help="skip the split-bf16 leg (the same job under pleas_arith(1))")
     ap.add_argument("--no-phases", action="store_true", help="skip the extra synchronised job that fills phases_s")
     ap.add_argument("--phase-log", action="store_true", help="debug: log the phases of that job as they finish")
     ap.add_argument("--prefetch-groups", type=int, default=2,
@@ -404,6 +405,64 @@ def time_normal_eq(spec, m1, m2, perm, costs, loader, ratio, sources_per_forward
             "_samples": samples, "_K": list(fit.K)}
 
 
+BF16_MATRIX_PEAK_TFLOPS = 2516.6      # MI355X_MICROARCH.md: 16 x the fp32 matrix rate (~2.5 PFLOP/s dense)
+
+
+def time_alt_arith(job, res, spec, value, n_match, world, rank, args):
+    """The SAME job under ``pleas_arith(PLEAS_ARITH_SPLIT_BF16)``: every fp32 operand of the contraction
+    kernels as the exact sum of three bf16 values, six bf16-MFMA products per k step, fp32 accumulation -- fp32 accuracy at 2.67x
+    less matrix-pipe time.  One untimed job, two timed ones; the kernels' HIP-event times; the result against the fp32-MFMA
+    job's on the same batches (assignments, costs, trained weights).  NOT the headline: ``value`` / ``dtype`` stay on the exact
+    fp32 MFMA path; ``parity_vs_oracle`` / ``parity_vs_fp64`` of this arithmetic are added by the cpu_baseline leg."""
+    from pleas_merging_amd import _lib, hip_ops
+
+    lib = _lib.lib()
+    lib.pleas_arith(1)
+    try:
+        job()
+        torch.cuda.synchronize()
+        hip_ops.profile_reset()
+        hip_ops.profile_enable(True, skip=("bn_act",))
+        times, alt = [], None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            alt = job()
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        hip_ops.profile_enable(False)
+        prof = hip_ops.profile_collect()
+    finally:
+        lib.pleas_arith(0)
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+    same = sum(1 for k in spec if torch.equal(alt["perm"][k], res["perm"][k]))
+    sd_a, sd_b = alt["m3"].state_dict(), res["m3"].state_dict()
+    rels = {k: rel(v, sd_b[k]) for k, v in sd_a.items() if v.dtype.is_floating_point and k != "conv1.weight"}
+    worst = max(rels, key=rels.get)
+    kernels = {}
+    for name, label in (("gram_partial", "gram_batch_kernel"), ("conv_fwd", "fwd_batch_kernel"), ("conv_wgrad", "wgrad_batch_kernel"),
+                        ("conv2d", "conv2d_fwd_kernel (k x k source convolutions)")):
+        rec = prof.get(name, (0, 0.0, 0.0, 0.0))
+        if rec[0]:
+            tf = rec[2] / (rec[1] * 1e-3) / 1e12
+            kernels[name] = {"kernel": label, "launches": rec[0], "avg_launch_us": round(rec[1] * 1e3 / rec[0], 2),
+                             "fp32_equivalent_tflops": round(tf, 1), "of_fp32_matrix_peak": round(tf / FP32_MATRIX_PEAK_TFLOPS, 3),
+                             "of_bf16_matrix_peak_over_6": round(tf / (BF16_MATRIX_PEAK_TFLOPS / 6.0), 3)}
+    out = {"arithmetic": "split bf16: x = h1 + h2 + h3 exactly, 6 of the 9 bf16 products per fp32 product on v_mfma_f32_32x32x16_bf16, "
+                         "fp32 accumulation (pleas_arith(PLEAS_ARITH_SPLIT_BF16)); tile forms without a split variant stay exact",
+           "job_s": round(min(times), 4), "jobs": [round(t, 4) for t in times], "speedup_vs_value": round(value / min(times), 3),
+           "kernels": kernels,
+           "vs_fp32_mfma_job": {"assignments_identical": "%d / %d" % (same, len(spec)),
+                                "worst_group_cost_rel_fro": max(rel(alt["costs"][k], res["costs"][k]) for k in spec),
+                                "worst_trained_tensor": worst, "worst_trained_rel_fro": rels[worst],
+                                "tensors_above_1e-4": sum(1 for v in rels.values() if v > 1e-4),
+                                "note": "full jobs on the same batches; weights after 401 Adam updates (sign-like first steps "
+                                        "amplify any rounding difference, as between any two fp32 implementations)"},
+           "note": "NOT the headline: value / dtype stay on the exact fp32 MFMA path until this leg has been through a green "
+                   "driver GPUTEST (tests/test_hip_split_bf16.py)"}
+    log("alt_arith (split bf16): %.3f s per job (fp32 MFMA %.3f), assignments identical %d / %d" % (min(times), value, same, len(spec)))
+    return out
+
+
 def time_sources_alone(m1, m2, pool, n_updates, per=2, groups=4):
     """The frozen source forwards of the PLeaS phase (vendor convolutions + pleas_bn_act, both models on two streams,
     ``per`` updates' batches per forward as in the jobs) with nothing else on the GPU, scaled to the job's updates."""
@@ -448,7 +507,7 @@ def time_bn_reset(m3, pool, n_batches=101):
     return out
 
 
-def cpu_baseline_and_parity(cfg, spec, m1, m2, pool, n_match, n_pleas, n_sched, sample_match, sample_updates):
+def cpu_baseline_and_parity(cfg, spec, m1, m2, pool, n_match, n_pleas, n_sched, sample_match, sample_updates, alt_arith=False):
     """The CPU oracle (restatement of the reference path) on this box's host cores, on the job's OWN first batches at the
     job's batch size -- ``sample_match`` matching batches and ``sample_updates`` PLeaS updates, i.e. the count is
     subsampled, not the batch -- and, on exactly those batches, the HIP job with the timed knobs (same batches per twin
@@ -457,8 +516,10 @@ def cpu_baseline_and_parity(cfg, spec, m1, m2, pool, n_match, n_pleas, n_sched, 
         is what the oracle's LAP returns on the HIP costs and its value under the ORACLE's costs is within 1e-6);
       * merged state dict bit-equal; trained tensors after the sample's updates (both sides continue from the ORACLE's
         assignment) against the oracle, with the oracle's own oneDNN-on / off disagreement as the yardstick
-        (tests/test_hip_timed_config.py is the same comparison as a test).
-    Returns (cpu_baseline, parity)."""
+        (tests/test_hip_timed_config.py is the same comparison as a test);
+      * the same sample in fp64 (oracle.fp64_anchor): distances TO it are statements about accuracy.
+    ``alt_arith``: the HIP job once more under pleas_arith(PLEAS_ARITH_SPLIT_BF16), compared with the SAME oracle results.
+    Returns (cpu_baseline, parity, parity of the split-bf16 job or None)."""
     import copy
 
     from oracle import pleas_oracle as orc
@@ -473,36 +534,35 @@ def cpu_baseline_and_parity(cfg, spec, m1, m2, pool, n_match, n_pleas, n_sched, 
     seen = {}
 
     def after_matching(perm, costs):
-        if cfg.get("match_mode") == "train":      # the oracle matches in the drivers' mode too (its `train` goes back to eval)
-            c1.train()
-            c2.train()
-        t0 = time.time()
-        want_costs = orc.matching_costs(spec, c1, c2, data[:nM], nM, accumulate=True)
-        seen["t_match"] = (time.time() - t0) / nM
-        t0 = time.time()
-        want_perm = {k: orc.solve_lsa(v) for k, v in want_costs.items()}
-        seen["t_lap"] = time.time() - t0
-        log("cpu: matching batch %.1fs, all LAPs %.2fs" % (seen["t_match"], seen["t_lap"]))
-        seen["want_perm"], seen["want_costs"] = want_perm, want_costs
-        return want_perm, {k: v.to(costs[k].device) for k, v in want_costs.items()}
+        if "want_perm" not in seen:
+            if cfg.get("match_mode") == "train":      # the oracle matches in the drivers' mode too (its `train` goes back to eval)
+                c1.train()
+                c2.train()
+            t0 = time.time()
+            want_costs = orc.matching_costs(spec, c1, c2, data[:nM], nM, accumulate=True)
+            seen["t_match"] = (time.time() - t0) / nM
+            t0 = time.time()
+            want_perm = {k: orc.solve_lsa(v) for k, v in want_costs.items()}
+            seen["t_lap"] = time.time() - t0
+            log("cpu: matching batch %.1fs, all LAPs %.2fs" % (seen["t_match"], seen["t_lap"]))
+            seen["want_perm"], seen["want_costs"] = want_perm, want_costs
+        return seen["want_perm"], {k: v.to(costs[k].device) for k, v in seen["want_costs"].items()}
 
     res = run_job(cfg, spec, m1, m2, pool.loader(0, nM), pool.loader(0, nU), n_sched, after_matching=after_matching)
     torch.cuda.synchronize()
+    res_alt = None
+    if alt_arith:
+        from pleas_merging_amd import _lib
+
+        _lib.lib().pleas_arith(1)
+        try:
+            res_alt = run_job(cfg, spec, m1, m2, pool.loader(0, nM), pool.loader(0, nU), n_sched, after_matching=after_matching)
+            torch.cuda.synchronize()
+        finally:
+            _lib.lib().pleas_arith(0)
     want_perm, want_costs = seen["want_perm"], seen["want_costs"]
     rel = lambda a, b: float((a.double().cpu() - b.double().cpu()).norm() / (b.double().norm() + 1e-30))
     value = lambda cost, perm: float(cost.double().cpu()[torch.arange(len(perm)), perm].sum())
-    worst_cost = max(rel(res["hip_costs"][k], want_costs[k]) for k in spec)
-    equal, near_ties, bad_groups = 0, {}, []
-    for k in spec:
-        if (res["hip_perm"][k] == want_perm[k]).all():
-            equal += 1
-            continue
-        same_lap = bool((orc.solve_lsa(res["hip_costs"][k].cpu()) == res["hip_perm"][k]).all())
-        best, mine = value(want_costs[k], want_perm[k]), value(want_costs[k], res["hip_perm"][k])
-        gap = (best - mine) / abs(best)
-        near_ties[str(k)] = [int((res["hip_perm"][k] != want_perm[k]).sum()), gap]
-        if not (same_lap and 0 <= gap < 1e-6):
-            bad_groups.append(str(k))
     # ---- merge + updates on the CPU, from the same assignment
     t0 = time.time()
     o3 = orc.partial_merge(spec, c1, c2, want_perm, want_costs, ratio)
@@ -517,67 +577,84 @@ def cpu_baseline_and_parity(cfg, spec, m1, m2, pool, n_match, n_pleas, n_sched, 
         v3 = orc.partial_merge(spec, c1, c2, want_perm, want_costs, ratio)
         v3, _ = orc.train(data[:nU], c1, c2, v3, spec, want_perm, want_costs, ratio, n_sched)
     variant = v3.state_dict()
-    got = {k: v.cpu() for k, v in res["m3"].state_dict().items()}
-    rows = {}
-    for k in want:
-        if k == "conv1.weight" or not want[k].dtype.is_floating_point or torch.equal(want[k], merged[k]):
-            continue      # the stem's residual is rounding noise in the reference itself
-        rows[k] = (rel(got[k], want[k]), rel(variant[k], want[k]))
-    worst = max(rows, key=lambda k: rows[k][0]) if rows else None
-    yard_max = max((v[1] for v in rows.values()), default=0.0)
-    over = {k: v for k, v in rows.items() if v[0] > max(1e-4, 3 * v[1])}
-    # tensors above 3 x their own yardstick: 0-1 of 105 observed in eval-mode matching, 2 in the drivers' train mode (one of them
-    # at 1.006e-4 against a 1e-4 floor); a wrong kernel moves dozens
-    ok = (worst_cost < 1e-4 and not bad_groups and len(near_ties) <= 4 and len(over) <= max(2, len(rows) // 50)
-          and all(v[0] <= max(1e-4, 3 * yard_max) for v in over.values()))
-    parity = {
-        "ok": bool(ok), "matching_batches": nM, "updates": nU, "batch": int(data[0][0].shape[0]),
-        "worst_group_cost_rel_fro": worst_cost, "assignments_equal": "%d / %d" % (equal, len(spec)),
-        "near_tie_groups": near_ties, "groups_that_are_not_near_ties": bad_groups,
-        "trained_tensors": len(rows), "worst_trained_tensor": worst,
-        "worst_trained_rel_fro": rows[worst][0] if worst else None,
-        "oracle_self_spread_of_that_tensor": rows[worst][1] if worst else None, "oracle_self_spread_worst": yard_max,
-        "tensors_above_1e-4": sum(1 for v in rows.values() if v[0] > 1e-4),
-        "tensors_above_3x_own_yardstick": {k: list(v) for k, v in over.items()},
-        "note": "HIP job with the timed knobs on the job's own first batches vs the CPU oracle on the same batches; trained "
-                "tensors: both sides continue from the oracle's assignment, yardstick = the oracle with oneDNN "
-                "convolutions on vs off; gate as tests/test_hip_timed_config.py"}
     # ---- the fp64 ANCHOR on the same batches: how far is each fp32 implementation from the exact path?  (distances between two
     # fp32 runs -- the yardstick above -- are statements about spread; these are statements about accuracy)
-    t0 = time.time()
     # (drivers' train-mode matching moves the running statistics batch by batch: the cost anchor is taken in eval mode only)
+    t0 = time.time()
     costs64, want64 = orc.fp64_anchor(spec, c1, c2, data, nM if cfg.get("match_mode") != "train" else 0, nU, want_perm,
                                       want_costs, ratio, n_sched)
     log("cpu: fp64 anchor %.1fs" % (time.time() - t0))
-    cost_rows = {str(k): (rel(res["hip_costs"][k], costs64[k]), rel(want_costs[k], costs64[k])) for k in spec} \
-        if costs64 is not None else {"-": (0.0, 0.0)}
-    t_rows = {k: (rel(got[k], want64[k]), max(rel(want[k], want64[k]), rel(variant[k], want64[k]))) for k in rows}
-    ratios = sorted(a / max(b, 1e-30) for a, b in t_rows.values()) or [0.0]
-    ref_max = max((b for _, b in t_rows.values()), default=0.0)
-    over_c = {k: list(v) for k, v in cost_rows.items() if v[0] > max(1e-6, 1.5 * v[1])}
-    over_t = {k: list(v) for k, v in t_rows.items() if v[0] > max(1e-4, 1.5 * v[1])}
-    anchor_ok = (not over_c and ratios[len(ratios) // 2] <= 1.25 and len(over_t) <= max(1, len(t_rows) // 20)
-                 and all(v[0] <= max(1e-4, 1.5 * ref_max) for v in over_t.values()))
-    parity["ok"] = bool(parity["ok"] and anchor_ok)
-    parity_fp64 = {
-        "ok": bool(anchor_ok), "groups": len(cost_rows), "worst_group_cost_hip_vs_fp64": max(a for a, _ in cost_rows.values()),
-        "worst_group_cost_oracle_fp32_vs_fp64": max(b for _, b in cost_rows.values()), "cost_groups_above_1.5x": over_c,
-        "tensors": len(t_rows), "worst_tensor_hip_vs_fp64": max((a for a, _ in t_rows.values()), default=0.0),
-        "worst_tensor_oracle_fp32_vs_fp64": ref_max, "median_ratio_hip_over_oracle_fp32": ratios[len(ratios) // 2],
-        "tensors_above_1e-4_vs_fp64": {"hip": sum(1 for a, _ in t_rows.values() if a > 1e-4),
-                                        "oracle_fp32": sum(1 for _, b in t_rows.values() if b > 1e-4)},
-        "tensors_above_1.5x_own_oracle_distance": over_t,
-        "note": "same batches in fp64 (oracle.fp64_anchor); per group cost hip <= 1.5 x oracle-fp32 distance (floor 1e-6); trained "
-                "tensors: median ratio <= 1.25, at most 1 in 20 above 1.5 x its own oracle distance (floor 1e-4; larger of the "
-                "oneDNN on / off variants), none above 1.5 x the model's largest -- the gate of tests/test_hip_timed_config.py"}
-    parity["parity_vs_fp64"] = parity_fp64
+
+    def compare(res):
+        worst_cost = max(rel(res["hip_costs"][k], want_costs[k]) for k in spec)
+        equal, near_ties, bad_groups = 0, {}, []
+        for k in spec:
+            if (res["hip_perm"][k] == want_perm[k]).all():
+                equal += 1
+                continue
+            same_lap = bool((orc.solve_lsa(res["hip_costs"][k].cpu()) == res["hip_perm"][k]).all())
+            best, mine = value(want_costs[k], want_perm[k]), value(want_costs[k], res["hip_perm"][k])
+            gap = (best - mine) / abs(best)
+            near_ties[str(k)] = [int((res["hip_perm"][k] != want_perm[k]).sum()), gap]
+            if not (same_lap and 0 <= gap < 1e-6):
+                bad_groups.append(str(k))
+        got = {k: v.cpu() for k, v in res["m3"].state_dict().items()}
+        rows = {}
+        for k in want:
+            if k == "conv1.weight" or not want[k].dtype.is_floating_point or torch.equal(want[k], merged[k]):
+                continue      # the stem's residual is rounding noise in the reference itself
+            rows[k] = (rel(got[k], want[k]), rel(variant[k], want[k]))
+        worst = max(rows, key=lambda k: rows[k][0]) if rows else None
+        yard_max = max((v[1] for v in rows.values()), default=0.0)
+        over = {k: v for k, v in rows.items() if v[0] > max(1e-4, 3 * v[1])}
+        # tensors above 3 x their own yardstick: 0-1 of 105 observed in eval-mode matching, 2 in the drivers' train mode (one of them
+        # at 1.006e-4 against a 1e-4 floor); a wrong kernel moves dozens
+        ok = (worst_cost < 1e-4 and not bad_groups and len(near_ties) <= 4 and len(over) <= max(2, len(rows) // 50)
+              and all(v[0] <= max(1e-4, 3 * yard_max) for v in over.values()))
+        parity = {
+            "ok": bool(ok), "matching_batches": nM, "updates": nU, "batch": int(data[0][0].shape[0]),
+            "worst_group_cost_rel_fro": worst_cost, "assignments_equal": "%d / %d" % (equal, len(spec)),
+            "near_tie_groups": near_ties, "groups_that_are_not_near_ties": bad_groups,
+            "trained_tensors": len(rows), "worst_trained_tensor": worst,
+            "worst_trained_rel_fro": rows[worst][0] if worst else None,
+            "oracle_self_spread_of_that_tensor": rows[worst][1] if worst else None, "oracle_self_spread_worst": yard_max,
+            "tensors_above_1e-4": sum(1 for v in rows.values() if v[0] > 1e-4),
+            "tensors_above_3x_own_yardstick": {k: list(v) for k, v in over.items()},
+            "note": "HIP job with the timed knobs on the job's own first batches vs the CPU oracle on the same batches; trained "
+                    "tensors: both sides continue from the oracle's assignment, yardstick = the oracle with oneDNN "
+                    "convolutions on vs off; gate as tests/test_hip_timed_config.py"}
+        cost_rows = {str(k): (rel(res["hip_costs"][k], costs64[k]), rel(want_costs[k], costs64[k])) for k in spec} \
+            if costs64 is not None else {"-": (0.0, 0.0)}
+        t_rows = {k: (rel(got[k], want64[k]), max(rel(want[k], want64[k]), rel(variant[k], want64[k]))) for k in rows}
+        ratios = sorted(a / max(b, 1e-30) for a, b in t_rows.values()) or [0.0]
+        ref_max = max((b for _, b in t_rows.values()), default=0.0)
+        over_c = {k: list(v) for k, v in cost_rows.items() if v[0] > max(1e-6, 1.5 * v[1])}
+        over_t = {k: list(v) for k, v in t_rows.items() if v[0] > max(1e-4, 1.5 * v[1])}
+        anchor_ok = (not over_c and ratios[len(ratios) // 2] <= 1.25 and len(over_t) <= max(1, len(t_rows) // 20)
+                     and all(v[0] <= max(1e-4, 3 * ref_max) for v in over_t.values()))
+        parity["ok"] = bool(parity["ok"] and anchor_ok)
+        parity["parity_vs_fp64"] = {
+            "ok": bool(anchor_ok), "groups": len(cost_rows), "worst_group_cost_hip_vs_fp64": max(a for a, _ in cost_rows.values()),
+            "worst_group_cost_oracle_fp32_vs_fp64": max(b for _, b in cost_rows.values()), "cost_groups_above_1.5x": over_c,
+            "tensors": len(t_rows), "worst_tensor_hip_vs_fp64": max((a for a, _ in t_rows.values()), default=0.0),
+            "worst_tensor_oracle_fp32_vs_fp64": ref_max, "median_ratio_hip_over_oracle_fp32": ratios[len(ratios) // 2],
+            "tensors_above_1e-4_vs_fp64": {"hip": sum(1 for a, _ in t_rows.values() if a > 1e-4),
+                                            "oracle_fp32": sum(1 for _, b in t_rows.values() if b > 1e-4)},
+            "tensors_above_1.5x_own_oracle_distance": over_t,
+            "note": "same batches in fp64 (oracle.fp64_anchor); per group cost hip <= 1.5 x oracle-fp32 distance (floor 1e-6); trained "
+                    "tensors: median ratio <= 1.25, at most 1 in 20 above 1.5 x its own oracle distance (floor 1e-4; larger of the "
+                    "oneDNN on / off variants), none above 3 x the model's largest -- the gate of tests/test_hip_timed_config.py"}
+        return parity
+
+    parity = compare(res)
+    parity_alt = compare(res_alt) if res_alt is not None else None
     total = n_match * seen["t_match"] + seen["t_lap"] + t_merge + n_pleas * t_step
     cpu = {"value": round(total, 1), "unit": "s", "cores": cores, "kind": "port",
            "sample": "oracle on the job's own batches at batch %d: %d matching batches (%.1fs each) + %d PLeaS updates (%.1fs "
                      "each), all %d LAPs (%.2fs), merge (%.2fs); counts scaled to %d matching batches + %d updates"
                      % (data[0][0].shape[0], nM, seen["t_match"], nU, t_step, len(want_perm), seen["t_lap"], t_merge, n_match,
                         n_pleas)}
-    return cpu, parity
+    return cpu, parity, parity_alt
 
 
 class _NodeTap(torch.fx.Interpreter):
@@ -964,6 +1041,9 @@ def main():
                   "note": "frozen source forwards of the PLeaS phase (MIOpen / Tensile convolutions + pleas_bn_act, both "
                           "models, %d samples per forward) with nothing else on the GPU; rocprofv3 kernel shares: profiles/"
                           % ((cfg["sources_per_forward"] or 2) * args.batch)}
+    alt_arith = None
+    if world == 1 and args.emulate_world <= 1 and not args.no_alt_arith and args.solver == "adam":
+        alt_arith = time_alt_arith(job, res, spec, value, n_match, world, rank, args)
     library = None
     if world == 1 and args.emulate_world <= 1 and not args.no_library_baseline and args.solver == "adam":
         library = library_baseline(cfg, spec, m1, m2, pool, n_match, n_pleas, n_sched, args.cpu_match_batches, args.cpu_updates,
@@ -1068,8 +1148,13 @@ def main():
                                   if args.emulate_allreduce_us > 0 else "skipped"))
             out["metric"] = "EMULATED " + out["metric"]
         if world == 1 and not args.no_cpu_baseline and args.emulate_world <= 1 and args.solver == "adam":
-            out["cpu_baseline"], parity = cpu_baseline_and_parity(cfg, spec, m1, m2, pool, n_match, n_pleas, n_sched,
-                                                                  args.cpu_match_batches, args.cpu_updates)
+            out["cpu_baseline"], parity, parity_alt = cpu_baseline_and_parity(cfg, spec, m1, m2, pool, n_match, n_pleas, n_sched,
+                                                                              args.cpu_match_batches, args.cpu_updates,
+                                                                              alt_arith=alt_arith is not None)
+            if alt_arith is not None and parity_alt is not None:
+                alt_arith["parity_vs_fp64"] = parity_alt.pop("parity_vs_fp64")
+                alt_arith["parity_vs_oracle"] = parity_alt
+                alt_arith["ok"] = bool(parity_alt["ok"])
             out["cpu_baseline"]["reference_legs"] = cpu_reference_legs(res["costs"], res["perm"], alt)
             checks["parity_vs_fp64"] = parity.pop("parity_vs_fp64")
             checks["parity_vs_oracle"] = parity
@@ -1098,6 +1183,8 @@ def main():
             out["alt_solver_emulated_rank"] = alt_emulated
         if inputs_cmp is not None:
             out["inputs"] = inputs_cmp
+        if alt_arith is not None:
+            out["alt_arith"] = alt_arith
         if library is not None:
             out["library_baseline"] = library
         if vendor is not None:

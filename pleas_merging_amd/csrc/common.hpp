@@ -60,6 +60,7 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 constexpr int kSplitRow = 104;   // bf16 per LDS row of a split image: 3 planes x 32 k + 8 pad = 208 B (13 16-byte slots: odd,
                                  // so the 16 rows of a ds_read_b128 lane group fall on 16 different slots)
 __device__ __forceinline__ uint32_t split_bf16_pair(float a, float b) {

@@ -61,8 +61,11 @@ struct WgradItemDev {
 // ONE 16-byte load at a 4-byte-aligned address (the hardware takes it; two aligned loads + a register shift move twice the
 // bytes through the 64 B/clk vector L1 and measured 5 % SLOWER than one pixel per load); nothing of Y is masked -- the
 // taps that fall off the image are voided by zeroing the RESIDUAL at those output pixels (a rectangle of (oh, ow)).
-template <int TM, int TN, int VECX, int YMODE>
+// SPLIT = 1 (pleas_arith(PLEAS_ARITH_SPLIT_BF16); 16-byte-loadable operands only: YMODE 0 / 2): the chunk goes to LDS as three
+// bf16 planes per row (common.hpp), ONE image per operand, two barriers per chunk, six v_mfma_f32_32x32x16_bf16 per k step.
+template <int TM, int TN, int VECX, int YMODE, int SPLIT = 0>
 __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradItemDev& it, float* smem) {
+    static_assert(!SPLIT || (VECX == 4 && (YMODE == 0 || YMODE == 2)), "the split image is written four k at a time");
     constexpr int MTM = TM / 64, MTN = TN / 64;
     constexpr bool YSHIFT = YMODE == 1;
     constexpr bool YROWS = YMODE == 3;     // every row of the Y tile has its own (channel, tap): virtual channels
@@ -72,6 +75,8 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradIt
     constexpr int LPR_Y = cBK / VECY, RPP_Y = cThreads / LPR_Y, PASS_Y = TN / RPP_Y;
     float* As = smem;                    // [2][TM][cLds]
     float* Bs = smem + 2 * TM * cLds;    // [2][TN][cLds]
+    __bf16* As16 = reinterpret_cast<__bf16*>(smem);      // SPLIT: [TM][kSplitRow], then [TN][kSplitRow]
+    __bf16* Bs16 = As16 + TM * kSplitRow;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int i0 = it.tm * TM, j0 = it.tn * TN;
@@ -249,7 +254,10 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradIt
         for (int q = 0; q < PASS_X; ++q) {
             const bool ok = kinx && ((okx >> q) & 1u);
             const int row = xrow + q * RPP_X;
-            if constexpr (VECX == 4) {
+            if constexpr (SPLIT) {
+                split3_store4(As16 + row * kSplitRow, xcol, (ok && (win & 1u)) ? rx[q][0] : 0.f, (ok && (win & 2u)) ? rx[q][1] : 0.f,
+                              (ok && (win & 4u)) ? rx[q][2] : 0.f, (ok && (win & 8u)) ? rx[q][3] : 0.f);
+            } else if constexpr (VECX == 4) {
                 f32x4 v = {(ok && (win & 1u)) ? rx[q][0] : 0.f, (ok && (win & 2u)) ? rx[q][1] : 0.f,
                            (ok && (win & 4u)) ? rx[q][2] : 0.f, (ok && (win & 8u)) ? rx[q][3] : 0.f};
                 *reinterpret_cast<f32x4*>(a + row * cLds + xcol) = v;
@@ -261,7 +269,11 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradIt
         for (int q = 0; q < PASS_Y; ++q) {
             const bool ok = (YROWS ? ((okyc >> q) & 1u) != 0 : kiny) && ((oky >> q) & 1u);
             const int row = yrow + q * RPP_Y;
-            if constexpr (YMODE == 2) {
+            if constexpr (SPLIT) {
+                const bool keep = YMODE == 2 ? ((oky >> q) & 1u) != 0 : ok;
+                split3_store4(Bs16 + row * kSplitRow, ycol, keep ? ry[q][0] : 0.f, keep ? ry[q][1] : 0.f, keep ? ry[q][2] : 0.f,
+                              keep ? ry[q][3] : 0.f);
+            } else if constexpr (YMODE == 2) {
                 const bool rowok = (oky >> q) & 1u;
                 f32x4 v = {rowok ? ry[q][0] : 0.f, rowok ? ry[q][1] : 0.f, rowok ? ry[q][2] : 0.f, rowok ? ry[q][3] : 0.f};
                 *reinterpret_cast<f32x4*>(b + row * cLds + ycol) = v;
@@ -274,6 +286,27 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradIt
         }
     };
     auto compute = [&](int buf) {
+        if constexpr (SPLIT) {
+            // lane (r, h) of k group g reads k = 16 g + 8 h .. + 7 of its row from each plane: the operand map of the MFMA
+            const __bf16* a16 = As16 + (wm * (TM / 2) + (lane & 31)) * kSplitRow + 8 * (lane >> 5);
+            const __bf16* b16 = Bs16 + (wn * (TN / 2) + (lane & 31)) * kSplitRow + 8 * (lane >> 5);
+#pragma unroll
+            for (int g16 = 0; g16 < cBK / 16; ++g16) {
+                bf16x8_t sa[MTM][3], sb[MTN][3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                    for (int s_ = 0; s_ < MTM; ++s_) sa[s_][p] = *reinterpret_cast<const bf16x8_t*>(a16 + s_ * 32 * kSplitRow + p * 32 + g16 * 16);
+#pragma unroll
+                    for (int s_ = 0; s_ < MTN; ++s_) sb[s_][p] = *reinterpret_cast<const bf16x8_t*>(b16 + s_ * 32 * kSplitRow + p * 32 + g16 * 16);
+                }
+#pragma unroll
+                for (int sm = 0; sm < MTM; ++sm)
+#pragma unroll
+                    for (int sn = 0; sn < MTN; ++sn) acc[sm][sn] = split3_mfma(sa[sm], sb[sn], acc[sm][sn]);
+            }
+            return;
+        }
         const float* a = As + buf * TM * cLds + (wm * (TM / 2) + (lane & 31)) * cLds + 4 * (lane >> 5);
         const float* b = Bs + buf * TN * cLds + (wn * (TN / 2) + (lane & 31)) * cLds + 4 * (lane >> 5);
 #pragma unroll
@@ -298,6 +331,16 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradIt
         store_chunk(0);
     }
     __syncthreads();
+    if constexpr (SPLIT) {
+        for (int c = it.c_begin; c < it.c_end; ++c) {
+            const bool more = c + 1 < it.c_end;
+            if (more) load_chunk(c + 1);      // stays in registers while this chunk is multiplied
+            compute(0);
+            __syncthreads();                  // every wave is done reading the image
+            if (more) store_chunk(0);
+            __syncthreads();
+        }
+    } else
     for (int c = it.c_begin; c < it.c_end; ++c) {
         const int buf = (c - it.c_begin) & 1;
         const bool more = c + 1 < it.c_end;
@@ -374,6 +417,14 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradIt
         }
 }
 
+// the split-bf16 forms: 16-byte-loadable operands only (1x1 stride-1 layers and stride-1 "same" k x k layers on images with
+// HW % 4 == 0); the plan sends every other layer's items to the exact kernel
+template <int TM, int TN>
+__device__ __forceinline__ void wgrad_dispatch_split(const WgradLayerDev& L, const WgradItemDev& it, float* smem) {
+    if (L.variant & 16) wgrad_tile<TM, TN, 4, 2, 1>(L, it, smem);
+    else wgrad_tile<TM, TN, 4, 0, 1>(L, it, smem);
+}
+
 template <int TM, int TN>
 __device__ __forceinline__ void wgrad_dispatch(const WgradLayerDev& L, const WgradItemDev& it, float* smem) {
     const bool xs = L.variant & 4, ys = L.variant & 8;
@@ -427,6 +478,20 @@ __global__ __launch_bounds__(cThreads, 2) void wgrad_batch_kernel(const WgradLay
         g_wgrad_timeline[blockIdx.x][3] = (long long)(it.c_end - it.c_begin) * ((L.variant & 1) ? 64 : 128) * ((L.variant & 2) ? 64 : 128);
     }
 #endif
+}
+
+__global__ __launch_bounds__(cThreads, 2) void wgrad_batch_split_kernel(const WgradLayerDev* __restrict__ layers,
+                                                                     const WgradItemDev* __restrict__ items) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const WgradItemDev it = items[blockIdx.x];
+    if (it.layer < 0) return;   // padding of the XCD-aware item order
+    const WgradLayerDev L = layers[it.layer];
+    switch (L.variant & 3) {  // block-uniform
+        case 0: wgrad_dispatch_split<128, 128>(L, it, smem); break;
+        case 1: wgrad_dispatch_split<64, 128>(L, it, smem); break;
+        case 2: wgrad_dispatch_split<128, 64>(L, it, smem); break;
+        default: wgrad_dispatch_split<64, 64>(L, it, smem); break;
+    }
 }
 
 // per-update operand pointers -> device layer table (carried in kernel arguments)
@@ -557,6 +622,9 @@ struct WgradPlan {
     size_t off_layers = 0, off_items = 0, off_bl = 0, off_bb = 0, off_slabs = 0, total = 0, lds = 0;
     double flops = 0, bytes = 0;
     bool uploaded = false;
+    int n_split = 0;         // items [0, n_split) run the split-bf16 kernel, the rest the exact one (pleas_arith)
+    size_t lds_split = 0;
+    double flops_split = 0;
 };
 // A few plans are kept (keyed by layer geometry + workspace address): a caller may alternate between grouped launches,
 // e.g. the two gradient buckets of a data-parallel update, without rebuilding and re-uploading the tables each time.
@@ -576,7 +644,11 @@ static int build_wgrad_plan(WgradPlan& P, const pleas_wgrad_layer* ly, int n) {
     P.lds = 0;
     std::vector<size_t> slab_off(n, 0);
     size_t slabs = 0;
-    std::vector<XcdWork<WgradItemDev>> work;
+    std::vector<XcdWork<WgradItemDev>> work, work_split;
+    const bool split_on = arith_mode() == 1;
+    P.n_split = 0;
+    P.lds_split = 0;
+    P.flops_split = 0;
     int blk = 0;
     for (int i = 0; i < n; ++i) {
         const pleas_wgrad_layer& l = ly[i];
@@ -633,7 +705,17 @@ static int build_wgrad_plan(WgradPlan& P, const pleas_wgrad_layer* ly, int n) {
             }
             blk += nb;
         }
-        P.lds = std::max(P.lds, (size_t)2 * (TM + TN) * cLds * sizeof(float));
+        // split-bf16 arithmetic: the 16-byte-loadable forms (X vector loads; Y direct or the aligned shifted form)
+        const bool split = split_on && xvec && !virt && (ydirect || (d.variant & 16));
+        if (split) {
+            d.variant |= 64;
+            P.lds_split = std::max(P.lds_split, (size_t)(TM + TN) * kSplitRow * sizeof(__bf16));
+            // the epilogue stages [TM][TN + 4] floats in the same memory
+            P.lds_split = std::max(P.lds_split, (size_t)TM * (TN + 4) * sizeof(float));
+            P.flops_split += 2.0 * l.Cout * (double)Cin * R * (double)K;
+        } else {
+            P.lds = std::max(P.lds, (size_t)2 * (TM + TN) * cLds * sizeof(float));
+        }
         P.flops += 2.0 * l.Cout * (double)Cin * R * (double)K;
         P.bytes += ((double)l.Cout * K + (double)l.Cin * l.N * HWi) * sizeof(float);
         const int tms = (int)ceil_div(l.Cout, TM), tns = (int)ceil_div(Cin, TN);
@@ -645,10 +727,15 @@ static int build_wgrad_plan(WgradPlan& P, const pleas_wgrad_layer* ly, int n) {
                         w.it = WgradItemDev{i, tm, tn, r, s, s * cps, std::min((s + 1) * cps, nchunks), 0};
                         w.w = (double)(w.it.c_end - w.it.c_begin) * TM * TN;
                         w.key = (int64_t)i * 65536 + s;   // every (tile, tap) of one K range reads the same residual / input rows
-                        work.push_back(w);
+                        (split ? work_split : work).push_back(w);
                     }
     }
-    P.items = xcd_order_items(work, WgradItemDev{-1, 0, 0, 0, 0, 0, 0, 0});
+    P.items = xcd_order_items(work_split, WgradItemDev{-1, 0, 0, 0, 0, 0, 0, 0});
+    P.n_split = (int)P.items.size();
+    {
+        std::vector<WgradItemDev> rest = xcd_order_items(work, WgradItemDev{-1, 0, 0, 0, 0, 0, 0, 0});
+        P.items.insert(P.items.end(), rest.begin(), rest.end());
+    }
     size_t off = 0;
     P.off_layers = off;
     off = walign(off + P.layers.size() * sizeof(WgradLayerDev));
@@ -669,7 +756,7 @@ static std::vector<int64_t> wgrad_key(const pleas_wgrad_layer* ly, int n, const 
     std::vector<int64_t> k;
     k.push_back(n);
     k.push_back((int64_t)(uintptr_t)ws);
-    k.push_back(g_wgrad_item_chunks);
+    k.push_back(g_wgrad_item_chunks * 2 + arith_mode());      // plans differ between the arithmetics (pleas_arith)
     for (int i = 0; i < n; ++i) {
         const pleas_wgrad_layer& l = ly[i];
         for (int v : {l.N, l.Cout, l.Cin, l.Hin, l.Win, l.KH, l.KW, l.stride, l.pad, l.flags}) k.push_back(v);
@@ -761,9 +848,16 @@ extern "C" int pleas_wgrad_batch(const pleas_wgrad_layer* layers, int n_layers, 
     }
     {
         ProfScope prof(kProfConvWgrad, P.flops, P.bytes, stream);
-        hipLaunchKernelGGL(wgrad_batch_kernel, dim3((unsigned)P.items.size()), dim3(cThreads), P.lds, stream, dl,
-                           reinterpret_cast<const WgradItemDev*>(base + P.off_items));
-        PLEAS_LAUNCH_CHECK("wgrad_batch_kernel");
+        const WgradItemDev* its = reinterpret_cast<const WgradItemDev*>(base + P.off_items);
+        if (P.n_split > 0) {
+            hipLaunchKernelGGL(wgrad_batch_split_kernel, dim3((unsigned)P.n_split), dim3(cThreads), P.lds_split, stream, dl, its);
+            PLEAS_LAUNCH_CHECK("wgrad_batch_split_kernel");
+        }
+        if ((int)P.items.size() > P.n_split) {
+            hipLaunchKernelGGL(wgrad_batch_kernel, dim3((unsigned)(P.items.size() - P.n_split)), dim3(cThreads), P.lds, stream, dl,
+                               its + P.n_split);
+            PLEAS_LAUNCH_CHECK("wgrad_batch_kernel");
+        }
         if (!P.blk_layer.empty()) {
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)P.blk_layer.size()), dim3(256), 0, stream, dl,
                                reinterpret_cast<const int*>(base + P.off_bl),

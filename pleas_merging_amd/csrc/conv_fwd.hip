@@ -452,8 +452,18 @@ __shared__ long long g_tl_phase[2];   // wall clock at the end of the prologue /
 // KIND 0: 1x1, 16-B loads along the pixel axis (HW % 4 == 0), two images (double buffer)
 // KIND 1: 1x1, scalar loads (HW % 4 != 0, e.g. 7 x 7), two images
 // KIND 2: k x k, scalar loads, ONE image per channel block shared by all taps
-template <int TM, int KIND>
+// SPLIT = 1 (pleas_arith(PLEAS_ARITH_SPLIT_BF16); KIND 0 and 2): every chunk goes to LDS as three bf16 planes (common.hpp), ONE
+// image per operand (two barriers per chunk), six v_mfma_f32_32x32x16_bf16 per 16-deep k step.
+//   weights:      [TM][kSplitRow] rows (3 planes x 32 k), fragments by ds_read_b128 -- the operand map of the MFMA
+//   k x k input:  [column][kSplitRow], a pixel's 32 channels contiguous per plane: the same 16-byte fragment reads
+//   1 x 1 input:  [plane][k][fSplitPixRow] (pixels contiguous, as they come from memory: 8-byte writes), fragments by
+//                 ds_read_b64_tr_b16 -- the hardware transposes 4 k x 16 pixels per 16-lane group
+constexpr int fSplitPixRow = 160;  // bf16 per k row of the 1 x 1 split image: 128 pixels + 32 pad = 320 B (rows 16 banks apart:
+                                   // the four rows x eight 8-byte column chunks of a half-wave's transposed read hit 32 distinct bank pairs)
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+template <int TM, int KIND, int SPLIT = 0>
 __device__ __forceinline__ void fwd_flat_tile(const FwdLayerDev& L, const FwdItemDev& it, float* smem, float* __restrict__ partials) {
+    static_assert(!SPLIT || KIND != 1, "the scalar 1 x 1 form (7 x 7 images) has no split variant");
     constexpr int MTM = TM / 64;
     constexpr int LPR = fBK / 4, RPP = fThreads / LPR, PASS = TM / RPP;   // weight staging: 16-B loads
     constexpr int Lr = KIND == 2 ? fFlatPix : fFlatRow1;                // compile-time: LDS offsets are immediates
@@ -473,6 +483,8 @@ __device__ __forceinline__ void fwd_flat_tile(const FwdLayerDev& L, const FwdIte
     const int nchunks = CB * R;
     float* As = smem;                                // [2][TM][fLdsA]
     float* Bs = smem + 2 * TM * fLdsA;               // 1x1: [NBUF][32][Lr]; k x k: [fFlatColsK][fFlatPix]
+    __bf16* As16 = reinterpret_cast<__bf16*>(smem);  // SPLIT: [TM][kSplitRow]
+    __bf16* Bs16 = As16 + TM * kSplitRow;            // SPLIT: k x k [fFlatColsK][kSplitRow]; 1 x 1 [3][32][fSplitPixRow]
 
     // ---- A (weights) staging, as in fwd_tile with VECA = 4
     const int arow = tid / LPR, acol = (tid % LPR) * 4;
@@ -558,6 +570,15 @@ __device__ __forceinline__ void fwd_flat_tile(const FwdLayerDev& L, const FwdIte
     const bool full_a = i0 + TM <= L.Cout;
     const bool full_b = p0 + fTN <= L.Ptot;
     auto store_a = [&](int buf, const f32x4 (&ra)[PASS]) {
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int q = 0; q < PASS; ++q) {
+                const bool ok = full_a || ((oka >> q) & 1u);
+                split3_store4(As16 + (arow + q * RPP) * kSplitRow, acol, ok ? ra[q][0] : 0.f, ok ? ra[q][1] : 0.f,
+                              ok ? ra[q][2] : 0.f, ok ? ra[q][3] : 0.f);
+            }
+            return;
+        }
         float* a = As + buf * TM * fLdsA;
         if (full_a) {
 #pragma unroll
@@ -595,6 +616,35 @@ __device__ __forceinline__ void fwd_flat_tile(const FwdLayerDev& L, const FwdIte
         }
     };
     auto store_b = [&](int buf, const auto& rb) {
+        if constexpr (SPLIT && KIND == 0) {
+            // this thread holds k rows tid / 32 + 8 i of pixels 4 (tid % 32) .. + 3: per row and plane one 8-byte write
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t lo[3], hi[3];
+                split3_pair(vok ? rb[4 * i] : 0.f, vok ? rb[4 * i + 1] : 0.f, lo);
+                split3_pair(vok ? rb[4 * i + 2] : 0.f, vok ? rb[4 * i + 3] : 0.f, hi);
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    *reinterpret_cast<u32x2_t*>(Bs16 + (p * fBK + (tid >> 5) + 8 * i) * fSplitPixRow + 4 * (tid & 31)) = u32x2_t{lo[p], hi[p]};
+            }
+            return;
+        } else if constexpr (SPLIT && KIND == 2) {
+            // channels 8 wave .. + 7 of columns lane + 64 m: per column and plane ONE 16-byte write
+#pragma unroll
+            for (int m = 0; m < MCOL; ++m)
+                if (m < M && lane + 64 * m < span) {
+                    const bool ok = (vok >> m) & 1u;
+                    uint32_t w[4][3];
+#pragma unroll
+                    for (int h = 0; h < 4; ++h)
+                        split3_pair(ok ? rb[(2 * h) * MCOL + m] : 0.f, ok ? rb[(2 * h + 1) * MCOL + m] : 0.f, w[h]);
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        *reinterpret_cast<u32x4_t*>(Bs16 + (lane + 64 * m) * kSplitRow + p * 32 + 8 * wave) =
+                            u32x4_t{w[0][p], w[1][p], w[2][p], w[3][p]};
+                }
+            return;
+        }
         float* b = Bs + buf * fBK * Lr;
         if constexpr (KIND == 0) {
             if (full_b) {
@@ -653,6 +703,49 @@ __device__ __forceinline__ void fwd_flat_tile(const FwdLayerDev& L, const FwdIte
 #define PLEAS_FWD_ZEROCOL 0
 #endif
         const bool ok0 = (tapok[0] >> r) & 1u, ok1 = (tapok[1] >> r) & 1u;
+        if constexpr (SPLIT) {
+            const __bf16* a16 = As16 + (wm * (TM / 2) + (lane & 31)) * kSplitRow + 8 * (lane >> 5);
+#pragma unroll
+            for (int g16 = 0; g16 < fBK / 16; ++g16) {
+                bf16x8_t sa[MTM][3], sb[2][3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int s_ = 0; s_ < MTM; ++s_) sa[s_][p] = *reinterpret_cast<const bf16x8_t*>(a16 + s_ * 32 * kSplitRow + p * 32 + g16 * 16);
+                if constexpr (KIND == 2) {
+                    // a lane whose tap is off the image reads the zero row (one select on the address per tap and fragment)
+                    const __bf16* c0 = Bs16 + (ok0 ? jb[0] + delta : jz) * kSplitRow + 8 * (lane >> 5) + g16 * 16;
+                    const __bf16* c1 = Bs16 + (ok1 ? jb[1] + delta : jz) * kSplitRow + 8 * (lane >> 5) + g16 * 16;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        sb[0][p] = *reinterpret_cast<const bf16x8_t*>(c0 + p * 32);
+                        sb[1][p] = *reinterpret_cast<const bf16x8_t*>(c1 + p * 32);
+                    }
+                } else {
+                    // transposed reads: lane 4 q + pp of a 16-lane group supplies row q, columns 4 pp .. + 3 of the group's
+                    // 4 k x 16 pixel block and receives its own pixel's four k; two reads give the lane its 8 k
+                    const int u = (lane >> 4) & 1, q = (lane >> 2) & 3, pp = lane & 3;
+                    const int krow = g16 * 16 + 8 * (lane >> 5) + q;
+#pragma unroll
+                    for (int sn = 0; sn < 2; ++sn)
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) {
+                            const __bf16* base = Bs16 + (p * fBK + krow) * fSplitPixRow + wn * 64 + sn * 32 + 16 * u + 4 * pp;
+                            const s16x4_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base));
+                            const s16x4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base + 4 * fSplitPixRow));
+                            typedef short s16x8_t __attribute__((ext_vector_type(8)));
+                            const s16x8_t both = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+                            sb[sn][p] = __builtin_bit_cast(bf16x8_t, both);
+                        }
+                }
+#pragma unroll
+                for (int sm = 0; sm < MTM; ++sm) {
+                    acc[sm][0] = split3_mfma(sa[sm], sb[0], acc[sm][0]);
+                    acc[sm][1] = split3_mfma(sa[sm], sb[1], acc[sm][1]);
+                }
+            }
+            return;
+        }
         if constexpr (KIND == 2) {
             // [column][k] image: a lane's four k of an MFMA group are ONE 16-byte read; a lane whose tap is off the image
             // reads the zero row (one select on the address per tap and fragment instead of one per value)
@@ -699,7 +792,11 @@ __device__ __forceinline__ void fwd_flat_tile(const FwdLayerDev& L, const FwdIte
     };
 
     // zero column of every row of every image (never overwritten: data columns end at span - 1 < jz); k x k: the zero row
-    if constexpr (KIND == 2) {
+    if constexpr (SPLIT) {
+        if constexpr (KIND == 2) {       // the zero row of the split image: 3 planes x 32 k
+            if (tid < 12) *reinterpret_cast<u32x4_t*>(Bs16 + jz * kSplitRow + 8 * tid) = u32x4_t{0u, 0u, 0u, 0u};
+        }                                // 1 x 1: pixels past the tensor's end are stored as zeros (no zero column)
+    } else if constexpr (KIND == 2) {
         if (tid < fFlatPix / 4) *reinterpret_cast<f32x4*>(Bs + jz * fFlatPix + 4 * tid) = f32x4{0.f, 0.f, 0.f, 0.f};
     } else if (tid < fBK * NBUF) Bs[tid * Lr + jz] = 0.f;
     load_a(0, 0, ra0);
@@ -735,6 +832,18 @@ __device__ __forceinline__ void fwd_flat_tile(const FwdLayerDev& L, const FwdIte
             if (r1 == R - 2 && cb1 + 1 < CB) load_b(cb1 + 1, rb0);     // ONE register set: an image per R chunks
         }
         compute(c & 1, bsel, r);
+        if constexpr (SPLIT) {
+            __syncthreads();                         // every wave is done reading the (single) images
+            store_a(0, ra_next);
+            if (newb) {
+                if constexpr (KIND == 2) store_b(0, rb0);
+                else store_b(0, rb_next);
+            }
+            __syncthreads();
+            r1 = r2;
+            cb1 = cb2;
+            return;
+        }
         store_a((c + 1) & 1, ra_next);
         if (newb) {
             if constexpr (NBUF == 2) {
@@ -778,7 +887,10 @@ constexpr int fForms = 10;
 __device__ long long g_fwd_timeline[32768][4];   // start, end (100 MHz wall clock), flat forms: prologue | K loop << 32 [ticks], form | chunks * TM << 8
 __device__ int g_fwd_timeline_n;
 #endif
-template <int FORM>
+// SPLIT = 1: the split-bf16 variant of a flat form (4, 6, 7, 9: KIND 0 / 2), launched instead of the exact one when the plan
+// was built under pleas_arith(PLEAS_ARITH_SPLIT_BF16); every other form runs the exact arithmetic in the same launch group.
+constexpr bool fwd_form_splits(int form) { return form == 4 || form == 6 || form == 7 || form == 9; }
+template <int FORM, int SPLIT = 0>
 __global__ __launch_bounds__(fThreads, 2) void fwd_batch_kernel(const FwdLayerDev* __restrict__ layers,
                                                              const FwdItemDev* __restrict__ items,
                                                              float* __restrict__ partials) {
@@ -808,12 +920,12 @@ __global__ __launch_bounds__(fThreads, 2) void fwd_batch_kernel(const FwdLayerDe
     else if constexpr (FORM == 1) fwd_tile<64, 4>(L, it, smem, partials);
     else if constexpr (FORM == 2) fwd_tile<128, 1>(L, it, smem, partials);
     else if constexpr (FORM == 3) fwd_tile<64, 1>(L, it, smem, partials);
-    else if constexpr (FORM < 7) fwd_flat_tile<128, FORM - 4>(L, it, smem, partials);
-    else fwd_flat_tile<64, FORM - 7>(L, it, smem, partials);
+    else if constexpr (FORM < 7) fwd_flat_tile<128, FORM - 4, SPLIT>(L, it, smem, partials);
+    else fwd_flat_tile<64, FORM - 7, SPLIT>(L, it, smem, partials);
 }
 // A plain convolution (pleas_conv2d_fwd): ONE layer, described in the kernel arguments; the work item is the block index
 // (output-channel tile fastest, as in the grouped plan), no tables, no target, no loss.
-template <int FORM>
+template <int FORM, int SPLIT = 0>
 __global__ __launch_bounds__(fThreads, 2) void conv2d_fwd_kernel(const FwdLayerDev L, const int tms) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const FwdItemDev it{0, (int)(blockIdx.x % (unsigned)tms), (int)(blockIdx.x / (unsigned)tms), 0};
@@ -821,8 +933,8 @@ __global__ __launch_bounds__(fThreads, 2) void conv2d_fwd_kernel(const FwdLayerD
     else if constexpr (FORM == 1) fwd_tile<64, 4>(L, it, smem, nullptr);
     else if constexpr (FORM == 2) fwd_tile<128, 1>(L, it, smem, nullptr);
     else if constexpr (FORM == 3) fwd_tile<64, 1>(L, it, smem, nullptr);
-    else if constexpr (FORM < 7) fwd_flat_tile<128, FORM - 4>(L, it, smem, nullptr);
-    else fwd_flat_tile<64, FORM - 7>(L, it, smem, nullptr);
+    else if constexpr (FORM < 7) fwd_flat_tile<128, FORM - 4, SPLIT>(L, it, smem, nullptr);
+    else fwd_flat_tile<64, FORM - 7, SPLIT>(L, it, smem, nullptr);
 }
 // side streams + events of the library for the concurrent forms (created once per process; no device memory)
 constexpr int fLanes = 3;          // side streams (+ the caller's stream = four hardware queues)
@@ -916,6 +1028,7 @@ struct FwdPlan {
     double flops = 0, bytes = 0;
     int n_parts = 0;
     bool uploaded = false;
+    bool split = false;                // built under pleas_arith(PLEAS_ARITH_SPLIT_BF16): the flat forms launch their split kernels
     // lanes from MEASURED durations: launch kCalibAt of a plan brackets every form's kernel with events on its lane; a
     // later launch that finds them complete deals the forms again, longest measured duration first
     int launches = 0, calib = 0;       // calib: 0 not measured yet, 1 events recorded, 2 lanes dealt from measurements
@@ -1104,6 +1217,12 @@ static int fwd_describe(const pleas_fwd_layer& l, FwdLayerDev& d, size_t& lds_by
             fTN + 2 * halo < Lr && flat_lds <= lds_bytes && (int64_t)l.N * l.Cin * HWo < (1ll << 32)) {
             d.variant |= 8 | (kind << 4);
             lds_bytes = flat_lds;
+            if (arith_mode() == 1 && kind != 1) {
+                // split-bf16 images (fwd_flat_tile<.., SPLIT = 1>): weights [TM][kSplitRow] + input k x k [columns][kSplitRow] /
+                // 1 x 1 [3][32][fSplitPixRow] bf16, ONE image each; the epilogue stages [TM][132] floats in the same memory
+                const size_t img = (size_t)(TM * kSplitRow + (kind == 2 ? fFlatColsK * kSplitRow : 3 * fBK * fSplitPixRow)) * sizeof(__bf16);
+                lds_bytes = std::max(img, (size_t)TM * 132 * sizeof(float));
+            }
         }
     }
     TM_out = TM;
@@ -1114,6 +1233,7 @@ static std::mutex g_fplan_mu;
 static size_t falign(size_t v) { return (v + 255) / 256 * 256; }
 
 static int build_fwd_plan(FwdPlan& P, const pleas_fwd_layer* ly, int n) {
+    P.split = arith_mode() == 1;
     P.layers.assign(n, FwdLayerDev());
     P.items.clear();
     for (int f = 0; f < fForms; ++f) P.form_begin[f] = P.form_count[f] = 0;
@@ -1302,8 +1422,16 @@ extern "C" int pleas_conv2d_fwd(const float* x, const float* w, const float* bia
     hipStream_t st = (hipStream_t)stream_;
     ProfScope prof(kProfConv2d, 2.0 * Cout * (double)d.Kd * (double)d.Ptot,
                    ((double)Cin * N * Hin * Win + (double)Cout * d.Ptot) * sizeof(float), st);
-    switch (fwd_form_of(d.variant)) {
-#define PLEAS_CONV_LAUNCH(F) case F: hipLaunchKernelGGL(conv2d_fwd_kernel<F>, grid, dim3(fThreads), lds, st, d, tms); break
+    const int form = fwd_form_of(d.variant);
+    if (arith_mode() == 1 && fwd_form_splits(form)) {
+        switch (form) {
+#define PLEAS_CONV_LAUNCH(F) case F: hipLaunchKernelGGL((conv2d_fwd_kernel<F, 1>), grid, dim3(fThreads), lds, st, d, tms); break
+            PLEAS_CONV_LAUNCH(4); PLEAS_CONV_LAUNCH(6); PLEAS_CONV_LAUNCH(7); PLEAS_CONV_LAUNCH(9);
+#undef PLEAS_CONV_LAUNCH
+        }
+    } else
+    switch (form) {
+#define PLEAS_CONV_LAUNCH(F) case F: hipLaunchKernelGGL((conv2d_fwd_kernel<F, 0>), grid, dim3(fThreads), lds, st, d, tms); break
         PLEAS_CONV_LAUNCH(0); PLEAS_CONV_LAUNCH(1); PLEAS_CONV_LAUNCH(2); PLEAS_CONV_LAUNCH(3); PLEAS_CONV_LAUNCH(4);
         PLEAS_CONV_LAUNCH(5); PLEAS_CONV_LAUNCH(6); PLEAS_CONV_LAUNCH(7); PLEAS_CONV_LAUNCH(8); PLEAS_CONV_LAUNCH(9);
 #undef PLEAS_CONV_LAUNCH
@@ -1324,7 +1452,7 @@ extern "C" int pleas_fwd_batch(const pleas_fwd_layer* layers, int n_layers, floa
     hipStream_t stream = (hipStream_t)stream_;
     std::lock_guard<std::mutex> lk(g_fplan_mu);
     std::vector<int64_t> key;
-    key.push_back(n_layers);
+    key.push_back(n_layers * 2 + arith_mode());      // plans (LDS sizes, kernels) differ between the arithmetics
     key.push_back((int64_t)(uintptr_t)ws);
     for (int i = 0; i < n_layers; ++i) {
         const pleas_fwd_layer& l = layers[i];
@@ -1429,8 +1557,15 @@ extern "C" int pleas_fwd_batch(const pleas_fwd_layer* layers, int n_layers, floa
             const FwdItemDev* its = items + un.begin;
             const size_t lds = P.form_lds[f];
             if (measure) PLEAS_HIP_CHECK(hipEventRecord(P.t0[o], st));
+            if (P.split && fwd_form_splits(f)) {
+                switch (f) {
+#define PLEAS_FWD_LAUNCH(F) case F: hipLaunchKernelGGL((fwd_batch_kernel<F, 1>), grid, dim3(fThreads), lds, st, dl, its, parts); break
+                    PLEAS_FWD_LAUNCH(4); PLEAS_FWD_LAUNCH(6); PLEAS_FWD_LAUNCH(7); PLEAS_FWD_LAUNCH(9);
+#undef PLEAS_FWD_LAUNCH
+                }
+            } else
             switch (f) {
-#define PLEAS_FWD_LAUNCH(F) case F: hipLaunchKernelGGL(fwd_batch_kernel<F>, grid, dim3(fThreads), lds, st, dl, its, parts); break
+#define PLEAS_FWD_LAUNCH(F) case F: hipLaunchKernelGGL((fwd_batch_kernel<F, 0>), grid, dim3(fThreads), lds, st, dl, its, parts); break
                 PLEAS_FWD_LAUNCH(0); PLEAS_FWD_LAUNCH(1); PLEAS_FWD_LAUNCH(2); PLEAS_FWD_LAUNCH(3); PLEAS_FWD_LAUNCH(4);
                 PLEAS_FWD_LAUNCH(5); PLEAS_FWD_LAUNCH(6); PLEAS_FWD_LAUNCH(7); PLEAS_FWD_LAUNCH(8); PLEAS_FWD_LAUNCH(9);
 #undef PLEAS_FWD_LAUNCH
