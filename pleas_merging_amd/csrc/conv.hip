@@ -358,40 +358,50 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradIt
     const bool kpos = (L.flags & PLEAS_WGRAD_KPOS_MAJOR) != 0;
     const bool rows = (L.S > 1 || kpos || R == 1) && (L.Cin & 3) == 0 && (((size_t)(L.S > 1 ? L.slab : L.out)) & 15) == 0;
     if (rows) {
-        constexpr int EL = TN + 4, VPT = TM * TN / 4 / cThreads;
+        // SPLIT tiles of 128 rows stage one 64-row half at a time (the waves of row half h): the staging tile then fits the
+        // split images' 52 KB and three workgroups share a CU
+        constexpr int HALVES = (SPLIT && TM == 128) ? 2 : 1, HM = TM / HALVES;
+        constexpr int EL = TN + 4, VPT = HM * TN / 4 / cThreads;
         float* Ct = smem;
-#pragma unroll
-        for (int sm = 0; sm < MTM; ++sm)
-#pragma unroll
-            for (int sn = 0; sn < MTN; ++sn) {
-                const int lci = wn * (TN / 2) + sn * 32 + (lane & 31);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int lco = wm * (TM / 2) + sm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    Ct[lco * EL + lci] = acc[sm][sn][r];
-                }
-            }
-        __syncthreads();
         const size_t row_len = (size_t)R * L.Cin;          // floats per output channel in the row-contiguous layouts
         gfloat* dst = L.S > 1 ? PLEAS_GLOBAL_W(L.slab) + (size_t)it.split * L.Cout * row_len : PLEAS_GLOBAL_W(L.out);
         const bool add = L.S == 1 && (L.flags & PLEAS_WGRAD_ACCUMULATE);
-        f32x4 old[VPT];
-        if (add) {
+#pragma unroll
+        for (int h = 0; h < HALVES; ++h) {
+            if (HALVES == 1 || wm == h) {
+#pragma unroll
+                for (int sm = 0; sm < MTM; ++sm)
+#pragma unroll
+                    for (int sn = 0; sn < MTN; ++sn) {
+                        const int lci = wn * (TN / 2) + sn * 32 + (lane & 31);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int lco = (HALVES == 1 ? wm * (TM / 2) : 0) + sm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                            Ct[lco * EL + lci] = acc[sm][sn][r];
+                        }
+                    }
+            }
+            __syncthreads();
+            const int r0 = i0 + h * HM;
+            f32x4 old[VPT];
+            if (add) {
+#pragma unroll
+                for (int q = 0; q < VPT; ++q) {
+                    const int v = tid + q * cThreads, lco = v / (TN / 4), lci = (v % (TN / 4)) * 4;
+                    const bool in = r0 + lco < L.Cout && j0 + lci < L.Cin;
+                    old[q] = *(const __attribute__((address_space(1))) f32x4*)(dst + (in ? (size_t)(r0 + lco) * row_len + (size_t)it.r * L.Cin + j0 + lci : 0));
+                }
+            }
 #pragma unroll
             for (int q = 0; q < VPT; ++q) {
                 const int v = tid + q * cThreads, lco = v / (TN / 4), lci = (v % (TN / 4)) * 4;
-                const bool in = i0 + lco < L.Cout && j0 + lci < L.Cin;
-                old[q] = *(const __attribute__((address_space(1))) f32x4*)(dst + (in ? (size_t)(i0 + lco) * row_len + (size_t)it.r * L.Cin + j0 + lci : 0));
+                if (r0 + lco < L.Cout && j0 + lci < L.Cin) {
+                    f32x4 val = *reinterpret_cast<const f32x4*>(Ct + lco * EL + lci);
+                    if (add) val += old[q];
+                    *(__attribute__((address_space(1))) f32x4*)(dst + (size_t)(r0 + lco) * row_len + (size_t)it.r * L.Cin + j0 + lci) = val;
+                }
             }
-        }
-#pragma unroll
-        for (int q = 0; q < VPT; ++q) {
-            const int v = tid + q * cThreads, lco = v / (TN / 4), lci = (v % (TN / 4)) * 4;
-            if (i0 + lco < L.Cout && j0 + lci < L.Cin) {
-                f32x4 val = *reinterpret_cast<const f32x4*>(Ct + lco * EL + lci);
-                if (add) val += old[q];
-                *(__attribute__((address_space(1))) f32x4*)(dst + (size_t)(i0 + lco) * row_len + (size_t)it.r * L.Cin + j0 + lci) = val;
-            }
+            if (h + 1 < HALVES) __syncthreads();      // the half is written out: its staging rows are free again
         }
         return;
     }
@@ -480,7 +490,7 @@ __global__ __launch_bounds__(cThreads, 2) void wgrad_batch_kernel(const WgradLay
 #endif
 }
 
-__global__ __launch_bounds__(cThreads, 2) void wgrad_batch_split_kernel(const WgradLayerDev* __restrict__ layers,
+__global__ __launch_bounds__(cThreads, 3) void wgrad_batch_split_kernel(const WgradLayerDev* __restrict__ layers,
                                                                      const WgradItemDev* __restrict__ items) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const WgradItemDev it = items[blockIdx.x];
@@ -710,8 +720,8 @@ static int build_wgrad_plan(WgradPlan& P, const pleas_wgrad_layer* ly, int n) {
         if (split) {
             d.variant |= 64;
             P.lds_split = std::max(P.lds_split, (size_t)(TM + TN) * kSplitRow * sizeof(__bf16));
-            // the epilogue stages [TM][TN + 4] floats in the same memory
-            P.lds_split = std::max(P.lds_split, (size_t)TM * (TN + 4) * sizeof(float));
+            // the epilogue stages [64][TN + 4] floats (one row half at a time for 128-row tiles) in the same memory
+            P.lds_split = std::max(P.lds_split, (size_t)64 * (TN + 4) * sizeof(float));
             P.flops_split += 2.0 * l.Cout * (double)Cin * R * (double)K;
         } else {
             P.lds = std::max(P.lds, (size_t)2 * (TM + TN) * cLds * sizeof(float));
@@ -750,6 +760,31 @@ static int build_wgrad_plan(WgradPlan& P, const pleas_wgrad_layer* ly, int n) {
     for (int i = 0; i < n; ++i) P.layers[i].slab = reinterpret_cast<float*>(slab_off[i]);
     P.uploaded = false;
     return PLEAS_OK;
+}
+
+// one side stream + two events per device for the exact grid of a launch under the split arithmetic (created once per process)
+struct WgradSideStream {
+    hipStream_t stream;
+    hipEvent_t forked, joined;
+    bool ok = false;
+};
+static WgradSideStream& wgrad_side_stream() {
+    constexpr int kMaxDev = 16;
+    static WgradSideStream sets[kMaxDev];
+    static bool tried[kMaxDev] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) {
+        static WgradSideStream none;
+        return none;
+    }
+    WgradSideStream& s = sets[dev];
+    if (!tried[dev]) {
+        tried[dev] = true;
+        s.ok = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess &&
+               hipEventCreateWithFlags(&s.forked, hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&s.joined, hipEventDisableTiming) == hipSuccess;
+    }
+    return s;
 }
 
 static std::vector<int64_t> wgrad_key(const pleas_wgrad_layer* ly, int n, const void* ws) {
@@ -849,14 +884,30 @@ extern "C" int pleas_wgrad_batch(const pleas_wgrad_layer* layers, int n_layers, 
     {
         ProfScope prof(kProfConvWgrad, P.flops, P.bytes, stream);
         const WgradItemDev* its = reinterpret_cast<const WgradItemDev*>(base + P.off_items);
+        const int n_exact = (int)P.items.size() - P.n_split;
+        // Under the split arithmetic the launch is TWO grids (split-bf16 tiles; exact tiles of the forms without a split variant:
+        // 7 x 7 images, strided layers, the stem -- few, long items).  Back to back on one stream the second would start when the
+        // first one's last workgroup has ended (0.39 ms for two layers alone, profiles/r05_pmc_split_3x3s1_14.txt): the exact grid
+        // goes to a side stream of the library instead (fork / join with events, as the forward's forms do).
+        WgradSideStream& side = wgrad_side_stream();
+        const bool fork = P.n_split > 0 && n_exact > 0 && side.ok;
+        hipStream_t st_exact = stream;
+        if (fork) {
+            PLEAS_HIP_CHECK(hipEventRecord(side.forked, stream));
+            PLEAS_HIP_CHECK(hipStreamWaitEvent(side.stream, side.forked, 0));
+            st_exact = side.stream;
+        }
+        if (n_exact > 0) {
+            hipLaunchKernelGGL(wgrad_batch_kernel, dim3((unsigned)n_exact), dim3(cThreads), P.lds, st_exact, dl, its + P.n_split);
+            PLEAS_LAUNCH_CHECK("wgrad_batch_kernel");
+        }
         if (P.n_split > 0) {
             hipLaunchKernelGGL(wgrad_batch_split_kernel, dim3((unsigned)P.n_split), dim3(cThreads), P.lds_split, stream, dl, its);
             PLEAS_LAUNCH_CHECK("wgrad_batch_split_kernel");
         }
-        if ((int)P.items.size() > P.n_split) {
-            hipLaunchKernelGGL(wgrad_batch_kernel, dim3((unsigned)(P.items.size() - P.n_split)), dim3(cThreads), P.lds, stream, dl,
-                               its + P.n_split);
-            PLEAS_LAUNCH_CHECK("wgrad_batch_kernel");
+        if (fork) {
+            PLEAS_HIP_CHECK(hipEventRecord(side.joined, side.stream));
+            PLEAS_HIP_CHECK(hipStreamWaitEvent(stream, side.joined, 0));
         }
         if (!P.blk_layer.empty()) {
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)P.blk_layer.size()), dim3(256), 0, stream, dl,

@@ -891,7 +891,7 @@ __device__ int g_fwd_timeline_n;
 // was built under pleas_arith(PLEAS_ARITH_SPLIT_BF16); every other form runs the exact arithmetic in the same launch group.
 constexpr bool fwd_form_splits(int form) { return form == 4 || form == 6 || form == 7 || form == 9; }
 template <int FORM, int SPLIT = 0>
-__global__ __launch_bounds__(fThreads, 2) void fwd_batch_kernel(const FwdLayerDev* __restrict__ layers,
+__global__ __launch_bounds__(fThreads, (SPLIT && FORM >= 7) ? 3 : 2) void fwd_batch_kernel(const FwdLayerDev* __restrict__ layers,
                                                              const FwdItemDev* __restrict__ items,
                                                              float* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -926,7 +926,7 @@ __global__ __launch_bounds__(fThreads, 2) void fwd_batch_kernel(const FwdLayerDe
 // A plain convolution (pleas_conv2d_fwd): ONE layer, described in the kernel arguments; the work item is the block index
 // (output-channel tile fastest, as in the grouped plan), no tables, no target, no loss.
 template <int FORM, int SPLIT = 0>
-__global__ __launch_bounds__(fThreads, 2) void conv2d_fwd_kernel(const FwdLayerDev L, const int tms) {
+__global__ __launch_bounds__(fThreads, (SPLIT && FORM >= 7) ? 3 : 2) void conv2d_fwd_kernel(const FwdLayerDev L, const int tms) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const FwdItemDev it{0, (int)(blockIdx.x % (unsigned)tms), (int)(blockIdx.x / (unsigned)tms), 0};
     if constexpr (FORM == 0) fwd_tile<128, 4>(L, it, smem, nullptr);

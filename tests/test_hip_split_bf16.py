@@ -77,3 +77,38 @@ def test_split_is_another_arithmetic_as_accurate_as_the_exact_one(ops):
     print("3x3 weight gradient, K = %d pixels: exact %.2e, split bf16 %.2e from fp64" % (N * H * H, e_exact, e_split))
     assert e_split < max(2 * e_exact, 5e-7), (e_split, e_exact)
     assert torch.equal(run(), exact)
+
+
+# ------------------------------------------------------------------------------------------ full size, on the switch
+@pytest.fixture(scope="module")
+def rn101():
+    import test_hip_fullsize as fs
+
+    return fs.Pair("resnet101")
+
+
+def test_rn101_matching_under_split_bf16_vs_oracle(rn101):
+    """ResNet-101, 71 groups, 344 tracked nodes: the drop-in call under the switch -- k x k twin convolutions and the matching
+    contraction on split bf16 -- against the oracle: costs within 1e-4, assignments identical up to near ties (the rule of
+    test_hip_fullsize._check_matching), and against the exact-arithmetic HIP call: costs to fp32 rounding."""
+    import test_hip_fullsize as fs
+    from pleas.methods.activation_matching import activation_matching
+
+    m1, m2 = rn101.gpu()
+    perm0, costs0 = activation_matching(rn101.spec, m1, m2, rn101.data, 2, output_costs=True)
+    with split_bf16():
+        perm, costs = activation_matching(rn101.spec, m1, m2, rn101.data, 2, output_costs=True)
+    fs._check_matching(rn101, perm, costs)
+    worst = max(fs._rel(costs[k], costs0[k]) for k in rn101.spec)
+    same = sum(1 for k in rn101.spec if torch.equal(perm[k], perm0[k]))
+    print("split vs exact arithmetic: worst group cost %.2e apart, %d / %d assignments identical" % (worst, same, len(perm)))
+    assert 0 < worst < 2e-5 and same >= len(perm) - 2
+
+
+def test_rn101_gradients_under_split_bf16_vs_fp64_on_identical_taps(rn101):
+    """One update of the HIP path under the switch (105 layers, K up to 6912, ratio 0.5) against fp64 autograd of the reference
+    objective on the SAME source activations (pleas_merging.py:281-287): the gate of the exact kernels."""
+    import test_hip_fullsize as fs
+
+    with split_bf16():
+        fs.test_rn101_gradients_vs_fp64_on_identical_taps(rn101)

@@ -64,19 +64,23 @@ def fp64_gate(costs_hip, costs_ref, costs64, got, want, variant, want64):
     return {"ok": bool(ok), "summary": summary, "costs": c, "tensors": t}
 
 
-def test_rn101_timed_configuration_vs_oracle():
-    from pleas.methods.activation_matching import activation_matching
-    from pleas.methods.partial_matching import partial_merge
+class _Ref:
+    """Everything the CPU side contributes, computed ONCE for the module: models, batches, the oracle's matching, merge, eight
+    updates (oneDNN on and off) and the fp64 anchor of the same sample."""
+
+
+@pytest.fixture(scope="module")
+def ref():
     from pleas_merging_amd import resnet as zoo
     from pleas_merging_amd.core.compiler import get_permutation_spec
-    from pleas_merging_amd.methods.pleas_merging import FrozenSources, PleasFitter
 
+    r = _Ref()
     threads = torch.get_num_threads()
     torch.set_num_threads(max(threads, min(16, _usable_cores())))
     try:
         # batch b = N(0, 1) seeded 1000 + b (SURVEY.md 8(d)); matching takes batches 0..9, PLeaS batches 0..7
-        data = [(torch.randn(BATCH, 3, 224, 224, generator=torch.Generator().manual_seed(1000 + b)), None)
-                for b in range(N_MATCH)]
+        r.data = [(torch.randn(BATCH, 3, 224, 224, generator=torch.Generator().manual_seed(1000 + b)), None)
+                  for b in range(N_MATCH)]
         models = []
         for seed in (0, 1):
             torch.manual_seed(seed)
@@ -84,60 +88,87 @@ def test_rn101_timed_configuration_vs_oracle():
             zoo.calibrate_bn(m, [torch.randn(BATCH, 3, 224, 224, generator=torch.Generator().manual_seed(900 + i))
                                  for i in range(2)])
             models.append(m.eval())
-        m1, m2 = models
-        spec = get_permutation_spec(m1, ((1, 3, 224, 224),))
-        g1, g2 = copy.deepcopy(m1).cuda(), copy.deepcopy(m2).cuda()
-        gdata = [(x.cuda(), None) for x, _ in data]
-        inputs = [x for x, _ in gdata[:N_UPDATES]]
-
-        # ---- HIP path, as bench.run_job drives it
-        early = {}
-
-        def while_solving():
-            early["sources"] = src = FrozenSources(g1, g2)
-            early["taken"] = src.prefetch(inputs, group=8, max_groups=2, memory_fraction=0.7)
-
-        perm, costs = activation_matching(spec, g1, g2, gdata, N_MATCH, output_costs=True, while_solving=while_solving,
-                                          batches_per_forward=10)
-        assert early["taken"] == 8, early["taken"]         # one 128-sample group was forwarded beside the LAP kernel
-
-        # ---- oracle: matching on the same ten batches
-        w = _Want()
-        w.spec = spec
-        w.want_perm, w.want_costs = orc.activation_matching(spec, m1, m2, data, N_MATCH, accumulate=True)
-        flips = fs._check_matching(w, perm, costs)
-        worst_cost = max(fs._rel(costs[k], w.want_costs[k]) for k in spec)
-        print("timed configuration, matching: worst group cost rel-fro %.2e, flipped groups %r" % (worst_cost, flips))
-
-        # ---- merge + 8 updates from the ORACLE's assignment (both sides merge the same blocks); the prefetched sources
-        # do not depend on it
-        gcosts = {k: v.cuda() for k, v in w.want_costs.items()}
-        m3 = partial_merge(spec, g1, g2, w.want_perm, gcosts, 0.0, device=torch.device("cuda"))
-        o3 = orc.partial_merge(spec, m1, m2, w.want_perm, w.want_costs, 0.0)
-        merged = {k: v.clone() for k, v in o3.state_dict().items()}
-        for k, v in m3.state_dict().items():
-            if v.dtype.is_floating_point:
-                assert torch.equal(v.cpu(), merged[k]), k
-        fit = PleasFitter(g1, g2, m3, spec, w.want_perm, gcosts, 0.0, T_MAX, sources=early["sources"])
-        n = 0
-        for _ in fit.steps(inputs, sources_per_forward=8):
-            n += 1
-        assert n == N_UPDATES and fit.fast_updates == N_UPDATES - 1
-        got = {k: v.cpu() for k, v in fit.finish().state_dict().items()}
-
-        o3, losses = orc.train(data[:N_UPDATES], m1, m2, o3, spec, w.want_perm, w.want_costs, 0.0, T_MAX)
+        r.m1, r.m2 = models
+        r.spec = get_permutation_spec(r.m1, ((1, 3, 224, 224),))
+        # ---- oracle: matching on the same ten batches, merge + 8 updates from its assignment
+        r.w = _Want()
+        r.w.spec = r.spec
+        r.w.want_perm, r.w.want_costs = orc.activation_matching(r.spec, r.m1, r.m2, r.data, N_MATCH, accumulate=True)
+        o3 = orc.partial_merge(r.spec, r.m1, r.m2, r.w.want_perm, r.w.want_costs, 0.0)
+        r.merged = {k: v.clone() for k, v in o3.state_dict().items()}
+        o3, losses = orc.train(r.data[:N_UPDATES], r.m1, r.m2, o3, r.spec, r.w.want_perm, r.w.want_costs, 0.0, T_MAX)
         assert len(losses) == N_UPDATES
-        want = {k: v.clone() for k, v in o3.state_dict().items()}
+        r.want = {k: v.clone() for k, v in o3.state_dict().items()}
         with torch.backends.mkldnn.flags(enabled=False):      # the oracle against itself: the yardstick at this depth
-            v3 = orc.partial_merge(spec, m1, m2, w.want_perm, w.want_costs, 0.0)
-            v3, _ = orc.train(data[:N_UPDATES], m1, m2, v3, spec, w.want_perm, w.want_costs, 0.0, T_MAX)
-        variant = v3.state_dict()
+            v3 = orc.partial_merge(r.spec, r.m1, r.m2, r.w.want_perm, r.w.want_costs, 0.0)
+            v3, _ = orc.train(r.data[:N_UPDATES], r.m1, r.m2, v3, r.spec, r.w.want_perm, r.w.want_costs, 0.0, T_MAX)
+        r.variant = v3.state_dict()
         # the fp64 ANCHOR: the same ten batches / eight updates in fp64 (oracle/pleas_oracle.fp64_anchor).  Distances to it are
         # statements about accuracy -- the oneDNN on / off yardstick above is ONE draw of the spread between two fp32 runs.
-        costs64, want64 = orc.fp64_anchor(spec, m1, m2, data, N_MATCH, N_UPDATES, w.want_perm, w.want_costs, 0.0, T_MAX)
+        r.costs64, r.want64 = orc.fp64_anchor(r.spec, r.m1, r.m2, r.data, N_MATCH, N_UPDATES, r.w.want_perm, r.w.want_costs, 0.0,
+                                              T_MAX)
     finally:
         torch.set_num_threads(threads)
+    return r
 
+
+def test_rn101_timed_configuration_vs_oracle(ref):
+    _hip_job_vs_reference(ref, "r05_timed_config")
+
+
+def test_rn101_timed_configuration_split_bf16_vs_oracle(ref):
+    """The same job under ``pleas_arith(PLEAS_ARITH_SPLIT_BF16)`` (matching contraction, k x k source convolutions, forward and
+    weight gradient of the updates on bf16 MFMA with exactly split operands) against the SAME oracle results and the SAME gates,
+    fp64 anchor included."""
+    from pleas_merging_amd import _lib
+
+    lib = _lib.lib()
+    assert lib.pleas_arith_get() == 0
+    lib.pleas_arith(1)
+    try:
+        _hip_job_vs_reference(ref, "r05_timed_config_split_bf16")
+    finally:
+        lib.pleas_arith(0)
+
+
+def _hip_job_vs_reference(ref, tag):
+    from pleas.methods.activation_matching import activation_matching
+    from pleas.methods.partial_matching import partial_merge
+    from pleas_merging_amd.methods.pleas_merging import FrozenSources, PleasFitter
+
+    m1, m2, spec, data, w = ref.m1, ref.m2, ref.spec, ref.data, ref.w
+    merged, want, variant, costs64, want64 = ref.merged, ref.want, ref.variant, ref.costs64, ref.want64
+    g1, g2 = copy.deepcopy(m1).cuda(), copy.deepcopy(m2).cuda()
+    gdata = [(x.cuda(), None) for x, _ in data]
+    inputs = [x for x, _ in gdata[:N_UPDATES]]
+
+    # ---- HIP path, as bench.run_job drives it
+    early = {}
+
+    def while_solving():
+        early["sources"] = src = FrozenSources(g1, g2)
+        early["taken"] = src.prefetch(inputs, group=8, max_groups=2, memory_fraction=0.7)
+
+    perm, costs = activation_matching(spec, g1, g2, gdata, N_MATCH, output_costs=True, while_solving=while_solving,
+                                      batches_per_forward=10)
+    assert early["taken"] == 8, early["taken"]         # one 128-sample group was forwarded beside the LAP kernel
+    flips = fs._check_matching(w, perm, costs)
+    worst_cost = max(fs._rel(costs[k], w.want_costs[k]) for k in spec)
+    print("timed configuration (%s), matching: worst group cost rel-fro %.2e, flipped groups %r" % (tag, worst_cost, flips))
+
+    # ---- merge + 8 updates from the ORACLE's assignment (both sides merge the same blocks); the prefetched sources
+    # do not depend on it
+    gcosts = {k: v.cuda() for k, v in w.want_costs.items()}
+    m3 = partial_merge(spec, g1, g2, w.want_perm, gcosts, 0.0, device=torch.device("cuda"))
+    for k, v in m3.state_dict().items():
+        if v.dtype.is_floating_point:
+            assert torch.equal(v.cpu(), merged[k]), k
+    fit = PleasFitter(g1, g2, m3, spec, w.want_perm, gcosts, 0.0, T_MAX, sources=early["sources"])
+    n = 0
+    for _ in fit.steps(inputs, sources_per_forward=8):
+        n += 1
+    assert n == N_UPDATES and fit.fast_updates == N_UPDATES - 1
+    got = {k: v.cpu() for k, v in fit.finish().state_dict().items()}
     # ---- the gate.  A tensor's yardstick is ONE draw of "two correct implementations apart" (the oracle with oneDNN
     # convolutions on / off), and so is the HIP path's distance.  Measured on the MI355X (profiles/r04_timed_config_parity*.json):
     # with the vendor's WINOGRAD 3 x 3 kernels in the 128-sample source forwards, one tensor of 105 (layer3.8.conv2.weight) sat
@@ -176,10 +207,10 @@ def test_rn101_timed_configuration_vs_oracle():
                "worst_rest_rel_fro": max(v[3] for v in rows.values()),
                "oracle_worst_rest_rel_fro": max(v[5] for v in rows.values()),
                "source_conv": __import__("pleas_merging_amd.methods.source_forward", fromlist=["x"]).SOURCE_CONV}
-    print("timed configuration, %d updates: %s" % (N_UPDATES, json.dumps(summary, indent=1)))
+    print("timed configuration (%s), %d updates: %s" % (tag, N_UPDATES, json.dumps(summary, indent=1)))
     out_dir = os.path.join(REPO, "gpurun_out")
     if os.path.isdir(out_dir):
-        with open(os.path.join(out_dir, "r04_timed_config_parity.json"), "w") as f:
+        with open(os.path.join(out_dir, tag + "_parity.json"), "w") as f:
             json.dump(summary, f, indent=1)
     assert len(over) <= max(2, len(rows) // 50), over      # 0 observed here, 0-2 in bench.py's lines; a wrong kernel moves dozens
     assert all(r <= max(fs.TOL, 3 * yard_max) for r, _ in over.values()), (over, yard_max)
@@ -192,8 +223,8 @@ def test_rn101_timed_configuration_vs_oracle():
     # ---- against the fp64 anchor: the HIP path must be as ACCURATE as the reference's fp32 arithmetic is
     anchor = fp64_gate({k: costs[k] for k in spec}, {k: w.want_costs[k] for k in spec}, costs64,
                        {k: got[k] for k in rows}, {k: want[k] for k in rows}, {k: variant[k] for k in rows}, want64)
-    print("timed configuration vs the fp64 anchor: %s" % json.dumps(anchor["summary"], indent=1))
+    print("timed configuration (%s) vs the fp64 anchor: %s" % (tag, json.dumps(anchor["summary"], indent=1)))
     if os.path.isdir(out_dir):
-        with open(os.path.join(out_dir, "r05_timed_config_fp64_anchor.json"), "w") as f:
+        with open(os.path.join(out_dir, tag + "_fp64_anchor.json"), "w") as f:
             json.dump(anchor, f, indent=1)
     assert anchor["ok"], anchor["summary"]

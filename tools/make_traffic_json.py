@@ -23,7 +23,8 @@ KERNELS = {   # tag in the PMC file names -> (output file, kernels of one launch
     "gram": ("gram_traffic.json", ("gram_batch_kernel",), ("pleas_merging_amd/csrc/gram.hip", "pleas_merging_amd/csrc/common.hpp"),
              5132100000.0, "one ResNet-101 matching batch as bench.py runs it: 240 nodes contracted, 104 BatchNorm nodes derived (gram_batch_rn101.hip, rn101_nodes_derived.txt)"),
     "neq": ("neq_traffic.json", ("neq_batch_kernel",), ("pleas_merging_amd/csrc/normal_eq.hip", "pleas_merging_amd/csrc/common.hpp"),
-            None, "one ResNet-101 closed-form batch: A += U^T U of 104 layers, batch 16 (neq_batch_rn101.hip)"),
+            1936100000.0, "one ResNet-101 closed-form batch: A += U^T U of 104 layers, batch 16 (neq_batch_rn101.hip); algorithmic bytes = the "
+            "merged inputs once (1.000 GB) + one read-modify-write of every A's lower triangle (sum K (K + 1) / 2 x 8 B = 0.936 GB)"),
 }
 LINE = re.compile(r"^(\S.*?)\s+(FETCH_SIZE|WRITE_SIZE)\s+n=\s*(\d+)\s+mean=(\S+)\s+sum=(\S+)")
 
@@ -56,7 +57,7 @@ def main():
             print("skip", key, "(kernel not found in the summary)")
             continue
         blob = {"kernel": " + ".join("pleas::" + k for k in kernels), "round": int(rnd[1:]), "tag": tag, "commit": commit, "what": what,
-                "command": "tools/" + ("run_final_profile_r03.sh" if rnd == "r03" else rnd + "/final_profile.sh") + " %s (standalone replay; rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in "
+                "command": "tools/" + rnd + "/final_profile.sh" + " %s (standalone replay; rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in "
                            "separate passes, mean per dispatch, summed over the launch's kernels)" % tag,
                 "fetch_size_kb_raw": fetch, "write_size_kb_raw": write, "fetch_size_kb_raw_per_kernel": per_f,
                 "write_size_kb_raw_per_kernel": per_w,
