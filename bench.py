@@ -1073,6 +1073,13 @@ def main():
                     "algorithmic_flop_per_launch": round(rec[2] / max(rec[0], 1)), "total_ms": round(rec[1], 2)}
 
         roofs = {k: roof(k) for k in labels}
+        # the plain convolution (k x k layers of the frozen sources / twin forwards): listed, never the dominant kernel -- the two
+        # source models' launches run pairwise on two streams, so a launch's HIP-event time includes its sibling's share of the
+        # chip (by rocprofv3 kernel time: fwd_batch_kernel 30.7 %, conv2d_fwd_kernel 18.1 %, profiles/r05_a_bench_kernel_stats.csv)
+        labels["conv2d"] = "conv2d_fwd_kernel (fp32 MFMA 32x32x2 plain convolution: the k x k layers of the frozen source / twin forwards)"
+        conv2d_roof = roof("conv2d")
+        conv2d_roof["note"] = ("the two source models' launches share the chip pairwise (two streams): event times include the "
+                               "sibling's share; alone at 128 samples the 3 x 3 layers run at 89-94 TFLOP/s (profiles/r05_probe_conv_classes_128.txt)")
         # `achieved` counts the flops the contraction kernel EXECUTES.  The path's algorithmic work per matching batch
         # (6.368e10 flop per sample for ResNet-101, every tracked node contracted) is larger: the 104
         # tracked BatchNorm nodes are derived from their convolution node in the reduce pass, not contracted.
@@ -1106,9 +1113,11 @@ def main():
                 roofs[key]["traffic_source"] = "profiles/" + fname
                 if roofs[key]["traffic"] and roofs[key]["avg_launch_us"]:    # north_star: rocprof HBM GB/s of the accumulation
                     roofs[key]["hbm_gbps"] = round(roofs[key]["traffic"] / (roofs[key]["avg_launch_us"] * 1e-6) / 1e9, 1)
-        dominant = max(roofs, key=lambda k: roofs[k]["total_ms"])   # own kernel with the most time in the timed region
+        dominant = max(roofs, key=lambda k: roofs[k]["total_ms"])   # own grouped launch with the most time in the timed region
         roofline = roofs[dominant]
         other = {k: v for k, v in roofs.items() if k != dominant}
+        if conv2d_roof["launches"]:
+            other["conv2d"] = conv2d_roof
         srt = sorted(per_job)
         out = {
             "metric": "wall-clock (s): ResNet-101 pair, 100-batch act-match + 400-step PLeaS, 1/8 GPU"

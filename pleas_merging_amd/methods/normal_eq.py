@@ -32,6 +32,9 @@ class NormalEqFitter(PleasFitter):
 
     def __init__(self, *args, ridge: float = 1e-6, shard_solve: bool = True, **kwargs):
         super().__init__(*args, **kwargs)
+        if self.vendor_layers:      # the Adam-faithful fitter fits such layers on the vendor's operators; the closed form does not
+            raise NotImplementedError("solver='normal_eq' takes dense, undilated Conv2d layers with a square kernel / stride / "
+                                      "padding; not supported: %s (solver='adam' fits them)" % ", ".join(self.vendor_layers))
         self.ridge = ridge
         # data parallel: rank r factorises only ITS layers (dealt by K^3, largest first) and the solved parameter arena is
         # summed once over the ranks (the others' layers are zero there): the solve shrinks with the ranks instead of being

@@ -203,7 +203,7 @@ def cosine_lrs(base_lr: float, t_max: int, n: int) -> List[float]:
 # ------------------------------------------------------------------------------------------ per-layer plan
 class _LayerPlan:
     __slots__ = ("name", "mod", "is_conv", "w", "b", "gw", "gb", "gw2", "gb2", "in_maps", "out_maps", "halves", "w_shape",
-                 "off_w", "kpos")
+                 "off_w", "kpos", "vendor")
 
 
 def _identity_block(n: int):
@@ -543,12 +543,11 @@ class PleasFitter:
 
         layers = {n: m for n, m in model3.named_modules() if isinstance(m, (nn.Conv2d, nn.Linear))}
         # The grouped HIP kernels take dense, undilated Conv2d layers with a square kernel / stride / padding (and Linear
-        # layers on 2-D inputs); there is no vendor fallback for other geometries.  Said HERE, with the whole list, instead
-        # of at the first update ("Layer geometries").
-        odd = [n for n, m in layers.items() if isinstance(m, nn.Conv2d) and not _square_conv(m)]
-        if odd:
-            raise NotImplementedError("pleas_merging.train: the grouped HIP kernels take dense, undilated Conv2d layers with a "
-                                      "square kernel / stride / padding; not supported: %s" % ", ".join(odd))
+        # layers on 2-D inputs) -- every layer of the ResNets the reference loads.  Any other geometry (rectangular, dilated or
+        # grouped Conv2d; Linear on inputs with more than two axes) is fitted the way the reference fits EVERY layer
+        # (`layer(ip)` under autograd, pleas_merging.py:281-287) on the vendor's operators, layer by layer (_fit_layer_vendor);
+        # an update that contains such a layer takes the layer-by-layer path every time ("Layer geometries").
+        self.vendor_layers = [n for n, m in layers.items() if isinstance(m, nn.Conv2d) and not _square_conv(m)]
         self.layer_modules = layers
         pad4 = lambda n: (n + 3) // 4 * 4   # every tensor starts 16-byte aligned inside the arenas (vector loads)
         total = sum(pad4(p.numel()) for m in layers.values() for p in m.parameters())
@@ -582,6 +581,7 @@ class PleasFitter:
         for name, mod in layers.items():
             plan = _LayerPlan()
             plan.name, plan.mod, plan.is_conv = name, mod, isinstance(mod, nn.Conv2d)
+            plan.vendor = name in self.vendor_layers
             plan.b = plan.gb = plan.gw2 = plan.gb2 = None
             # k x k convolutions with Cin % 32 == 0 keep their weight (gradient, mask, Adam state) KERNEL-POSITION-MAJOR
             # [Cout][KH][KW][Cin] in the arenas: the fused forward then has one tap per K chunk, the weight-gradient
@@ -666,8 +666,8 @@ class PleasFitter:
         square = plan.is_conv and _square_conv(mod)
         linear = (not plan.is_conv) and ip1.dim() == 2
         if not (square or linear):
-            raise NotImplementedError("layer %s: the grouped HIP kernels take dense, undilated Conv2d layers with a square "
-                                      "kernel / stride / padding and Linear layers on 2-D inputs" % name)
+            self._fit_layer_vendor(idx, plan)
+            return
         geo = (tuple(mod.kernel_size), mod.stride[0], mod.padding[0]) if plan.is_conv else ((1, 1), 1, 0)
         # a 1x1 convolution with a stride reads every s-th pixel of every s-th line: the grouped merge writes exactly those, and
         # the layer is a dense 1x1 stride-1 layer for the forward and the weight gradient (16-byte loads along the pixel axis
@@ -697,6 +697,38 @@ class PleasFitter:
             self.wgrad.add(resid, ip, gw, *geo, flags=ops.WgradBatch.KPOS_MAJOR if plan.kpos else 0)
             if gb is not None:
                 self._bias_grads.append((resid, plan, gb))
+
+    def _fit_layer_vendor(self, idx: int, plan: _LayerPlan) -> None:
+        """A layer the grouped kernels do not take, fitted as the reference fits every layer (pleas_merging.py:116-147, :281-287):
+        merged input and target by ``pleas_merge_blocks``, then ``layer(ip)``, the MSE and its gradients on the vendor's operators
+        under autograd.  Gradients land in the same arena (mask and Adam are shared with all other layers); the loss joins
+        ``loss_now`` after the grouped forward's."""
+        import torch.nn.functional as F
+
+        ops, name, mod = self.ops, plan.name, plan.mod
+        ip1, ip2 = self.t1_in[name], self.t2_in[name]
+        o1, o2 = self.t1_out[name], self.t2_out[name]
+        halves = len(plan.halves)
+        for h, (in_maps, out_maps) in enumerate(plan.halves):
+            axis = 1 if plan.is_conv else ip1.dim() - 1      # channels: axis 1 of a feature map, the last axis of a Linear input
+            ip = ops.merge_blocks(ip1, ip2, axis, *in_maps)
+            op = ops.merge_blocks(o1, o2, axis, *out_maps)
+            with torch.enable_grad():
+                w = plan.w.detach().requires_grad_(True)
+                b = plan.b.detach().requires_grad_(True) if plan.b is not None else None
+                if plan.is_conv:
+                    out = F.conv2d(ip, w, b, mod.stride, mod.padding, mod.dilation, mod.groups)
+                else:
+                    out = F.linear(ip, w, b)
+                n = out.numel() * halves * self.world      # the mean runs over the full (global, stacked) batch
+                loss = ((out - op) ** 2).sum() / n
+                grads = torch.autograd.grad(loss, [w] + ([b] if b is not None else []))
+            gw, gb = (plan.gw, plan.gb) if h == 0 else (plan.gw2, plan.gb2)
+            gw.copy_(grads[0])
+            if b is not None:
+                gb.copy_(grads[1])
+            self._vendor_losses.append((idx, loss.detach()))
+        self._complete = False      # no table to replay: the next update goes layer by layer again
 
     def _bias_gradients(self) -> None:
         for resid, plan, gb in self._bias_grads:      # HIP: one deterministic row-sum launch per biased layer
@@ -851,6 +883,7 @@ class PleasFitter:
             self._replay = None
             self._bufs = self._buffers.setdefault(key, {}) if key else {}
             self._fwd_rows, self._bias_grads = [], []
+            self._vendor_losses, self._complete = [], True
             complete = bool(key)
             with self.ops.pin_stream():
                 for idx, plan in enumerate(self.plans):
@@ -859,6 +892,7 @@ class PleasFitter:
                         complete = False
                         continue
                     self._fit_layer(idx, plan)
+            complete = complete and self._complete
             self.merge.flush()   # ONE grouped launch: the merged inputs of every layer
             if self._fwd_rows:   # ONE grouped MFMA launch: forward + target + residual + loss of every merged layer
                 if self._fwd_loss is None or self._fwd_loss.numel() != len(self._fwd_rows):
@@ -871,6 +905,16 @@ class PleasFitter:
                 self.loss_now.index_add_(0, self._fwd_index, self._fwd_loss)
             else:
                 self.loss_now.index_copy_(0, self._fwd_index, self._fwd_loss)
+        if replay is None and self._vendor_losses:      # layers fitted on the vendor's operators (_fit_layer_vendor)
+            if not self._fwd_rows:
+                self.loss_now.zero_()
+            seen = set()
+            for idx, loss in self._vendor_losses:
+                if idx in seen:
+                    self.loss_now[idx] += loss
+                else:
+                    self.loss_now[idx] = loss
+                    seen.add(idx)
         self._bias_gradients()
         if replay is not None:
             with self.ops.pin_stream():

@@ -38,7 +38,7 @@ def pytest_configure(config):
 # reference-generated pipeline fixtures, the full-size oracle comparisons, and the multi-process REHEARSALS (which compare
 # the HIP path with itself) last -- a flake in a rehearsal must never hide an oracle or golden test again (GPUTEST_r04).
 GPU_FILE_ORDER = ("test_hip_kernels", "test_hip_pipeline", "test_hip_fullsize", "test_hip_timed_config",
-                  "test_hip_long_horizon", "test_hip_extras", "test_hip_determinism", "test_hip_split_bf16",
+                  "test_hip_long_horizon", "test_hip_extras", "test_hip_odd_layers", "test_hip_determinism", "test_hip_split_bf16",
                   "test_hip_distributed", "test_hip_fullsize_dp")
 
 

@@ -1,0 +1,113 @@
+"""Layers outside the ResNet geometries (missing 4): the reference trains ANY Conv2d / Linear through ``layer(ip)``
+(pleas/methods/pleas_merging.py:281); the grouped HIP kernels take dense, undilated Conv2d layers with a square kernel / stride /
+padding.  A model with a rectangular and a dilated convolution goes through the drop-in calls: those two layers are fitted on the
+vendor's operators (``PleasFitter._fit_layer_vendor``), the others by the grouped launches in the same update, against the oracle."""
+import copy
+
+import pytest
+import torch
+from torch import nn
+
+from oracle import pleas_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+class OddNet(nn.Module):
+    def __init__(self, classes=10):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 8, (1, 3), padding=(0, 1), bias=False)       # rectangular kernel / padding
+        self.bn1 = nn.BatchNorm2d(8)
+        self.relu1 = nn.ReLU()
+        self.conv2 = nn.Conv2d(8, 12, 3, padding=2, dilation=2, bias=True)     # dilated, with a bias
+        self.bn2 = nn.BatchNorm2d(12)
+        self.relu2 = nn.ReLU()
+        self.conv3 = nn.Conv2d(12, 16, 1, bias=False)                          # a layer the grouped kernels take
+        self.relu3 = nn.ReLU()
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(16, classes)
+
+    def forward(self, x):
+        x = self.relu1(self.bn1(self.conv1(x)))
+        x = self.relu2(self.bn2(self.conv2(x)))
+        x = self.relu3(self.conv3(x))
+        return self.fc(torch.flatten(self.avgpool(x), 1))
+
+
+def _rel(a, b):
+    return float((a.double().cpu() - b.double().cpu()).norm() / (b.double().cpu().norm() + 1e-30))
+
+
+@pytest.mark.parametrize("ratio", [0.0, 0.5])
+def test_rectangular_and_dilated_layers_vs_oracle(ratio):
+    from pleas.core.compiler import get_permutation_spec
+    from pleas.methods.activation_matching import activation_matching
+    from pleas.methods.partial_matching import partial_merge
+    from pleas.methods.pleas_merging import PleasFitter, train
+
+    g = torch.Generator().manual_seed(3)
+    data = [(torch.randn(4, 3, 12, 14, generator=g), torch.zeros(4, dtype=torch.long)) for _ in range(7)]
+    models = []
+    for seed in (0, 1):
+        torch.manual_seed(seed)
+        m = OddNet()
+        m.train()
+        with torch.no_grad():
+            for x, _ in data[:3]:
+                m(x)                      # BatchNorm statistics that mean something
+        models.append(m.eval())
+    m1, m2 = models
+    spec = get_permutation_spec(m1, ((2, 3, 12, 14),))
+    assert len(spec) == 3, list(spec)
+    want_perm, want_costs = orc.activation_matching(spec, m1, m2, data, 3, accumulate=True)
+    g1, g2 = copy.deepcopy(m1).cuda(), copy.deepcopy(m2).cuda()
+    perm, costs = activation_matching(spec, g1, g2, data, 3, output_costs=True)
+    for k in spec:
+        assert _rel(costs[k], want_costs[k]) < 1e-4, k
+        assert torch.equal(perm[k], want_perm[k]), k
+    o3 = orc.partial_merge(spec, m1, m2, want_perm, want_costs, ratio)
+    merged = {k: v.clone() for k, v in o3.state_dict().items()}
+    o3, losses = orc.train(data, m1, m2, o3, spec, want_perm, want_costs, ratio, 5, num_classes=10)
+    want = o3.state_dict()
+
+    m3 = partial_merge(spec, g1, g2, perm, costs, ratio)
+    for k, v in m3.state_dict().items():
+        if v.dtype.is_floating_point:
+            assert torch.equal(v.cpu(), merged[k]), k
+    fit = PleasFitter(g1, g2, copy.deepcopy(m3), spec, perm, costs, ratio, 5, num_classes=10)
+    assert fit.vendor_layers == ["conv1", "conv2"]
+    n = sum(1 for _ in fit.steps([x for x, _ in data[:6]]))
+    assert n == 6 and fit.fast_updates == 0          # an update with such a layer goes layer by layer every time
+    got = {k: v.cpu() for k, v in fit.finish().state_dict().items()}
+    worst = 0.0
+    for k in want:
+        if k == "conv1.weight":
+            continue          # the first layer sees the SAME input in both models: its residual is rounding noise
+        if want[k].dtype.is_floating_point and not torch.equal(want[k], merged[k]):
+            worst = max(worst, _rel(got[k], want[k]))
+            assert _rel(got[k], want[k]) < 1e-4, (k, _rel(got[k], want[k]))
+    from stem_gate import gate_stem
+
+    gate_stem(got["conv1.weight"], merged["conv1.weight"], [want["conv1.weight"]], what="rectangular first layer, ratio %.1f" % ratio)
+    print("ratio %.1f: worst trained tensor %.2e rel-fro from the oracle; the oracle's losses %s" % (ratio, worst, [round(v, 4) for v in losses[:2]]))
+    # the drop-in call itself
+    m3b = train(data, g1, g2, copy.deepcopy(m3), spec, perm, costs, ratio, False, 5, None, num_classes=10)
+    for k, v in m3b.state_dict().items():
+        assert torch.equal(v.cpu(), got[k]), k     # and the job repeats itself bit for bit
+
+
+def test_closed_form_refuses_such_layers():
+    from pleas.core.compiler import get_permutation_spec
+    from pleas.methods.pleas_merging import train
+
+    torch.manual_seed(0)
+    m1, m2 = OddNet().eval().cuda(), OddNet().eval().cuda()
+    spec = get_permutation_spec(m1, ((2, 3, 12, 14),))
+    perm = {k: torch.arange(g.size) for k, g in spec.items()}
+    costs = {k: torch.eye(g.size, device="cuda") for k, g in spec.items()}
+    from pleas.methods.partial_matching import partial_merge
+
+    m3 = partial_merge(spec, m1, m2, perm, costs, 0.0)
+    with pytest.raises(NotImplementedError):
+        train([(torch.randn(2, 3, 12, 14), None)], m1, m2, m3, spec, perm, costs, 0.0, False, 1, None, num_classes=10,
+              solver="normal_eq")
