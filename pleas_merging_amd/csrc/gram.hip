@@ -28,6 +28,7 @@ namespace pleas {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef f32x4 f32x4u __attribute__((aligned(4)));   // 16 bytes at a 4-byte-aligned address: still ONE global_load_dwordx4
 
 constexpr int kBK = 32;      // K chunk (floats) staged per step
 constexpr int kLds = 36;     // padded LDS row stride: 16-B aligned rows, conflict-free ds_read_b128
@@ -46,6 +47,11 @@ struct GramGeom {
     int nchunks;
     int chunks_per_split;
     int tiles;  // tiles per matrix side
+    // PAD form (images with HW % 4 != 0, e.g. the 7 x 7 maps of a ResNet's last stage): the K axis is (sample, pixel padded to
+    // a multiple of four) -- a thread's four k never straddle two samples, both operands come through under-aligned 16-byte
+    // loads instead of four 4-byte loads, and the padding pixels are stored as zeros
+    uint32_t HWp, Kk;   // padded pixels per sample, B * HWp  (== HW, Ktot outside the PAD form)
+    uint32_t bytes;     // 4 * B * C * HW: clamps the PAD form's last run
 };
 
 // One operand tile in flight between global memory and LDS.
@@ -74,9 +80,10 @@ __device__ __forceinline__ void split3(const float (&v)[4], u32x2_t (&h)[3]) {  
 }
 
 // One workgroup's share: output tile (tm, tn) over K chunks [c_begin, c_end) -> slab `split`.
-template <int TILE, int VEC, int SPLIT = 0>
+template <int TILE, int VEC, int SPLIT = 0, int PAD = 0>
 __device__ __forceinline__ void gram_tile(const GramGeom& g, float* smem, const int tm, const int tn, const int split,
                                           const int c_begin, const int c_end) {
+    static_assert(!PAD || (VEC == 4 && !SPLIT), "the padded form: 16-byte loads, exact arithmetic");
     constexpr int MT = TILE / 64;                    // 32x32 MFMA tiles per wave per side
     constexpr int LANES_PER_ROW = kBK / VEC;         // 8 (16-B loads) or 32 (4-B loads)
     constexpr int ROWS_PER_PASS = kThreads / LANES_PER_ROW;
@@ -137,21 +144,48 @@ __device__ __forceinline__ void gram_tile(const GramGeom& g, float* smem, const 
     const bool interior = i0 + TILE <= g.C && j0 + TILE <= g.C;       // every row of both operand tiles exists
     // (sample, pixel) of this thread's k in the chunk being loaded: ONE division per work item, then steps of kBK
     // (chunks are loaded in order); images smaller than a chunk keep the division
+    const uint32_t HWk = PAD ? g.HWp : g.HW, Kk = PAD ? g.Kk : g.Ktot;      // pixels per sample / length of the K axis
     uint32_t lk = (uint32_t)c_begin * kBK + scol;
-    uint32_t ln = lk / g.HW, lp = lk - ln * g.HW;
+    uint32_t ln = lk / HWk, lp = lk - ln * HWk;
+    unsigned pmask = 0xFu;                                                    // PAD: which of the thread's four pixels exist
     const char* xb = reinterpret_cast<const char*>(g.x);
     const char* yb = reinterpret_cast<const char*>(g.y);
     auto load_chunk = [&](int c) {
         const uint32_t k = lk;
-        const bool kin = k < g.Ktot;
-        staged_full = (uint32_t)(c + 1) * kBK <= g.Ktot;
+        const bool kin = k < Kk;
+        staged_full = !PAD && (uint32_t)(c + 1) * kBK <= Kk;
         const uint32_t n = kin ? ln : 0u;
         const uint32_t p = kin ? lp : 0u;
         const uint32_t base = 4u * (n * (uint32_t)g.C * g.HW + p);
         staged_kin = kin;
+        if constexpr (PAD) {
+            pmask = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pmask |= (p + e < g.HW ? 1u : 0u) << e;
+        }
 #pragma unroll
         for (int q = 0; q < PASSES; ++q) {
-            if constexpr (VEC == 4) {
+            if constexpr (PAD) {
+                // rows start at 4-byte-aligned addresses only: one under-aligned 16-byte load per operand; the run that would
+                // read past the tensor's last float goes element by element, clamped (its extra elements are masked)
+                const uint32_t oa = base + row_off_a[q], ob = base + row_off_b[q];
+                if (oa + 16u <= g.bytes) {
+                    const f32x4 va = *(const __attribute__((address_space(1))) f32x4u*)(xb + oa);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ra.v[q][e] = va[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ra.v[q][e] = *(const __attribute__((address_space(1))) float*)(xb + min(oa + 4u * e, g.bytes - 4u));
+                }
+                if (ob + 16u <= g.bytes) {
+                    const f32x4 vb = *(const __attribute__((address_space(1))) f32x4u*)(yb + ob);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rb.v[q][e] = vb[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rb.v[q][e] = *(const __attribute__((address_space(1))) float*)(yb + min(ob + 4u * e, g.bytes - 4u));
+                }
+            } else if constexpr (VEC == 4) {
                 const f32x4 va = *(const __attribute__((address_space(1))) f32x4*)(xb + (base + row_off_a[q]));
                 const f32x4 vb = *(const __attribute__((address_space(1))) f32x4*)(yb + (base + row_off_b[q]));
 #pragma unroll
@@ -166,15 +200,15 @@ __device__ __forceinline__ void gram_tile(const GramGeom& g, float* smem, const 
         }
         // next chunk
         lk += kBK;
-        if (g.HW >= (uint32_t)kBK) {
+        if (HWk >= (uint32_t)kBK) {
             lp += kBK;
-            if (lp >= g.HW) {
-                lp -= g.HW;
+            if (lp >= HWk) {
+                lp -= HWk;
                 ++ln;
             }
         } else {
-            ln = lk / g.HW;
-            lp = lk - ln * g.HW;
+            ln = lk / HWk;
+            lp = lk - ln * HWk;
         }
     };
     auto store_chunk = [&](int buf) {
@@ -186,7 +220,14 @@ __device__ __forceinline__ void gram_tile(const GramGeom& g, float* smem, const 
             const bool oka = staged_kin && ((rows_ok_a >> q) & 1u);
             const bool okb = staged_kin && ((rows_ok_b >> q) & 1u);
             // a tile inside the matrix on a chunk inside K needs no masking (block-uniform test, no selects)
-            if (!(interior && staged_full)) {
+            if constexpr (PAD) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const bool pe = (pmask >> e) & 1u;
+                    ra.v[q][e] = (oka && pe) ? ra.v[q][e] : 0.f;
+                    rb.v[q][e] = (okb && pe) ? rb.v[q][e] : 0.f;
+                }
+            } else if (!(interior && staged_full)) {
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
                     ra.v[q][e] = oka ? ra.v[q][e] : 0.f;
@@ -400,7 +441,8 @@ struct GramNodeDev {      // device node table entry
     int C;
     uint32_t HW;
     uint32_t Ktot;
-    int variant;          // 0: <128,4>  1: <128,1>  2: <64,4>  3: <64,1>
+    uint32_t HWp, Kk;     // PAD forms: padded pixels per sample, B * HWp (else HW, Ktot)
+    int variant;          // 0: <128,4>  1: <128,1>  2: <64,4>  3: <64,1>  4: <128,4,PAD>  5: <64,4,PAD>
     int S;
     int group;
     int source;           // >= 0: derived from that node's slabs (no contraction of its own); -1: contracted
@@ -426,6 +468,9 @@ __global__ __launch_bounds__(kThreads, 2) void gram_batch_kernel(const GramNodeD
     g.C = nd.C;
     g.HW = nd.HW;
     g.Ktot = nd.Ktot;
+    g.HWp = nd.HWp;
+    g.Kk = nd.Kk;
+    g.bytes = 4u * nd.C * nd.Ktot;
     g.nchunks = 0;
     g.chunks_per_split = 0;
     g.tiles = 0;
@@ -433,7 +478,9 @@ __global__ __launch_bounds__(kThreads, 2) void gram_batch_kernel(const GramNodeD
         case 0: gram_tile<128, 4>(g, smem, it.tm, it.tn, it.split, it.c_begin, it.c_end); break;
         case 1: gram_tile<128, 1>(g, smem, it.tm, it.tn, it.split, it.c_begin, it.c_end); break;
         case 2: gram_tile<64, 4>(g, smem, it.tm, it.tn, it.split, it.c_begin, it.c_end); break;
-        default: gram_tile<64, 1>(g, smem, it.tm, it.tn, it.split, it.c_begin, it.c_end); break;
+        case 3: gram_tile<64, 1>(g, smem, it.tm, it.tn, it.split, it.c_begin, it.c_end); break;
+        case 4: gram_tile<128, 4, 0, 1>(g, smem, it.tm, it.tn, it.split, it.c_begin, it.c_end); break;
+        default: gram_tile<64, 4, 0, 1>(g, smem, it.tm, it.tn, it.split, it.c_begin, it.c_end); break;
     }
 }
 
@@ -455,6 +502,9 @@ __global__ __launch_bounds__(kThreads, 2) void gram_batch_split_kernel(const Gra
     g.C = nd.C;
     g.HW = nd.HW;
     g.Ktot = nd.Ktot;
+    g.HWp = nd.HWp;
+    g.Kk = nd.Kk;
+    g.bytes = 4u * nd.C * nd.Ktot;
     g.nchunks = 0;
     g.chunks_per_split = 0;
     g.tiles = 0;
@@ -462,7 +512,9 @@ __global__ __launch_bounds__(kThreads, 2) void gram_batch_split_kernel(const Gra
         case 0: gram_tile<128, 4, 1>(g, smem, it.tm, it.tn, it.split, it.c_begin, it.c_end); break;
         case 1: gram_tile<128, 1>(g, smem, it.tm, it.tn, it.split, it.c_begin, it.c_end); break;
         case 2: gram_tile<64, 4, 1>(g, smem, it.tm, it.tn, it.split, it.c_begin, it.c_end); break;
-        default: gram_tile<64, 1>(g, smem, it.tm, it.tn, it.split, it.c_begin, it.c_end); break;
+        case 3: gram_tile<64, 1>(g, smem, it.tm, it.tn, it.split, it.c_begin, it.c_end); break;
+        case 4: gram_tile<128, 4, 0, 1>(g, smem, it.tm, it.tn, it.split, it.c_begin, it.c_end); break;      // exact: no split variant
+        default: gram_tile<64, 4, 0, 1>(g, smem, it.tm, it.tn, it.split, it.c_begin, it.c_end); break;
     }
 }
 
@@ -628,6 +680,9 @@ extern "C" int pleas_gram_accum(const float* x, const float* y, int B, int C, in
     g.C = C;
     g.HW = (uint32_t)HW;
     g.Ktot = (uint32_t)((int64_t)B * HW);
+    g.HWp = g.HW;
+    g.Kk = g.Ktot;
+    g.bytes = 4u * (uint32_t)C * g.Ktot;
     g.nchunks = p.nchunks;
     g.chunks_per_split = p.cps;
     g.tiles = p.tiles;
@@ -719,14 +774,21 @@ static int build_batch_plan(BatchPlan& P, const pleas_gram_node* nd, int n, floa
         const int tile = C > 64 ? 128 : 64;
         const int vec = (HW % 4 == 0) ? 4 : 1;  // operand alignment is checked per call
         const int tiles = (int)ceil_div(C, tile);
-        const int nchunks = (int)ceil_div((int64_t)B * HW, kBK);
+        // images with HW % 4 != 0 and at least four pixels: the padded K axis with under-aligned 16-byte loads instead of one
+        // pixel per load (PLEAS_GRAM_PADK=0 keeps the scalar form for A/B)
+        static const bool padk = !(std::getenv("PLEAS_GRAM_PADK") && std::atoi(std::getenv("PLEAS_GRAM_PADK")) == 0);
+        const bool pad = padk && vec == 1 && HW >= 4;
+        const int64_t HWp = pad ? (HW + 3) / 4 * 4 : HW;
+        const int nchunks = (int)ceil_div((int64_t)B * HWp, kBK);
         const int S = (int)ceil_div(nchunks, g_item_chunks);
         const int cps = (int)ceil_div(nchunks, S);
         GramNodeDev& d = P.nodes[i];
         d.C = C;
         d.HW = (uint32_t)HW;
         d.Ktot = (uint32_t)((int64_t)B * HW);
-        d.variant = (tile == 128 ? 0 : 2) + (vec == 4 ? 0 : 1);
+        d.HWp = (uint32_t)HWp;
+        d.Kk = (uint32_t)((int64_t)B * HWp);
+        d.variant = pad ? (tile == 128 ? 4 : 5) : (tile == 128 ? 0 : 2) + (vec == 4 ? 0 : 1);
         d.group = nd[i].group;
         d.source = nd[i].derived ? nd[i].source : -1;
         d.sums = is_source[i];
@@ -773,7 +835,8 @@ static int build_batch_plan(BatchPlan& P, const pleas_gram_node* nd, int n, floa
             size_t end = pos;
             while (end < P.items.size() && P.items[end].node == P.items[pos].node && P.items[end].split == P.items[pos].split)
                 ++end;
-            const int t = (int)ceil_div(P.nodes[P.items[pos].node].C, P.nodes[P.items[pos].node].variant < 2 ? 128 : 64);
+            const int var_ = P.nodes[P.items[pos].node].variant;
+            const int t = (int)ceil_div(P.nodes[P.items[pos].node].C, (var_ < 2 || var_ == 4) ? 128 : 64);
             if ((int)(end - pos) == t * t && t >= 4 && (t & (t - 1)) == 0) {
                 int sr = 1, sc = 1;  // sr * sc = t*t/8, as square as possible, sc >= sr
                 for (int area = t * t / 8; sr * sc < area;) (sc <= sr ? sc : sr) *= 2;

@@ -520,6 +520,24 @@ def test_gram_batch_matches_per_node_sums(ops):
             assert _rel(got, ref) < 1e-5, _rel(got, ref)  # different K splits: only rounding may differ
 
 
+@pytest.mark.parametrize("shape", [(16, 2048, 7, 7), (3, 136, 7, 7), (2, 70, 5, 3), (1, 33, 3, 3), (5, 130, 9, 9)])
+def test_gram_batch_padded_pixel_form_vs_fp64(ops, shape):
+    """Images with HW % 4 != 0 in the grouped launch: the K axis of (sample, pixel padded to a multiple of four) with under-aligned
+    16-byte loads (round 5; the single-node entry point keeps one pixel per load) against fp64, both epilogues, and the last
+    row's clamped run (the tensor ends inside a padded group)."""
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g)
+    y = 0.6 * x + 0.5 * torch.randn(shape, generator=g)
+    C = shape[1]
+    for epi, want in ((ops.EPI_INNER, orc.cross_features_inner_product(x.double(), y.double(), 1)),
+                      (ops.EPI_NEG_CDIST, orc.cross_features_cdist_f64(x, y, 1))):
+        mats = [torch.full((C, C), float("nan"), device="cuda")]
+        batch = ops.GramBatch(mats, epi)
+        batch.add(x.cuda(), y.cuda(), 1, 0)
+        batch.flush(accumulate=False)
+        assert _rel(mats[0].cpu(), want) < 2e-6, (shape, epi, _rel(mats[0].cpu(), want))
+
+
 @pytest.mark.parametrize("epi", ["cdist", "inner"])
 def test_gram_batch_derived_affine_nodes_match_contracted_ones(ops, epi):
     """A node declared as a per-channel affine image of another node (eval-mode BatchNorm of a convolution output) is
@@ -623,6 +641,13 @@ WGRAD_CASES = [
     (2, 8, 3, 9, 11, 3, 1, 1),         # tiny, ragged, one tile
     (2, 20, 5, 12, 12, 5, 2, 2),       # 5x5 stride 2: 125 virtual channels, HWo = 36
     (3, 70, 15, 7, 7, 3, 1, 1),        # 135 virtual channels: TN = 128, HW = 49 (scalar residual loads)
+    # images with HW % 4 != 0 on stride-1 same-size layers (one pixel per load; a padded-pixel 16-byte form was built and measured
+    # in round 5: no gain on these short-K layers, profiles/r05_padk_ab.txt -- the cases stay)
+    (4, 96, 64, 7, 7, 3, 1, 1),        # 3x3 at 7 x 7 (layer4)
+    (16, 512, 512, 7, 7, 3, 1, 1),     # the same at ResNet size: 128 x 128 tiles, 25 chunks
+    (16, 2048, 512, 7, 7, 1, 1, 0),    # 1x1 at 7 x 7, batch 16 (layer4 conv3)
+    (2, 20, 32, 5, 5, 5, 1, 2),        # 5x5 "same" on a 5 x 5 image (HW = 25)
+    (1, 33, 17, 3, 3, 1, 1, 0),        # one sample, HW = 9: the last row's run is clamped at the tensor's end
 ]
 
 

@@ -170,15 +170,14 @@ def _hip_job_vs_reference(ref, tag):
     assert n == N_UPDATES and fit.fast_updates == N_UPDATES - 1
     got = {k: v.cpu() for k, v in fit.finish().state_dict().items()}
     # ---- the gate.  A tensor's yardstick is ONE draw of "two correct implementations apart" (the oracle with oneDNN
-    # convolutions on / off), and so is the HIP path's distance.  Measured on the MI355X (profiles/r04_timed_config_parity*.json):
-    # with the vendor's WINOGRAD 3 x 3 kernels in the 128-sample source forwards, one tensor of 105 (layer3.8.conv2.weight) sat
-    # at 5.7e-4 = 7 x its own yardstick with 0.34 % of its coordinates on the other side of Adam's first sign-like steps; with
-    # the vendor's direct kernels -- what the library asks MIOpen for since round 4 (pleas_merging_amd/__init__.py) -- no
-    # tensor is above 3 x its yardstick and the worst share is 0.14 %, below the oracle's own 0.21 %.  The spread is the
-    # vendor's convolution arithmetic, not the update's kernels (those are held to fp64 on identical taps in
-    # test_hip_fullsize.py).  So, as for the long horizon (tests/test_hip_long_horizon.py): at most two tensors of ~100 above
-    # 3 x their own yardstick, none above 3 x the model's LARGEST yardstick; the share of coordinates with a visibly different
-    # Adam step within 3 x the oracle's worst share; all other coordinates together within max(1e-4, 2 x the oracle's worst).
+    # convolutions on / off), and so is the HIP path's distance.  History of this comparison on the MI355X: with the vendor's
+    # Winograd 3 x 3 kernels in the source forwards one tensor of 105 sat at 7 x its own yardstick (round 4); with the vendor's
+    # direct kernels none above 3 x; since round 5 the k x k source convolutions are the library's own (repeatable bits): none above
+    # 3 x here, one (layer3.11.conv2.weight) in the bench's model draw (profiles/r05_timed_config_parity.json, r05_a_bench.json).
+    # The update's kernels themselves are held to fp64 on identical taps in test_hip_fullsize.py.  So, as for the long horizon
+    # (tests/test_hip_long_horizon.py): at most two tensors of ~100 above 3 x their own yardstick, none above 3 x the model's
+    # LARGEST yardstick; the share of coordinates with a visibly different Adam step within 3 x the oracle's worst share; all
+    # other coordinates together within max(1e-4, 2 x the oracle's worst).  The fp64 anchor below is the statement about accuracy.
     rows = {}
     for k in want:
         if k == fs.DEGENERATE or not want[k].dtype.is_floating_point:
