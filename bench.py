@@ -26,7 +26,7 @@ Besides the contract's keys the JSON line carries
   alt_solver    the closed-form PLeaS phase (solver="normal_eq": MFMA normal equations + batched Cholesky), N = 1;
   library_baseline  the reference's loops with STOCK PyTorch-ROCm operators on the same GPU (torch.cdist, autograd convolutions,
                 torch.optim.Adam, scipy LAP after D2H), bounded sample scaled like cpu_baseline, N = 1 only;
-  vendor        the frozen source forwards of the PLeaS phase (vendor convolutions + pleas_bn_act) timed alone;
+  vendor        the frozen source forwards of the PLeaS phase (own convolutions since round 5 + pleas_bn_act) timed alone;
   checks        invariants of the last timed job's result (permutations valid, losses fell, weights finite) and
                 parity_vs_oracle: the HIP job with the timed knobs against the oracle on the same batches (exit 3 on failure).
 """
@@ -1053,9 +1053,9 @@ def main():
         src_s, src_per = time_sources_alone(m1, m2, pool, n_pleas, per=cfg["sources_per_forward"] or 2)
         vendor = {"source_forwards_alone_s_per_job": round(src_s, 3), "ms_per_update": round(src_per * 1e3, 3),
                   "share_of_value": round(src_s / value, 3),
-                  "note": "frozen source forwards of the PLeaS phase (MIOpen / Tensile convolutions + pleas_bn_act, both "
-                          "models, %d samples per forward) with nothing else on the GPU; rocprofv3 kernel shares: profiles/"
-                          % ((cfg["sources_per_forward"] or 2) * args.batch)}
+                  "note": "frozen source forwards of the PLeaS phase (convolutions as config.source_convolutions says + pleas_bn_act, "
+                          "both models, %d samples per forward) with nothing else on the GPU; the key keeps its rounds 1-4 name; "
+                          "rocprofv3 kernel shares: profiles/" % ((cfg["sources_per_forward"] or 2) * args.batch)}
     alt_arith = None
     if world == 1 and args.emulate_world <= 1 and not args.no_alt_arith and args.solver == "adam":
         alt_arith = time_alt_arith(job, res, spec, value, n_match, world, rank, args)
@@ -1088,7 +1088,8 @@ def main():
         labels["conv2d"] = "conv2d_fwd_kernel (fp32 MFMA 32x32x2 plain convolution: the k x k layers of the frozen source / twin forwards)"
         conv2d_roof = roof("conv2d")
         conv2d_roof["note"] = ("the two source models' launches share the chip pairwise (two streams): event times include the "
-                               "sibling's share; alone at 128 samples the 3 x 3 layers run at 89-94 TFLOP/s (profiles/r05_probe_conv_classes_128.txt)")
+                               "sibling's share; alone at 128 samples the 3 x 3 layers run at 89-94 TFLOP/s, the 1 x 1 layers at "
+                               "46-96 (profiles/r05_probe_conv_classes_128.txt)")
         # `achieved` counts the flops the contraction kernel EXECUTES.  The path's algorithmic work per matching batch
         # (6.368e10 flop per sample for ResNet-101, every tracked node contracted) is larger: the 104
         # tracked BatchNorm nodes are derived from their convolution node in the reduce pass, not contracted.

@@ -1194,7 +1194,10 @@ static int fwd_describe(const pleas_fwd_layer& l, FwdLayerDev& d, size_t& lds_by
     d.dscale = l.dscale;
     // short-K layers (1x1 with few input channels) are bound by their epilogue's memory traffic, not by the MFMAs:
     // 64-row tiles (52 KB of LDS, <= 132 registers) let THREE workgroups share a CU and overlap more of it
-    static const int tm64_k = std::getenv("PLEAS_FWD_TM64_K") ? std::atoi(std::getenv("PLEAS_FWD_TM64_K")) : 256;
+    // (round 5: 128-row tiles for them too are 1.6 % faster per launch group in both arithmetics -- half the tiles re-read and, under
+    // the split arithmetic, re-convert each input chunk -- so the threshold is 0 unless PLEAS_FWD_TM64_K says otherwise:
+    // 2.570 -> 2.529 ms exact, 1.884 -> 1.837 ms split, profiles/r05_exp_source_conv.txt; 64-row tiles remain for Cout <= 64)
+    static const int tm64_k = std::getenv("PLEAS_FWD_TM64_K") ? std::atoi(std::getenv("PLEAS_FWD_TM64_K")) : 0;
     const int TM = (l.Cout > 64 && !(l.KH * l.KW == 1 && l.stride == 1 && Kd <= tm64_k && l.Cin % fBK == 0)) ? 128 : 64;
     d.variant = (TM == 64 ? 1 : 0) | (Kd % 4 == 0 ? 0 : 2);
     if (l.flags & PLEAS_FWD_KPOS_MAJOR) {

@@ -34,14 +34,17 @@ from .. import hip_ops
 
 
 # Which convolutions of the frozen source / twin forwards run on the library's own kernel instead of the vendor's:
-#   "kxk"    (default) dense, undilated, square k x k layers with k > 1.  MIOpen's immediate-mode picks for them split K with
-#            atomics on small images / batches: the SAME forward differs from itself run to run from the first 3 x 3 layer on
-#            (ResNet-101: layer4's at 128 samples, layer2's at 16, layer1's at 4), which flipped near-tie assignments between two
-#            runs of one job (GPUTEST_r04).  Its deterministic solvers (torch.backends.cudnn.deterministic) are 6-15x slower
-#            per 3 x 3 layer; the own kernel is as fast as the non-deterministic pick (22.8 vs 23.3 ms per 128-sample
-#            ResNet-101 forward) and needs no layout transposes.  1 x 1 layers stay on the vendor's GEMM (repeatable, measured).
-#   "all"    1 x 1 layers too;  "vendor"  none (rounds 1-4).      profiles/r05_probe_conv_classes_128.txt
-SOURCE_CONV = os.environ.get("PLEAS_SOURCE_CONV", "kxk")
+#   "all"    (default) every dense, undilated, square Conv2d.  Two reasons.  (1) Repeatability: MIOpen's immediate-mode picks for
+#            k x k layers split K with atomics on small images / batches -- the SAME forward differs from itself run to run from
+#            the first 3 x 3 layer on (ResNet-101: layer4's at 128 samples, layer2's at 16, layer1's at 4), which flipped near-tie
+#            assignments between two runs of one job (GPUTEST_r04); its deterministic solvers (torch.backends.cudnn.deterministic)
+#            are 6-15x slower per 3 x 3 layer.  (2) Time: layer by layer in isolation the vendor's 1 x 1 GEMMs are as fast or
+#            faster (profiles/r05_probe_conv_classes_128.txt), but IN THE JOB -- two models on two streams beside each other,
+#            no layout transposes, one dispatch path -- the own kernel for every layer is the fastest arrangement: 6.07 s per job
+#            against 6.18 s with the 1 x 1 layers on the vendor's GEMM (same box; under the split-bf16 arithmetic 4.90 against
+#            5.27 s; profiles/r05_exp_source_conv.txt).
+#   "kxk"    only the layers with k > 1 (the 1 x 1 layers on the vendor's GEMM: measured repeatable);  "vendor"  none (rounds 1-4).
+SOURCE_CONV = os.environ.get("PLEAS_SOURCE_CONV", "all")
 
 
 def own_conv_ok(mod: nn.Module, mode: Optional[str] = None) -> bool:

@@ -261,7 +261,8 @@ def test_forward_launch_units_partition_every_form():
 
     fresh = get(None)
     forms = {u[0]: (u[1], u[2]) for u in fresh}
-    assert len(forms) == len(fresh) and sum(c for _, c in forms.values()) > 20000      # one unit per form
+    assert len(forms) == len(fresh) and sum(c for _, c in forms.values()) > 15000      # one unit per form (round 5: 128-row tiles
+    # for the short-K 1 x 1 layers too: 18 036 items, was 27 732)
     rng = np.random.default_rng(0)
     cases = [np.array([1.76, 0, 0, 0.24, 2.56, 0.27, 1.61, 2.56, 0, 0.36]),             # measured in round 3's bench job
              np.ones(10), np.array([0, 0, 0, 0, 0, 0, 0, 9.0, 0, 0.01])] + [rng.random(10) * 3 for _ in range(20)]
@@ -274,7 +275,7 @@ def test_forward_launch_units_partition_every_form():
             for (b0, c0), (b1, _) in zip(slices, slices[1:]):
                 assert b0 + c0 == b1 and c0 > 0, (f, slices)
     split = get((ctypes.c_double * 10)(*cases[0].tolist()))
-    assert len([u for u in split if u[0] == 7]) >= 2 and len([u for u in split if u[0] == 4]) >= 2   # the two 2.56 ms forms
+    assert len([u for u in split if u[0] == 4]) >= 2   # the long 1 x 1 form is cut into slices
 
 
 def test_host_code_under_sanitizers():
