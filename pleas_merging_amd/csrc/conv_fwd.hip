@@ -85,7 +85,8 @@ __device__ __forceinline__ void fwd_load_maps(const FwdLayerDev& L, const int i0
     }
 }
 
-template <int TM>
+// PLAIN = 1 (pleas_conv2d_fwd): no target -- nothing is gathered, no loss partial; the epilogue is bias + store
+template <int TM, int PLAIN = 0>
 __device__ __forceinline__ void fwd_epilogue(const FwdLayerDev& L, const FwdItemDev& it, f32x16 (&acc)[TM / 64][2],
                                              const int (&m1)[TM / 8], const int (&m2)[TM / 8],
                                              const float (&bias_v)[TM / 8], float* smem, float* __restrict__ partials) {
@@ -149,7 +150,9 @@ __device__ __forceinline__ void fwd_epilogue(const FwdLayerDev& L, const FwdItem
                 const int j = bt * GB + u;
                 const uint32_t oa = (gin && m1[j] >= 0) ? gbase + (uint32_t)m1[j] * hw4 : 0u;
                 const uint32_t ob = (gin && m2[j] >= 0) ? gbase + (uint32_t)m2[j] * hw4 : 0u;
-                if constexpr ((PLEAS_FWD_ABLATE & 1) != 0) {
+                if constexpr (PLAIN) {
+                    ta[bt][u] = tb[bt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                } else if constexpr ((PLEAS_FWD_ABLATE & 1) != 0) {
                     ta[bt][u] = f32x4{(float)(oa & 3), 0.f, 0.f, 0.f};
                     tb[bt][u] = f32x4{(float)(ob & 3), 0.f, 0.f, 0.f};
                 } else {
@@ -216,7 +219,7 @@ __device__ __forceinline__ void fwd_epilogue(const FwdLayerDev& L, const FwdItem
     if (tid == 0 && partials) partials[L.part_base + it.slot] = (smem[0] + smem[1]) + (smem[2] + smem[3]);
 }
 
-template <int TM, int VECA>
+template <int TM, int VECA, int PLAIN = 0>
 __device__ __forceinline__ void fwd_tile(const FwdLayerDev& L, const FwdItemDev& it, float* smem, float* __restrict__ partials) {
     constexpr int MTM = TM / 64;
     constexpr int LPR = fBK / VECA, RPP = fThreads / LPR, PASS = TM / RPP;
@@ -409,7 +412,7 @@ __device__ __forceinline__ void fwd_tile(const FwdLayerDev& L, const FwdItemDev&
     __syncthreads();
     PLEAS_FWD_STAMP(st2);
 
-    fwd_epilogue<TM>(L, it, acc, m1, m2, bias_v, smem, partials);
+    fwd_epilogue<TM, PLAIN>(L, it, acc, m1, m2, bias_v, smem, partials);
 #if (PLEAS_FWD_ABLATE & 16)
     if (tid == 0 && blockIdx.x < 32768) {
         const long long st3 = clock64();
@@ -461,7 +464,7 @@ __shared__ long long g_tl_phase[2];   // wall clock at the end of the prologue /
 constexpr int fSplitPixRow = 160;  // bf16 per k row of the 1 x 1 split image: 128 pixels + 32 pad = 320 B (rows 16 banks apart:
                                    // the four rows x eight 8-byte column chunks of a half-wave's transposed read hit 32 distinct bank pairs)
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
-template <int TM, int KIND, int SPLIT = 0>
+template <int TM, int KIND, int SPLIT = 0, int PLAIN = 0>
 __device__ __forceinline__ void fwd_flat_tile(const FwdLayerDev& L, const FwdItemDev& it, float* smem, float* __restrict__ partials) {
     static_assert(!SPLIT || KIND != 1, "the scalar 1 x 1 form (7 x 7 images) has no split variant");
     constexpr int MTM = TM / 64;
@@ -876,7 +879,7 @@ __device__ __forceinline__ void fwd_flat_tile(const FwdLayerDev& L, const FwdIte
     compute((nchunks - 1) & 1, bsel, r);
     __syncthreads();
     PLEAS_TL_PHASE(1);
-    fwd_epilogue<TM>(L, it, acc, m1, m2, bias_v, smem, partials);
+    fwd_epilogue<TM, PLAIN>(L, it, acc, m1, m2, bias_v, smem, partials);
 }
 
 // One kernel per tile form (register allocation and LDS are then per form, not the maximum over all of them); the host
@@ -929,12 +932,12 @@ template <int FORM, int SPLIT = 0>
 __global__ __launch_bounds__(fThreads, (SPLIT && FORM >= 7) ? 3 : 2) void conv2d_fwd_kernel(const FwdLayerDev L, const int tms) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const FwdItemDev it{0, (int)(blockIdx.x % (unsigned)tms), (int)(blockIdx.x / (unsigned)tms), 0};
-    if constexpr (FORM == 0) fwd_tile<128, 4>(L, it, smem, nullptr);
-    else if constexpr (FORM == 1) fwd_tile<64, 4>(L, it, smem, nullptr);
-    else if constexpr (FORM == 2) fwd_tile<128, 1>(L, it, smem, nullptr);
-    else if constexpr (FORM == 3) fwd_tile<64, 1>(L, it, smem, nullptr);
-    else if constexpr (FORM < 7) fwd_flat_tile<128, FORM - 4, SPLIT>(L, it, smem, nullptr);
-    else fwd_flat_tile<64, FORM - 7, SPLIT>(L, it, smem, nullptr);
+    if constexpr (FORM == 0) fwd_tile<128, 4, 1>(L, it, smem, nullptr);
+    else if constexpr (FORM == 1) fwd_tile<64, 4, 1>(L, it, smem, nullptr);
+    else if constexpr (FORM == 2) fwd_tile<128, 1, 1>(L, it, smem, nullptr);
+    else if constexpr (FORM == 3) fwd_tile<64, 1, 1>(L, it, smem, nullptr);
+    else if constexpr (FORM < 7) fwd_flat_tile<128, FORM - 4, SPLIT, 1>(L, it, smem, nullptr);
+    else fwd_flat_tile<64, FORM - 7, SPLIT, 1>(L, it, smem, nullptr);
 }
 // side streams + events of the library for the concurrent forms (created once per process; no device memory)
 constexpr int fLanes = 3;          // side streams (+ the caller's stream = four hardware queues)
