@@ -81,10 +81,12 @@ def parse(argv=None):
                     help="groups of source forwards enqueued while the LAP kernel runs (0: none); also bounded by memory.  "
                          "Two 128-sample groups take about as long as the LAP kernel (0.16 s); more would still be running "
                          "beside the first updates and stretch their kernels (fwd 2.7 -> 3.2 ms at 6 groups, same job time)")
-    ap.add_argument("--sources-per-forward", type=int, default=8,
-                    help="updates PER RANK whose batches go through the frozen sources as ONE forward (128 samples per "
-                         "forward at 8: the vendor convolutions run 15-30 %% faster per sample than at 32); 0 = the fitter's "
-                         "default of 2; the prefetch takes --prefetch-groups forwards of that size")
+    ap.add_argument("--sources-per-forward", type=int, default=10,
+                    help="updates PER RANK whose batches go through the frozen sources as ONE forward (160 samples per "
+                         "forward at 10: a layer's grid is then a few rounds of the chip's 512 workgroup slots instead of a "
+                         "fraction of one; 8 -> 10: -1.6 %% of the job, 12: no further gain for 28 GB more taps, "
+                         "profiles/r05_exp_conv_bn.txt); 0 = the fitter's default of 2; the prefetch takes "
+                         "--prefetch-groups forwards of that size")
     ap.add_argument("--match-per-forward", type=int, default=10,
                     help="matching batches per twin forward (every tracked node is still contracted per batch): the vendor "
                          "convolutions run faster per sample at 64-160 samples than at 16; 0 = the library's default (forwards of up to 64 "
@@ -106,7 +108,7 @@ def parse(argv=None):
     ap.add_argument("--cpu-match-batches", type=int, default=10, help="cpu_baseline / parity sample: matching batches of the "
                     "job's own (default 10 = one twin forward of the timed size)")
     ap.add_argument("--cpu-updates", type=int, default=8, help="cpu_baseline / parity sample: PLeaS updates on the job's own "
-                    "first batches (default 8 = one source forward of the timed size)")
+                    "first batches (default 8: within one source forward of the timed size)")
     ap.add_argument("--gc", default="lap", choices=("lap", "auto"),
                     help="lap (default): Python's cyclic garbage collector is switched off while a job runs and called once "
                          "per job where the host has nothing to do -- while the batched LAP kernel runs; auto: the "

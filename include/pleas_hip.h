@@ -316,6 +316,14 @@ int pleas_fwd_batch(const pleas_fwd_layer* layers, int n_layers, float* loss, vo
  *   x and w 16-byte aligned; square kernels up to 64 taps; no workspace, no tables: the layer rides in the kernel arguments. */
 int pleas_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int Hin, int Win, int Cout,
                      int KH, int KW, int stride, int pad, int flags, void* stream);
+/* pleas_conv2d_bn_act_fwd: the same convolution with the eval-mode BatchNorm / residual add / ReLU that follows it in a frozen
+ * source (torchvision Bottleneck: conv -> bn -> relu, conv3 -> bn3 -> (+ identity) -> relu, downsample conv -> bn) in its
+ * epilogue:  y = conv(x, w) (+ bias)  is stored for the hooks of pleas_merging.py:197-231 (the layer's OUTPUT is a regression
+ * target), and  z = act(y * scale[c] + shift[c] (+ res))  -- bit for bit what pleas_bn_act makes of y -- is stored beside it
+ * from the registers, so y is not read back.  res (or NULL) and z are shaped like y; y, z, res 16-byte aligned. */
+int pleas_conv2d_bn_act_fwd(const float* x, const float* w, const float* bias, float* y, const float* scale,
+                            const float* shift, const float* res, float* z, int relu, int N, int Cin, int Hin, int Win,
+                            int Cout, int KH, int KW, int stride, int pad, int flags, void* stream);
 typedef struct pleas_wgrad_layer {
     const float* resid; /* [N][Cout][Hout*Wout] */
     const float* ip;    /* [N][Cin][Hin][Win]   */

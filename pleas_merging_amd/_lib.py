@@ -74,6 +74,7 @@ SIGNATURES = {
     "pleas_allreduce_sum": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "pleas_fwd_batch": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "pleas_conv2d_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
+    "pleas_conv2d_bn_act_fwd": (c_int, [c_void_p] * 8 + [c_int] * 11 + [c_void_p]),
     "pleas_wgrad_batch_ws_bytes": (c_size_t, [c_void_p, c_int]),
     "pleas_wgrad_batch": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "pleas_gram_batch_ws_bytes": (c_size_t, [c_void_p, c_int, POINTER(c_int), c_int]),

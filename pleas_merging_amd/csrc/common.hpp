@@ -74,6 +74,12 @@ __device__ __forceinline__ void split3_pair(float a, float b, uint32_t (&p)[3]) 
     p[1] = split_bf16_pair(ra, rb);
     p[2] = split_bf16_pair(ra - __builtin_bit_cast(float, p[1] << 16), rb - __builtin_bit_cast(float, p[1] & 0xffff0000u));
 }
+// Which row of a 32-row staging pass the 8-lane group g = tid / 8 (0 .. 31) writes under the split arithmetic.  Rows of a split
+// image are kSplitRow = 208 bytes apart (the stride that keeps the 16-byte fragment READS conflict-free) and a lane writes 8 bytes
+// per plane, so the four CONSECUTIVE rows of a half-wave overlap in 4 of 64 banks pairwise (a two-way conflict on every plane
+// write: profiles/r05_pmc_split_*.txt); rows 4 apart start 16 banks apart and tile the 64 banks exactly.  Which lane group
+// stages which row is free -- global rows are whole cache lines either way.
+__device__ __forceinline__ int split_stage_row(int g) { return ((g & 3) << 2) | ((g >> 2) & 3) | (g & 16); }
 // four consecutive k of one row -> the row's three planes of an LDS split image (`row` points at the row's plane 0, `col` = k)
 __device__ __forceinline__ void split3_store4(__bf16* row, int col, float v0, float v1, float v2, float v3) {
     uint32_t lo[3], hi[3];

@@ -84,8 +84,9 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayerDev& L, const WgradIt
     const int dh = kh - L.pad, dw = kw - L.pad;
     const uint32_t HWi = (uint32_t)L.Hin * L.Win;
 
-    const int xrow = tid / LPR_X, xcol = (tid % LPR_X) * VECX;
-    const int yrow = tid / LPR_Y, ycol = (tid % LPR_Y) * VECY;
+    // SPLIT (16-byte loads of both operands: 8 lanes per row, 32 rows per pass): bank-conflict-free plane writes
+    const int xrow = SPLIT ? split_stage_row(tid / LPR_X) : tid / LPR_X, xcol = (tid % LPR_X) * VECX;
+    const int yrow = SPLIT ? split_stage_row(tid / LPR_Y) : tid / LPR_Y, ycol = (tid % LPR_Y) * VECY;
     float rx[PASS_X][VECX], ry[PASS_Y][VECY];
     unsigned okx = 0, oky = 0;
     unsigned win = 0xFu;                  // YMODE 2: bit e = output pixel e of this thread's run has tap r inside the image

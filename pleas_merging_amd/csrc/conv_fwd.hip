@@ -57,7 +57,14 @@ struct FwdLayerDev {
     int variant;          // bit0: TM == 64, bit1: scalar W loads, bit2: W is kernel-position-major [Cout][KH*KW][Cin],
                           // bit3: flat-shift tile (fwd_flat_tile), bits 4-5: its KIND
     int part_base;        // first loss-partial slot of this layer
-    int pad0;
+    int bn_relu;          // PLAIN == 2: ReLU after the affine map (+ identity)
+    // PLAIN == 2 (pleas_conv2d_bn_act_fwd): the convolution's output goes to `resid` AND its activated image
+    // z = act(y * bn_scale[co] + bn_shift[co] (+ bn_res)) to `bn_z` -- the BatchNorm / add / ReLU pass that follows a frozen
+    // source's convolution, without reading y back from memory
+    const float* bn_scale;   // [Cout]
+    const float* bn_shift;   // [Cout]
+    const float* bn_res;     // [N][Cout][HWo] or null
+    float* bn_z;             // [N][Cout][HWo]
 };
 struct FwdItemDev {
     int layer, tm, tp, slot;  // slot: loss-partial index
@@ -71,13 +78,19 @@ __device__ long long g_fwd_stamps[32768][4];   // per work item: prologue, K loo
 #endif
 
 // ---- shared by both tile forms: the block maps / biases of a tile's output channels, and the epilogue
-template <int TM>
+template <int TM, int PLAIN = 0>
 __device__ __forceinline__ void fwd_load_maps(const FwdLayerDev& L, const int i0, int (&m1)[TM / 8], int (&m2)[TM / 8],
                                               float (&bias_v)[TM / 8]) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int j = 0; j < TM / 8; ++j) {
         const int co = min(i0 + (tid >> 5) + 8 * j, L.Cout - 1);
+        if constexpr (PLAIN == 2) {      // no block maps: their registers carry the channel's affine map (as bit patterns)
+            m1[j] = __float_as_int(PLEAS_GLOBAL(L.bn_scale)[co]);
+            m2[j] = __float_as_int(PLEAS_GLOBAL(L.bn_shift)[co]);
+            bias_v[j] = L.bias ? PLEAS_GLOBAL(L.bias)[co] : 0.f;
+            continue;
+        }
         // a plain convolution (pleas_conv2d_fwd) has no block maps: every source row is absent, the target is zero
         m1[j] = L.row1 ? PLEAS_GLOBAL_I(L.row1)[co] : -1;
         m2[j] = L.row2 ? PLEAS_GLOBAL_I(L.row2)[co] : -1;
@@ -86,6 +99,9 @@ __device__ __forceinline__ void fwd_load_maps(const FwdLayerDev& L, const int i0
 }
 
 // PLAIN = 1 (pleas_conv2d_fwd): no target -- nothing is gathered, no loss partial; the epilogue is bias + store
+// PLAIN = 2 (pleas_conv2d_bn_act_fwd): the same, and the activated image  act(fma(y, scale, shift) + identity)  is stored
+// beside y -- the arithmetic of bn_act_kernel (elementwise.hip) on the value that is still in registers; the identity takes
+// the gather slots of the target
 template <int TM, int PLAIN = 0>
 __device__ __forceinline__ void fwd_epilogue(const FwdLayerDev& L, const FwdItemDev& it, f32x16 (&acc)[TM / 64][2],
                                              const int (&m1)[TM / 8], const int (&m2)[TM / 8],
@@ -141,16 +157,27 @@ __device__ __forceinline__ void fwd_epilogue(const FwdLayerDev& L, const FwdItem
         const uint32_t hw4 = 4u * L.HWo;
         const uint32_t gbase = 4u * (gn * (uint32_t)L.Csrc * L.HWo + gp);
         const uint32_t rbase = 4u * ((gn * (uint32_t)L.Cout + (uint32_t)i0 + (uint32_t)(tid >> 5)) * L.HWo + gp);
-        const char* o1b = reinterpret_cast<const char*>(L.o1);
+        // PLAIN == 2: the identity (shaped like the output) stands where the first source's outputs are gathered from
+        const bool has_res = PLAIN == 2 && L.bn_res != nullptr;
+        const char* o1b = reinterpret_cast<const char*>(PLAIN == 2 ? (has_res ? L.bn_res : L.ip) : L.o1);
         const char* o2b = reinterpret_cast<const char*>(L.o2);
         char* rb_ = reinterpret_cast<char*>(L.resid);
+        char* zb_ = reinterpret_cast<char*>(L.bn_z);
         auto gather = [&](const int bt) {
 #pragma unroll
             for (int u = 0; u < GB; ++u) {
                 const int j = bt * GB + u;
                 const uint32_t oa = (gin && m1[j] >= 0) ? gbase + (uint32_t)m1[j] * hw4 : 0u;
                 const uint32_t ob = (gin && m2[j] >= 0) ? gbase + (uint32_t)m2[j] * hw4 : 0u;
-                if constexpr (PLAIN) {
+                if constexpr (PLAIN == 2) {
+                    // unconditional load from a valid address (the output's own offset into the identity; the first floats
+                    // of the input for rows / pixels outside the layer and when there is no identity -- then voided by a
+                    // select): no branch around a load
+                    const bool live = has_res && gin && i0 + (tid >> 5) + 8 * j < L.Cout;
+                    const uint32_t oz = live ? rbase + (uint32_t)(8 * j) * hw4 : 0u;
+                    const f32x4 idn = *(const __attribute__((address_space(1))) f32x4*)(o1b + oz);
+                    ta[bt][u] = has_res ? idn : f32x4{0.f, 0.f, 0.f, 0.f};
+                } else if constexpr (PLAIN) {
                     ta[bt][u] = tb[bt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
                 } else if constexpr ((PLEAS_FWD_ABLATE & 1) != 0) {
                     ta[bt][u] = f32x4{(float)(oa & 3), 0.f, 0.f, 0.f};
@@ -167,6 +194,22 @@ __device__ __forceinline__ void fwd_epilogue(const FwdLayerDev& L, const FwdItem
                 const int j = bt * GB + u;
                 const int lco = (tid >> 5) + 8 * j, co = i0 + lco;
                 const bool live = gin && co < L.Cout;
+                if constexpr (PLAIN == 2) {
+                    const float a = __int_as_float(m1[j]), b = __int_as_float(m2[j]);
+                    const f32x4 o = *reinterpret_cast<const f32x4*>(Ct + lco * EL + pg);
+                    f32x4 y, z;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        y[e] = o[e] + bias_v[j];
+                        const float sm = fmaf(y[e], a, b) + ta[bt][u][e];
+                        z[e] = L.bn_relu ? fmaxf(sm, 0.f) : sm;
+                    }
+                    if (live) {
+                        *(__attribute__((address_space(1))) f32x4*)(rb_ + (rbase + (uint32_t)(8 * j) * hw4)) = y;
+                        *(__attribute__((address_space(1))) f32x4*)(zb_ + (rbase + (uint32_t)(8 * j) * hw4)) = z;
+                    }
+                    continue;
+                }
                 // target = (o1 * [present] + o2 * [present]) * coef, coef in {0.5, 1}: folding coef into the two factors is
                 // exact (power of two), so  fma(o2, cb, o1 * ca)  rounds once, like the sum it replaces
                 const float coef = co < L.n_merged ? 0.5f : 1.0f;
@@ -202,6 +245,14 @@ __device__ __forceinline__ void fwd_epilogue(const FwdLayerDev& L, const FwdItem
                 const uint32_t Pe = Pg + e;
                 if (Pe >= L.Ptot) break;
                 const uint32_t n = Pe / L.HWo, p = Pe - n * L.HWo;
+                if constexpr (PLAIN == 2) {
+                    const size_t at = ((size_t)n * L.Cout + co) * L.HWo + p;
+                    const float y = o[e] + bias_v[j];
+                    const float sm = fmaf(y, __int_as_float(m1[j]), __int_as_float(m2[j])) + (L.bn_res ? PLEAS_GLOBAL(L.bn_res)[at] : 0.f);
+                    PLEAS_GLOBAL_W(L.resid)[at] = y;
+                    PLEAS_GLOBAL_W(L.bn_z)[at] = L.bn_relu ? fmaxf(sm, 0.f) : sm;
+                    continue;
+                }
                 float a = 0.f, b = 0.f;
                 if (m1[j] >= 0) a = PLEAS_GLOBAL(L.o1)[((size_t)n * L.Csrc + m1[j]) * L.HWo + p];
                 if (m2[j] >= 0) b = PLEAS_GLOBAL(L.o2)[((size_t)n * L.Csrc + m2[j]) * L.HWo + p];
@@ -399,7 +450,7 @@ __device__ __forceinline__ void fwd_tile(const FwdLayerDev& L, const FwdItemDev&
     constexpr int ROWS = TM / 8;
     int m1[ROWS], m2[ROWS];
     float bias_v[ROWS];
-    auto load_maps = [&]() { fwd_load_maps<TM>(L, i0, m1, m2, bias_v); };
+    auto load_maps = [&]() { fwd_load_maps<TM, PLAIN>(L, i0, m1, m2, bias_v); };
     for (int c = 0; c + 1 < nchunks; ++c) {
         const int buf = c & 1;
         load_chunk(c + 1);
@@ -490,7 +541,7 @@ __device__ __forceinline__ void fwd_flat_tile(const FwdLayerDev& L, const FwdIte
     __bf16* Bs16 = As16 + TM * kSplitRow;            // SPLIT: k x k [fFlatColsK][kSplitRow]; 1 x 1 [3][32][fSplitPixRow]
 
     // ---- A (weights) staging, as in fwd_tile with VECA = 4
-    const int arow = tid / LPR, acol = (tid % LPR) * 4;
+    const int arow = SPLIT ? split_stage_row(tid / LPR) : tid / LPR, acol = (tid % LPR) * 4;      // SPLIT: conflict-free plane writes
     f32x4 ra0[PASS], ra1[PASS];    // two register sets: the weights of chunk c + 2 are requested while chunk c computes
     unsigned oka = 0;
     uint32_t offa[PASS];
@@ -875,7 +926,7 @@ __device__ __forceinline__ void fwd_flat_tile(const FwdLayerDev& L, const FwdIte
         step(c, r, ra1, ra0, rb1, rb0);
         r = ra_;
     }
-    fwd_load_maps<TM>(L, i0, m1, m2, bias_v);        // epilogue operands, requested under the last chunk's MFMAs
+    fwd_load_maps<TM, PLAIN>(L, i0, m1, m2, bias_v);        // epilogue operands, requested under the last chunk's MFMAs
     compute((nchunks - 1) & 1, bsel, r);
     __syncthreads();
     PLEAS_TL_PHASE(1);
@@ -928,16 +979,17 @@ __global__ __launch_bounds__(fThreads, (SPLIT && FORM >= 7) ? 3 : 2) void fwd_ba
 }
 // A plain convolution (pleas_conv2d_fwd): ONE layer, described in the kernel arguments; the work item is the block index
 // (output-channel tile fastest, as in the grouped plan), no tables, no target, no loss.
-template <int FORM, int SPLIT = 0>
+template <int FORM, int SPLIT = 0, int BN = 0>
 __global__ __launch_bounds__(fThreads, (SPLIT && FORM >= 7) ? 3 : 2) void conv2d_fwd_kernel(const FwdLayerDev L, const int tms) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const FwdItemDev it{0, (int)(blockIdx.x % (unsigned)tms), (int)(blockIdx.x / (unsigned)tms), 0};
-    if constexpr (FORM == 0) fwd_tile<128, 4, 1>(L, it, smem, nullptr);
-    else if constexpr (FORM == 1) fwd_tile<64, 4, 1>(L, it, smem, nullptr);
-    else if constexpr (FORM == 2) fwd_tile<128, 1, 1>(L, it, smem, nullptr);
-    else if constexpr (FORM == 3) fwd_tile<64, 1, 1>(L, it, smem, nullptr);
-    else if constexpr (FORM < 7) fwd_flat_tile<128, FORM - 4, SPLIT, 1>(L, it, smem, nullptr);
-    else fwd_flat_tile<64, FORM - 7, SPLIT, 1>(L, it, smem, nullptr);
+    constexpr int PLAIN = 1 + BN;      // 2: the BatchNorm / add / ReLU image is written beside the output
+    if constexpr (FORM == 0) fwd_tile<128, 4, PLAIN>(L, it, smem, nullptr);
+    else if constexpr (FORM == 1) fwd_tile<64, 4, PLAIN>(L, it, smem, nullptr);
+    else if constexpr (FORM == 2) fwd_tile<128, 1, PLAIN>(L, it, smem, nullptr);
+    else if constexpr (FORM == 3) fwd_tile<64, 1, PLAIN>(L, it, smem, nullptr);
+    else if constexpr (FORM < 7) fwd_flat_tile<128, FORM - 4, SPLIT, PLAIN>(L, it, smem, nullptr);
+    else fwd_flat_tile<64, FORM - 7, SPLIT, PLAIN>(L, it, smem, nullptr);
 }
 // side streams + events of the library for the concurrent forms (created once per process; no device memory)
 constexpr int fLanes = 3;          // side streams (+ the caller's stream = four hardware queues)
@@ -1408,10 +1460,16 @@ extern "C" size_t pleas_fwd_batch_ws_bytes(const pleas_fwd_layer* layers, int n_
     return tmp.total;
 }
 
-extern "C" int pleas_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int Hin, int Win,
-                                int Cout, int KH, int KW, int stride, int pad, int flags, void* stream_) {
+// y = conv(x, w) (+ bias); with `scale`: also z = act(y * scale[c] + shift[c] (+ res)) in the same epilogue
+static int conv2d_launch(const float* x, const float* w, const float* bias, float* y, const float* scale, const float* shift,
+                         const float* res, float* z, int relu, int N, int Cin, int Hin, int Win, int Cout, int KH, int KW,
+                         int stride, int pad, int flags, void* stream_) {
     if (!x || !w || !y) return bad_arg("conv2d_fwd: null pointer");
     if (((uintptr_t)w & 15) != 0 || ((uintptr_t)x & 15) != 0) return bad_arg("conv2d_fwd: x and w must be 16-byte aligned");
+    const bool bn = scale != nullptr;
+    if (bn && (!shift || !z)) return bad_arg("conv2d_bn_act_fwd: scale needs shift and z");
+    if (bn && ((((uintptr_t)y | (uintptr_t)z | (uintptr_t)res) & 15) != 0))
+        return bad_arg("conv2d_bn_act_fwd: y, z and res must be 16-byte aligned");
     pleas_fwd_layer l{};
     l.ip = x; l.w = w; l.bias = bias; l.resid = y;
     l.N = N; l.Cout = Cout; l.Cin = Cin; l.Hin = Hin; l.Win = Win; l.KH = KH; l.KW = KW; l.stride = stride; l.pad = pad;
@@ -1423,27 +1481,50 @@ extern "C" int pleas_conv2d_fwd(const float* x, const float* w, const float* bia
     // no block maps: every source row is absent (fwd_load_maps), the masked gathers read the first floats of x
     d.ip = x; d.w = w; d.bias = bias; d.o1 = x; d.o2 = x; d.row1 = nullptr; d.row2 = nullptr; d.resid = y;
     d.part_base = 0;
+    d.bn_scale = scale; d.bn_shift = shift; d.bn_res = res; d.bn_z = z; d.bn_relu = relu ? 1 : 0;
     const int tms = (int)ceil_div(Cout, TM), tps = (int)ceil_div((int64_t)d.Ptot, fTN);
     const dim3 grid((unsigned)((int64_t)tms * tps));
     hipStream_t st = (hipStream_t)stream_;
+    const double out_floats = (double)Cout * d.Ptot;
     ProfScope prof(kProfConv2d, 2.0 * Cout * (double)d.Kd * (double)d.Ptot,
-                   ((double)Cin * N * Hin * Win + (double)Cout * d.Ptot) * sizeof(float), st);
+                   ((double)Cin * N * Hin * Win + out_floats * (bn ? (res ? 3.0 : 2.0) : 1.0)) * sizeof(float), st);
     const int form = fwd_form_of(d.variant);
-    if (arith_mode() == 1 && fwd_form_splits(form)) {
-        switch (form) {
-#define PLEAS_CONV_LAUNCH(F) case F: hipLaunchKernelGGL((conv2d_fwd_kernel<F, 1>), grid, dim3(fThreads), lds, st, d, tms); break
-            PLEAS_CONV_LAUNCH(4); PLEAS_CONV_LAUNCH(6); PLEAS_CONV_LAUNCH(7); PLEAS_CONV_LAUNCH(9);
-#undef PLEAS_CONV_LAUNCH
-        }
-    } else
-    switch (form) {
-#define PLEAS_CONV_LAUNCH(F) case F: hipLaunchKernelGGL((conv2d_fwd_kernel<F, 0>), grid, dim3(fThreads), lds, st, d, tms); break
-        PLEAS_CONV_LAUNCH(0); PLEAS_CONV_LAUNCH(1); PLEAS_CONV_LAUNCH(2); PLEAS_CONV_LAUNCH(3); PLEAS_CONV_LAUNCH(4);
-        PLEAS_CONV_LAUNCH(5); PLEAS_CONV_LAUNCH(6); PLEAS_CONV_LAUNCH(7); PLEAS_CONV_LAUNCH(8); PLEAS_CONV_LAUNCH(9);
-#undef PLEAS_CONV_LAUNCH
+    const bool split = arith_mode() == 1 && fwd_form_splits(form);
+#define PLEAS_CONV_LAUNCH(F, S, B) case F: hipLaunchKernelGGL((conv2d_fwd_kernel<F, S, B>), grid, dim3(fThreads), lds, st, d, tms); break
+#define PLEAS_CONV_FORMS(B)                                                                                              \
+    if (split) {                                                                                                         \
+        switch (form) {                                                                                                  \
+            PLEAS_CONV_LAUNCH(4, 1, B); PLEAS_CONV_LAUNCH(6, 1, B); PLEAS_CONV_LAUNCH(7, 1, B); PLEAS_CONV_LAUNCH(9, 1, B); \
+        }                                                                                                                \
+    } else {                                                                                                             \
+        switch (form) {                                                                                                  \
+            PLEAS_CONV_LAUNCH(0, 0, B); PLEAS_CONV_LAUNCH(1, 0, B); PLEAS_CONV_LAUNCH(2, 0, B); PLEAS_CONV_LAUNCH(3, 0, B); \
+            PLEAS_CONV_LAUNCH(4, 0, B); PLEAS_CONV_LAUNCH(5, 0, B); PLEAS_CONV_LAUNCH(6, 0, B); PLEAS_CONV_LAUNCH(7, 0, B); \
+            PLEAS_CONV_LAUNCH(8, 0, B); PLEAS_CONV_LAUNCH(9, 0, B);                                                      \
+        }                                                                                                                \
     }
+    if (bn) {
+        PLEAS_CONV_FORMS(1)
+    } else {
+        PLEAS_CONV_FORMS(0)
+    }
+#undef PLEAS_CONV_FORMS
+#undef PLEAS_CONV_LAUNCH
     PLEAS_LAUNCH_CHECK("conv2d_fwd_kernel");
     return PLEAS_OK;
+}
+
+extern "C" int pleas_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int Hin, int Win,
+                                int Cout, int KH, int KW, int stride, int pad, int flags, void* stream_) {
+    return conv2d_launch(x, w, bias, y, nullptr, nullptr, nullptr, nullptr, 0, N, Cin, Hin, Win, Cout, KH, KW, stride, pad, flags,
+                         stream_);
+}
+
+extern "C" int pleas_conv2d_bn_act_fwd(const float* x, const float* w, const float* bias, float* y, const float* scale,
+                                       const float* shift, const float* res, float* z, int relu, int N, int Cin, int Hin,
+                                       int Win, int Cout, int KH, int KW, int stride, int pad, int flags, void* stream_) {
+    if (!scale || !shift || !z) return bad_arg("conv2d_bn_act_fwd: null pointer");
+    return conv2d_launch(x, w, bias, y, scale, shift, res, z, relu, N, Cin, Hin, Win, Cout, KH, KW, stride, pad, flags, stream_);
 }
 
 extern "C" int pleas_fwd_batch(const pleas_fwd_layer* layers, int n_layers, float* loss, void* ws, size_t ws_bytes,

@@ -98,7 +98,7 @@ __device__ __forceinline__ void gram_tile(const GramGeom& g, float* smem, const 
     const int wm = wave >> 1, wn = wave & 1;
     const int i0 = tm * TILE, j0 = tn * TILE;
 
-    const int srow = tid / LANES_PER_ROW;
+    const int srow = SPLIT ? split_stage_row(tid / LANES_PER_ROW) : tid / LANES_PER_ROW;      // SPLIT: VEC == 4, 32 rows per pass
     const int scol = (tid % LANES_PER_ROW) * VEC;
 
     Stage<PASSES, VEC> ra, rb;

@@ -792,6 +792,34 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], strid
     return out
 
 
+def conv2d_bn_act(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], stride: int, pad: int, kpos_major: bool,
+                  scale: torch.Tensor, shift: torch.Tensor, res: Optional[torch.Tensor], relu: bool):
+    """``y = conv2d(x, w, bias)`` and ``z = bn_act(y, scale, shift, res, relu)`` from ONE launch (``pleas_conv2d_bn_act_fwd``):
+    the activated image is written from the registers that hold y, bit for bit what ``bn_act`` makes of y.  Returns ``(y, z)``."""
+    _need_gpu(x, w, scale, shift)
+    if x.dim() != 4 or w.dim() != 4 or not x.is_contiguous() or not w.is_contiguous():
+        raise PleasHipError("conv2d_bn_act: contiguous 4-D tensors expected")
+    N, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    KH, KW = (w.shape[1], w.shape[2]) if kpos_major else (w.shape[2], w.shape[3])
+    if (w.shape[3] if kpos_major else w.shape[1]) != Cin:
+        raise PleasHipError("conv2d_bn_act: %d input channels vs a weight of %s" % (Cin, tuple(w.shape)))
+    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    if scale.numel() != Cout or shift.numel() != Cout or scale.dtype != torch.float32 or shift.dtype != torch.float32:
+        raise PleasHipError("conv2d_bn_act: scale / shift must be fp32 vectors of %d channels" % Cout)
+    if res is not None and (tuple(res.shape) != (N, Cout, Ho, Wo) or res.dtype != torch.float32 or not res.is_contiguous()
+                            or res.device != x.device):
+        raise PleasHipError("conv2d_bn_act: the identity must be a contiguous fp32 tensor shaped like the output")
+    y = torch.empty((N, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    z = torch.empty_like(y)
+    check(_lib.lib().pleas_conv2d_bn_act_fwd(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                             y.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                             res.data_ptr() if res is not None else None, z.data_ptr(), 1 if relu else 0,
+                                             N, Cin, H, W, Cout, KH, KW, stride, pad,
+                                             FwdBatch.KPOS_MAJOR if kpos_major else 0, _stream()), "pleas_conv2d_bn_act_fwd")
+    return y, z
+
+
 class WgradBatch:
     """Weight gradients of all merged layers of one update in ONE grouped launch (``pleas_wgrad_batch``).
     ``add`` per layer (operands must stay unmodified until ``flush``), ``flush`` once per update."""

@@ -13,6 +13,8 @@ be fused.  ``fuse_bn_act`` rewrites an fx trace of the model:
 
     Conv2d (k x k, dense, undilated)   =>  HipConv(conv)(x): ``hip_ops.conv2d`` -- the grouped forward's tile forms as a plain
                                            convolution, bit-for-bit repeatable (``SOURCE_CONV``)
+    HipConv(conv)(x) -> bn_act(...)    =>  HipConvBnAct: ONE launch that stores the convolution's output (the hooks' tensor) and
+                                           its activated image from the same registers (``SOURCE_CONV_BN``)
 
 ``scale = weight / sqrt(running_var + eps)`` and ``shift = bias - running_mean * scale`` are computed
 once in fp64.  The hooked modules are the SAME objects in the rewritten GraphModule, so hooks
@@ -45,6 +47,9 @@ from .. import hip_ops
 #            5.27 s; profiles/r05_exp_source_conv.txt).
 #   "kxk"    only the layers with k > 1 (the 1 x 1 layers on the vendor's GEMM: measured repeatable);  "vendor"  none (rounds 1-4).
 SOURCE_CONV = os.environ.get("PLEAS_SOURCE_CONV", "all")
+# "1" (default): an own convolution whose only consumer is an eval-mode BatchNorm chain takes that chain into its epilogue
+# (``hip_ops.conv2d_bn_act``: same bits as the two launches, the convolution's output is not read back); "0": two launches.
+SOURCE_CONV_BN = os.environ.get("PLEAS_SOURCE_CONV_BN", "1")
 
 
 def own_conv_ok(mod: nn.Module, mode: Optional[str] = None) -> bool:
@@ -97,6 +102,33 @@ class HipConv:
 
 def _bn_act(x, scale, shift, res, relu):
     return hip_ops.bn_act(x, scale, shift, res, relu)
+
+
+class HipConvBnAct:
+    """``bn_act(HipConv(conv)(x), scale, shift, res, relu)`` as ONE launch (``hip_ops.conv2d_bn_act``): the convolution's
+    output is still written -- the module's forward hooks get it, it is a regression target of the PLeaS loop -- and the
+    activated image is stored beside it from the same registers.  Anything the fused kernel does not take (CPU tensors,
+    autograd, an identity that is a strided view) goes through the two calls it replaces, as does the activation after a
+    hook that RETURNS another output."""
+
+    def __init__(self, own: HipConv):
+        self.own = own
+        self.__name__ = self.__qualname__ = own.__name__ + "_bn_act"
+
+    def __call__(self, x, scale, shift, res, relu):
+        own, conv = self.own, self.own.conv
+        if (not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4 or not conv.weight.is_cuda or scale.dim() != 1
+                or (torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad))
+                or (res is not None and (not res.is_contiguous() or res.dtype != torch.float32 or res.data_ptr() % 16))):
+            return _bn_act(own(x), scale, shift, res, relu)
+        y, z = hip_ops.conv2d_bn_act(x if x.is_contiguous() else x.contiguous(), own.weight(), conv.bias, own.stride, own.pad,
+                                     own.kpos, scale, shift, res, relu)
+        if own.fire_hooks and conv._forward_hooks:
+            for hook in list(conv._forward_hooks.values()):
+                out = hook(conv, (x,), y)
+                if out is not None:
+                    y, z = out, None
+        return z if z is not None else _bn_act(y, scale, shift, res, relu)
 
 
 def _bn_act_pool(x, scale, shift, kernel, stride, padding, relu):
@@ -275,6 +307,21 @@ def fuse_bn_act(model: nn.Module, op: Callable = _bn_act, train_stats: bool = Fa
                 node.replace_all_uses_with(own)
                 graph.erase_node(node)
                 folded += 1
+        if SOURCE_CONV_BN == "1":
+            # an own convolution consumed by one eval-mode chain only (constants, not per-batch statistics): one launch
+            for node in list(graph.nodes):
+                if not (node.op == "call_function" and node.target is op and isinstance(node.args[0], torch.fx.Node)):
+                    continue
+                src, s = node.args[0], node.args[1]
+                if not (src.op == "call_function" and isinstance(src.target, HipConv) and len(src.users) == 1
+                        and isinstance(s, torch.fx.Node) and s.op == "get_attr"):
+                    continue
+                with graph.inserting_before(node):
+                    both = graph.create_node("call_function", HipConvBnAct(src.target), (src.args[0],) + tuple(node.args[1:]), {},
+                                             name=src.name + "_bn_act")
+                node.replace_all_uses_with(both)
+                graph.erase_node(node)
+                graph.erase_node(src)
     if folded == 0:
         return None
     graph.lint()

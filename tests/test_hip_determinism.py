@@ -19,7 +19,7 @@ import test_hip_fullsize_dp as dp
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("geo", [
+GEOMETRIES = [
     # (N, Cin, H, W, Cout, k, stride, pad, bias)
     (4, 64, 56, 56, 64, 3, 1, 1, False),       # flat-shift k x k form, kernel-position-major weights
     (3, 128, 28, 28, 96, 3, 1, 1, True),       # Cout not a multiple of the tile, bias
@@ -30,7 +30,10 @@ pytestmark = pytest.mark.gpu
     (2, 48, 15, 15, 24, 3, 1, 0, False),       # "valid" padding, Cin % 32 != 0
     (3, 256, 14, 14, 1024, 1, 1, 0, False),    # 1 x 1 (mode "all")
     (2, 256, 56, 56, 512, 1, 2, 0, False),     # strided 1 x 1 (mode "all")
-])
+]
+
+
+@pytest.mark.parametrize("geo", GEOMETRIES)
 def test_conv2d_vs_fp64_and_repeatable(geo):
     from pleas_merging_amd import hip_ops
 
@@ -52,12 +55,46 @@ def test_conv2d_vs_fp64_and_repeatable(geo):
         assert torch.equal(hip_ops.conv2d(x, wk, b, stride, pad, kpos), got)
 
 
+@pytest.mark.parametrize("arith", ["fp32", "split_bf16"])
+@pytest.mark.parametrize("geo", GEOMETRIES + [(2, 64, 56, 56, 256, 1, 1, 0, False),      # short-K 1 x 1, 128-row tiles
+                                              (3, 2048, 7, 7, 512, 1, 1, 0, False)])     # 1 x 1 on 7 x 7 images
+def test_conv2d_bn_act_equals_the_two_launches_it_replaces(geo, arith):
+    """``pleas_conv2d_bn_act_fwd``: the convolution's output AND its BatchNorm / add / ReLU image from one launch -- both
+    ``torch.equal`` to ``conv2d`` followed by ``bn_act`` (with and without identity, with and without ReLU), every tile form,
+    both arithmetics."""
+    from pleas_merging_amd import hip_ops
+
+    N, Cin, H, W, Cout, k, stride, pad, has_bias = geo
+    g = torch.Generator().manual_seed(sum(geo) + 1)
+    x = torch.randn(N, Cin, H, W, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).cuda()
+    b = torch.randn(Cout, generator=g).cuda() if has_bias else None
+    scale = (0.5 + torch.rand(Cout, generator=g)).cuda()
+    shift = torch.randn(Cout, generator=g).cuda()
+    kpos = k > 1 and Cin % 32 == 0
+    wk = w.permute(0, 2, 3, 1).contiguous() if kpos else w
+    from pleas_merging_amd import _lib
+
+    lib = _lib.lib()
+    assert lib.pleas_arith_get() == 0
+    lib.pleas_arith(1 if arith == "split_bf16" else 0)
+    try:
+        y0 = hip_ops.conv2d(x, wk, b, stride, pad, kpos)
+        res = torch.randn(y0.shape, generator=g).cuda()
+        for identity, relu in ((None, True), (res, True), (None, False), (res, False)):
+            y, z = hip_ops.conv2d_bn_act(x, wk, b, stride, pad, kpos, scale, shift, identity, relu)
+            assert torch.equal(y, y0), (geo, "y")
+            assert torch.equal(z, hip_ops.bn_act(y0, scale, shift, identity, relu)), (geo, identity is not None, relu)
+    finally:
+        lib.pleas_arith(0)
+
+
 def test_source_forward_is_repeatable_and_matches_the_modules():
     """One frozen-source forward of a ResNet-101 twice: every tap bit-equal; and against the model's own modules (vendor
     convolutions + vendor BatchNorm) to fp32 rounding."""
     from pleas_merging_amd import resnet as zoo
     from pleas_merging_amd.methods.pleas_merging import FrozenSources
-    from pleas_merging_amd.methods.source_forward import HipConv
+    from pleas_merging_amd.methods.source_forward import HipConv, HipConvBnAct
 
     g = torch.Generator().manual_seed(5)
     x = torch.randn(8, 3, 224, 224, generator=g).cuda()
@@ -68,8 +105,11 @@ def test_source_forward_is_repeatable_and_matches_the_modules():
         zoo.calibrate_bn(m, [x])
         models.append(m.eval())
     src = FrozenSources(*models)
-    own = sum(1 for n in src.src1.graph.nodes if n.op == "call_function" and isinstance(n.target, HipConv))
+    calls = [n.target for n in src.src1.graph.nodes if n.op == "call_function"]
+    own = sum(1 for t in calls if isinstance(t, (HipConv, HipConvBnAct)))
     assert own == 104, own         # every convolution of a ResNet-101 (SOURCE_CONV = "all"); the classifier stays a vendor GEMM
+    # ... and all but the stem (whose chain ends in the pooling pass) carry their BatchNorm chain in the epilogue
+    assert sum(1 for t in calls if isinstance(t, HipConvBnAct)) == 103
     runs = []
     for _ in range(3):
         _, (in1, out1), (in2, out2), _ev = src.launch(x)
