@@ -394,7 +394,7 @@ def time_normal_eq(spec, m1, m2, perm, costs, loader, ratio, sources_per_forward
             "fp64_fallbacks_note": "systems the fp32 HIP Cholesky flagged (non-positive pivot) and torch.linalg redid in fp64",
             "kernels_ms": {k: {"launches": v[0], "total_ms": round(v[1], 2)} for k, v in sorted(p.items()) if v[0]},
             "kernels_note": "own kernels of this leg by HIP events (on several streams: they overlap); what is left of accumulate_s is "
-                            "the vendor source forwards (see `vendor`), the bias statistics and host dispatch",
+                            "what the events do not bracket (the classifier's GEMM, elementwise torch ops), the bias statistics and host dispatch",
             "neq_batch_kernel": {"bound": "mfma", "launches": rec[0], "avg_launch_us": round(rec[1] * 1e3 / max(rec[0], 1), 1),
                                  "achieved": round(ach, 1), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                                  "frac": round(ach / FP32_MATRIX_PEAK_TFLOPS, 3),
@@ -1055,7 +1055,7 @@ def main():
         src_s, src_per = time_sources_alone(m1, m2, pool, n_pleas, per=cfg["sources_per_forward"] or 2)
         vendor = {"source_forwards_alone_s_per_job": round(src_s, 3), "ms_per_update": round(src_per * 1e3, 3),
                   "share_of_value": round(src_s / value, 3),
-                  "note": "frozen source forwards of the PLeaS phase (convolutions as config.source_convolutions says + pleas_bn_act, "
+                  "note": "frozen source forwards of the PLeaS phase (convolutions as config.source_convolutions says, "
                           "both models, %d samples per forward) with nothing else on the GPU; the key keeps its rounds 1-4 name; "
                           "rocprofv3 kernel shares: profiles/" % ((cfg["sources_per_forward"] or 2) * args.batch)}
     alt_arith = None
@@ -1150,7 +1150,9 @@ def main():
                 "matching_mode": args.match_mode,
                 "source_convolutions": {"kxk": "k x k layers of the frozen source / twin forwards on the library's own kernel "
                                                    "(pleas_conv2d_fwd: repeatable bits), 1 x 1 layers on the vendor's GEMM",
-                                            "all": "every convolution of the frozen source / twin forwards on the library's own kernel",
+                                            "all": "every convolution of the frozen source / twin forwards on the library's own kernel"
+                                                   + (", the PLeaS phase's with their BatchNorm / add / ReLU chain in the epilogue"
+                                                      if os.environ.get("PLEAS_SOURCE_CONV_BN", "1") == "1" else ""),
                                             "vendor": "MIOpen / Tensile for every convolution of the frozen source / twin forwards "
                                                       "(rounds 1-4; not run-to-run deterministic)"}[source_conv_mode()],
                 "not_in_value": "get_permutation_spec %.2f s (host, once per model)" % spec_s,
