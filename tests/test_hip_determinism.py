@@ -146,6 +146,45 @@ def test_source_forward_is_repeatable_and_matches_the_modules():
     print("fused source forward vs fp64, worst layer %s: %.2e (the model's own modules there: %.2e)" % (worst[2], worst[0], worst[1]))
 
 
+def test_fused_epilogue_taps_equal_the_two_launch_graph(monkeypatch):
+    """The frozen-source graph with the BatchNorm chains in the convolutions' epilogues (default) against the graph that runs
+    ``conv2d`` and ``bn_act`` as two launches (``SOURCE_CONV_BN = "0"``): every hooked input and output ``torch.equal``, on a
+    ResNet-50 at two batch sizes (the second one with pixel tiles that straddle samples)."""
+    from pleas_merging_amd import resnet as zoo
+    from pleas_merging_amd.methods import source_forward
+    from pleas_merging_amd.methods.pleas_merging import FrozenSources
+    from pleas_merging_amd.methods.source_forward import HipConvBnAct
+
+    g = torch.Generator().manual_seed(11)
+    xs = [torch.randn(n, 3, 224, 224, generator=g).cuda() for n in (4, 3)]
+    models = []
+    for seed in (0, 1):
+        torch.manual_seed(seed)
+        m = zoo.MODELS["resnet50"](num_classes=100).cuda()
+        zoo.calibrate_bn(m, [xs[0]])
+        models.append(m.eval())
+
+    def taps(fused):
+        monkeypatch.setattr(source_forward, "SOURCE_CONV_BN", "1" if fused else "0")
+        src = FrozenSources(*models)
+        n = sum(1 for nd in src.src1.graph.nodes if nd.op == "call_function" and isinstance(nd.target, HipConvBnAct))
+        assert n == (52 if fused else 0), n
+        out = []
+        for x in xs:
+            _, (in1, out1), (in2, out2), _ev = src.launch(x)
+            torch.cuda.synchronize()
+            out.append([{k: v.clone() for k, v in t.items()} for t in (in1, out1, in2, out2)])
+        src.close()
+        return out
+
+    a, b = taps(True), taps(False)
+    for per_x_a, per_x_b in zip(a, b):
+        for ta, tb in zip(per_x_a, per_x_b):
+            assert ta.keys() == tb.keys() and len(ta) == 54
+            for k in ta:
+                assert torch.equal(ta[k], tb[k]), k
+
+
 def test_rn101_job_twice_is_bit_identical(tmp_path):
     """The ResNet-101 job of test_hip_fullsize_dp (matching over 2 batches -> 71 LAPs -> partial merge at ratio 0.5 -> 5 updates
     with grouped source forwards) run twice in one process: costs, assignments, trained weights and losses ``torch.equal``."""
