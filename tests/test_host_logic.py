@@ -462,6 +462,33 @@ def test_source_forward_rewrite_keeps_values_and_hooks(tiny_bottleneck):
     model.eval()
 
 
+def test_source_graph_joins_convolutions_with_their_batchnorm_chain(monkeypatch):
+    """Graph structure of the default frozen-source rewrite (no GPU): every dense square Conv2d becomes an own-kernel call, and a
+    convolution whose ONLY consumer is an eval-mode BatchNorm chain carries that chain (``HipConvBnAct``: conv -> bn -> relu,
+    conv3 -> bn3 -> + identity -> relu, downsample conv -> bn); the stem, whose chain ends in the pooling pass, a convolution
+    with a second consumer, and ``SOURCE_CONV_BN = "0"`` keep two calls."""
+    from pleas_merging_amd import resnet as zoo
+    from pleas_merging_amd.methods import source_forward as sf
+
+    torch.manual_seed(5)
+    rn = zoo.resnet50(num_classes=10).eval()
+    calls = lambda gm: [n.target for n in gm.graph.nodes if n.op == "call_function"]
+    gm = sf.fuse_bn_act(rn)
+    fused = [t for t in calls(gm) if isinstance(t, sf.HipConvBnAct)]
+    assert len(fused) == 52 and sum(1 for t in calls(gm) if isinstance(t, sf.HipConv)) == 1          # 53 convolutions, the stem alone
+    assert not [n for n in gm.graph.nodes if n.op == "call_module" and isinstance(rn.get_submodule(n.target), torch.nn.Conv2d)]
+    assert sum(1 for t in calls(gm) if t is sf._bn_act) == 0
+    # identity operands: 16 bottleneck blocks end in conv3 -> bn3 -> (+ identity) -> relu
+    with_res = [n for n in gm.graph.nodes if n.op == "call_function" and isinstance(n.target, sf.HipConvBnAct) and n.args[3] is not None]
+    assert len(with_res) == 16 and all(n.args[4] is True for n in with_res)
+    # the same module objects: hooks registered on the model fire from the rewritten graph
+    assert all(t.own.conv is rn.get_submodule(name) for t, name in [(fused[0], "layer1.0.conv1")])
+    monkeypatch.setattr(sf, "SOURCE_CONV_BN", "0")
+    two = sf.fuse_bn_act(rn)
+    assert not [t for t in calls(two) if isinstance(t, sf.HipConvBnAct)]
+    assert sum(1 for t in calls(two) if isinstance(t, sf.HipConv)) == 53 and sum(1 for t in calls(two) if t is sf._bn_act) == 52
+
+
 def test_split_twin_graph_defers_sinks_and_keeps_inplace_targets(tiny_bottleneck):
     """The two-stream twin graph (model2's chain, then model1's, then the sinks) sees the same activations as the
     interleaved one -- also for a model that overwrites tracked tensors in place (``out += identity``, ``relu_``)."""
